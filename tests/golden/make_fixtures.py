@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Regenerate the committed fixtures under tests/golden/ (run in the build container only).
+
+Inputs : /root/reference/docs/src/Rijke_mm.msh  (a DATA file shipped with the reference's docs,
+         MIT licence, see /root/reference/LICENSE) -- parsed, never copied.
+Outputs: rijke_p1.npz   P1 Helmholtz terms M, K, C, Q of the Rijke-tube tutorial as CSR arrays
+                        (derived data; the discretisation is oracle/helmholtz_p1.py)
+         golden.json    the recorded tutorial outputs G1..G9 that pin the oracle,
+                        each with the reference file:line it was read from.
+No reference source text is stored: only numbers the reference's executed tutorials print.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from oracle import helmholtz_p1 as H  # noqa: E402
+
+REF = "/root/reference"
+
+
+def main():
+    mesh, L = H.rijke_tube(os.path.join(REF, "docs/src/Rijke_mm.msh"), n=0.01, tau=0.001)
+    out = {"d": np.int64(L.size()),
+           "npoints": np.int64(len(mesh.points)), "ntriangles": np.int64(len(mesh.triangles)),
+           "ntetrahedra": np.int64(len(mesh.tetrahedra))}
+    for t in L.terms:
+        if t.operator == "__aux__":
+            continue            # aux = -M, rebuilt by the loader
+        A = sp.csr_matrix(t.coeff)
+        A.sum_duplicates(); A.sort_indices()
+        out[f"{t.operator}_indptr"] = A.indptr.astype(np.int32)
+        out[f"{t.operator}_indices"] = A.indices.astype(np.int32)
+        out[f"{t.operator}_data"] = A.data.astype(np.complex128)
+    np.savez_compressed(os.path.join(HERE, "rijke_p1.npz"), **out)
+
+    golden = {
+        "_about": "Recorded outputs of the reference's executed tutorials (SURVEY.md section 4).",
+        "G1": {"src": "examples/tutorials/tutorial_04_perturbation_theory.ipynb:128-155",
+               "setup": "Rijke_mm.msh P1, n=0.01, tau=0.001, Y=1e15; householder(L,340*2pi,maxiter=20,tol=1e-11)",
+               "omega": [1710.6977772393461, 9.615018460173488], "iterations": 7, "flag": 0,
+               "iterates": [[2136.2830044410593, 0.0], [1753.640443755553, 8.160610349893785],
+                            [1711.2293969397867, 9.58445933911067], [1710.6978605746078, 9.615009671129867],
+                            [1710.6977772393602, 9.615018460179712]]},
+        "G2": {"src": "examples/tutorials/tutorial_04_perturbation_theory.ipynb:288-308",
+               "setup": "G1 then perturb_fast!(sol,L,:tau,20)",
+               "taylor": [[1710.6977772393461, 9.615018460173488], [16655.767682558846, -1972.5369656026314],
+                          [-1.2612982476560106e6, -1.46322883044807e7], [-8.808906967838312e9, 1.1615582738796182e8],
+                          [-5.873840733061559e11, 4.175332269859226e12], [1.7004887170778765e15, 7.439153396440475e14],
+                          [6.058284950153509e17, -6.190897825855365e17], [-1.8938118510974376e20, -4.003170158460829e20],
+                          [-2.3191390766688626e23, 2.898858067332429e22], [-2.275112427776431e25, 1.2162923188570618e26],
+                          [5.799143769580233e28, 3.183913640454199e28], [2.6380804905911956e31, -2.44451708180038e31],
+                          [-8.222422195967745e33, -1.8038057337062285e34], [-1.0957581029026753e37, 1.211309773723197e36],
+                          [-1.2703381232412134e39, 6.041956342213871e39], [3.012726806969943e42, 1.744584592236548e42],
+                          [1.4744387490957574e45, -1.3149324622042034e45], [-4.5028654465230355e47, -1.0334597113739691e48],
+                          [-6.434729914382895e50, 6.048576186744849e49], [-8.243537285189499e52, 3.6288343760940155e53],
+                          [1.8444413529644624e56, 1.1066598160933247e56]]},
+        "G3": {"src": "examples/tutorials/tutorial_04_perturbation_theory.ipynb:385-387 and cells 14,19",
+               "setup": "G1, tau -> tau+1e-5",
+               "omega_exact": [1710.864199971756, 9.593830019670127],
+               "taylor20_estimate": [1710.8641999717368, 9.593830019669932],
+               "taylor1_estimate_over_2pi": [272.4515667269969, 1.508301985260934]},
+        "G4": {"src": "docs/src/tutorial_04_perturbation_theory.md:199-210,241-271 (n=1 baseline G5, order 30)",
+               "taylor30_estimate_over_2pi_at_tau_plus_5e-4": [145.8978874014616, 78.67497208762059],
+               "conv_radius": [0.0026438071359421856, 0.0018498027477203886, 0.0012670310435927681, 0.0009886548876531008,
+                               0.0009100554815832927, 0.0008709697017278116, 0.000838910762099998, 0.0008140058757174155,
+                               0.0007955250149644752, 0.0007813536279922974, 0.0007700125089152769, 0.0007607027504841114,
+                               0.000752936147548007, 0.0007463656620716248, 0.0007407359084332154, 0.0007358585624584575,
+                               0.0007315926734366027, 0.0007278304643904657, 0.0007244879957019495, 0.0007214989316859786,
+                               0.0007188101801265639, 0.0007163787543387638, 0.0007141694816882979, 0.0007121533078940557,
+                               0.0007103060243302641, 0.0007086072999209774, 0.000707039935855723, 0.0007055892855979911,
+                               0.0007042427990056821, 0.0007029896606802446]},
+        "G4b": {"src": "examples/tutorials/tutorial_04_perturbation_theory.ipynb:608,640,676-685",
+                "note": "the notebook's order-30 cells were executed on a stale kernel state (their conv. radii do not match "
+                        "its own order-20 coefficients); only the householder re-solve below is a self-contained pin",
+                "tau": 0.001 + 0.0008798274754933992 + 0.001,
+                "omega_n0.01": [1707.4565281774599, -9.11764397194075]},
+        "G5": {"src": "docs/src/tutorial_04_perturbation_theory.md:57,75-88",
+               "setup": "Rijke_mm.msh P1, n=1, tau=0.001; mslp(L,340*2pi,maxiter=20,tol=1e-11)",
+               "omega": [1075.325211506839, 372.1017670372039], "iterations": 8, "flag": 0},
+        "G6": {"src": "docs/src/tutorial_04_perturbation_theory.md:128,142,171",
+               "setup": "G5 + perturb_fast!(sol,L,:tau,20); tau -> 0.0015",
+               "taylor20_estimate": [916.7085040155473, 494.3258317478708],
+               "omega_exact": [916.7036137579256, 494.32932528479967],
+               "taylor_6digits": [[1075.33, 372.102], [-2.62868e5, 3.40796e5], [-1.79944e8, -1.475e8],
+                                  [9.4741e10, -1.57309e11], [1.66943e14, 8.14274e13], [-8.3483e16, 1.86246e17]]},
+        "G7": {"src": "docs/src/tutorial_01_rijke_tube.md:202-213,259-269",
+               "setup": "Rijke passive flame (n=0), beyn(L,Gamma,l=5,N=256), Gamma=[150+5i,150-5i,1000-5i,1000+5i]*2pi",
+               "modes_hz": [272, 695], "active_growth_rate": 59.22},
+        "G8": {"src": "docs/src/tutorial_00_NLEVP.md:32-42,144,174,252,273-286,315-325",
+               "setup": "qep1: T(l)=l^2*A2+l*A1+A0, Gamma=[2+2i,-2+2i,-2-2i,2-2i], beyn(T,Gamma,l=6)",
+               "A2": [[0, 6, 0], [0, 6, 0], [0, 0, 1]], "A1": [[1, -6, 0], [2, -7, 0], [0, 0, 0]],
+               "A0": [[1, 0, 0], [0, 1, 0], [0, 0, 1]],
+               "eigs_inside": [[1 / 3, 0], [0.5, 0], [1, 0], [0, 1], [0, -1]], "n_small_sigma": 1,
+               "mslp_from_0_tol1e-10": {"omega": [1 / 3, 0], "iterations": 6}, "count_poles_and_zeros": 5},
+        "G9": {"src": "docs/src/tutorial_01_rijke_tube.md:63-65", "points": 1006, "triangles": 1562, "tetrahedra": 3380},
+    }
+    with open(os.path.join(HERE, "golden.json"), "w") as f:
+        json.dump(golden, f, indent=1)
+    print("wrote rijke_p1.npz, golden.json")
+
+
+if __name__ == "__main__":
+    main()
