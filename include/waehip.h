@@ -1,0 +1,160 @@
+/* waehip.h -- C ABI of libwaehip.so: the MI355X (gfx950) NLEVP hot path for WavesAndEigenvalues.jl.
+ *
+ * The reference (Julia, serial, CPU) has no FFI of its own; the drop-in boundary is the method surface its
+ * solvers use on a LinearOperatorFamily.  Each entry below names the reference call sites
+ * it replaces (paths relative to the reference repository root).  Conventions:
+ *   - every function returns int: 0 ok, >0 warning (e.g. WAE_WARN_MAXITER), <0 error; no C++ exception
+ *     crosses the boundary; wae_last_error() returns a thread-local message for the last failure.
+ *   - complex numbers are interleaved (re,im) doubles == Julia ComplexF64 == C99 double _Complex.
+ *   - dense arrays are column-major (Julia Array) with leading dimension d unless stated.
+ *   - the caller owns all host buffers and must keep them alive for the duration of the call only
+ *     (Julia: GC.@preserve); the library copies inputs at wae_family_create.
+ *   - calls on one handle must be serialised by the caller (the reference is single-threaded).
+ *   - no torch / HIP types appear in signatures; "dev" pointers are raw device addresses (uint64-castable).
+ */
+#ifndef WAEHIP_H
+#define WAEHIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wae_family wae_family;      /* opaque: all terms A_k resident in HBM + solver workspaces */
+
+/* return codes: mapped by the host wrappers onto the reference's itsol_* flags
+ * (src/NLEVP/iterative_solvers.jl:4-14), like the reference maps exceptions (:192-210). */
+#define WAE_OK                 0
+#define WAE_WARN_MAXITER       1   /* inner Krylov solve hit maxit on >=1 column  -> itsol_maxiter            */
+#define WAE_WARN_STAGNATION    2   /*                                             -> itsol_slow_convergence   */
+#define WAE_ERR_INVALID       -1   /* bad argument                                -> itsol_impossible         */
+#define WAE_ERR_BREAKDOWN     -2   /* singular coarse operator / Krylov breakdown -> itsol_singular_exception */
+#define WAE_ERR_EIGS          -3   /* shift-invert Arnoldi did not converge       -> itsol_arpack_exception   */
+#define WAE_ERR_NAN           -4   /*                                             -> itsol_isnan              */
+#define WAE_ERR_HIP           -5   /* HIP runtime failure                         -> itsol_unknown            */
+
+/* operator applied: N = L, T = L^T, C = L^H (Julia `A'`: Householder.jl:101, iterative_solvers.jl:398,572) */
+#define WAE_OP_N 0
+#define WAE_OP_T 1
+#define WAE_OP_C 2
+
+/* storage orientation of the term matrices handed to wae_family_create */
+#define WAE_CSC 0   /* Julia SparseMatrixCSC (colptr,rowval,nzval) */
+#define WAE_CSR 1
+
+const char *wae_last_error(void);
+int wae_device_count(int *n);
+/* version / build info string (static) */
+const char *wae_version(void);
+
+/* -- family ------------------------------------------------------------------------------------------
+ * Upload the T term matrices of a LinearOperatorFamily once (replaces nothing in the reference by itself:
+ * it is what makes `L(z)` (src/NLEVP/LinOpFam.jl:482-529) a device-resident operator instead of a new
+ * SparseMatrixCSC per call).  Re-create only if a term's matrix changes, not if L.params change.
+ *   d            dimension (size(L), LinOpFam.jl:385-393)
+ *   T            number of terms (length(L.terms)), including the "__aux__" term if present
+ *   index_bytes  4 (UInt32/Int32, Helmholtz.jl:407-408,515) or 8 (Int64)
+ *   base         0 or 1 (Julia)
+ *   orientation  WAE_CSC / WAE_CSR
+ *   ptr[k], idx[k], val[k]  per-term arrays: ptr has d+1 entries, idx/val have nnz_k entries
+ *   device       HIP device ordinal
+ */
+int wae_family_create(wae_family **out, int64_t d, int32_t T, int32_t index_bytes, int32_t base,
+                      int32_t orientation, const void *const *ptr, const void *const *idx,
+                      const double *const *val, int32_t device);
+int wae_family_destroy(wae_family *h);
+/* d, T, total nnz, and the algorithmic byte count of one spmv_sum with r right-hand sides over the terms
+ * whose coefficient is non-zero in `mask` (NULL = all):  sum_k[nnz_k*(16+4)+(d+1)*4] + 2*r*d*16 */
+int wae_family_info(const wae_family *h, int64_t *d, int32_t *T, int64_t *nnz_total);
+int64_t wae_family_spmv_bytes(const wae_family *h, const uint8_t *mask, int32_t r);
+
+/* -- Y = sum_k c_k op(A_k) X -------------------------------------------------------------------------
+ * Replaces `L(z)*x`, `L(z,1)*x`, `L(m,n)*w`, `M*v`, `A'*y`: LinOpFam.jl:482-529 followed by a sparse
+ * mat-vec (iterative_solvers.jl:307,399,571-572,581; perturbation.jl:339,352,413; Householder.jl:189-190).
+ *   coeffs  T complex scalars c_k = prod_j f_kj(params; derivs) evaluated on the host (LinOpFam.jl:466-477);
+ *           a term skipped by the functor (LinOpFam.jl:502-516) is passed as 0.
+ *   X, Y    d x r column-major complex, host memory.
+ */
+int wae_spmv_sum(wae_family *h, const double *coeffs, const double *X, double *Y, int32_t r, int32_t op);
+/* per-term inputs: Y = sum_k c_k A_k X_k, X = d x T column-major (regrouped perturbation recurrence,
+ * SURVEY appendix C; replaces the sum over (m,n) of `L(m,n)*w` at perturbation.jl:394-415). */
+int wae_spmv_sum_multi(wae_family *h, const double *coeffs, const double *X, double *Y);
+
+/* -- solver set-up ----------------------------------------------------------------------------------
+ * Build the multigrid hierarchy used to precondition every `L(z)\b` (smoothed aggregation on
+ * Re(sum_k c_ref_k A_k); every term is Galerkin-projected so that coarse operators are again families).
+ * Replaces the symbolic analysis UMFPACK repeats at every `\`/`lu` call (beyn.jl:65,257; perturbation.jl:329).
+ * Must be called once before wae_solve / wae_beyn_moments / wae_arnoldi_shiftinvert / wae_perturb.
+ * opts (may be NULL -> defaults): [0] strength threshold (0.02), [1] max coarse size (128),
+ *   [2] Jacobi weight (0.8), [3] pre/post sweeps (1), [4] GMRES restart (30), [5] penalty-row ratio (1e8),
+ *   [6] batch width (columns solved in lock-step, 64).
+ */
+int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts, int32_t nopts);
+
+typedef struct {
+    int32_t iters_max;      /* most iterations any column needed            */
+    int32_t iters_total;    /* sum over columns                              */
+    int32_t n_unconverged;  /* columns that stopped at maxit                 */
+    int32_t levels;         /* multigrid levels used                         */
+    double  relres_max;     /* max_b ||B_b - A X_b|| / ||B_b|| (true residual, recomputed)      */
+    double  seconds;        /* wall time of the device work                  */
+} wae_solve_info;
+
+/* -- X = op(sum_k c_k A_k)^{-1} B -------------------------------------------------------------------
+ * Replaces sparse `\` / `lu` + solve (UMFPACK): beyn.jl:65,257; iterative_solvers.jl:307,397-398,570-572;
+ * perturbation.jl:359,423,539.  ncoef = 1: one coefficient set for all r columns;
+ * ncoef = r: column j uses coeffs[j*T .. j*T+T) (independent systems solved in lock-step).
+ */
+int wae_solve(wae_family *h, const double *coeffs, int32_t ncoef, const double *B, double *X, int32_t r,
+              int32_t op, double tol, int32_t maxit, wae_solve_info *info);
+
+/* -- Beyn moments -------------------------------------------------------------------------------------
+ * The whole quadrature loop of `beyn` / `compute_moment_matrices` (beyn.jl:62-74,112-138,251-268):
+ *   A[:,:,p] = sum_j w_j z_j^p (sum_k c_jk A_k)^{-1} V ,  p = 0..2K-1
+ * npts points z[j] with effective weights w[j] (= GL weight * (b-a)/2), coefficient table npts x T
+ * (row j = coefficients of L(z_j)), V d x l column-major.  Output d x l x 2K column-major (host), or, with
+ * out_dev != 0, written to that device address instead (layout identical) so that the caller can reduce
+ * partial moments across GPUs with RCCL before copying to the host.
+ */
+int wae_beyn_moments(wae_family *h, int32_t npts, const double *z, const double *w, const double *coeff_table,
+                     const double *V, int32_t l, int32_t K, double tol, int32_t maxit, double *A_out,
+                     uint64_t out_dev, wae_solve_info *info);
+
+/* -- shift-invert Arnoldi factorisation for (A, M), A = sum cA_k A_k, M = sum cM_k A_k -----------------
+ * The device half of `Arpack.eigs(A,M,nev=nev,sigma=0,v0=v0)` and of the adjoint call on (A',M')
+ * (Householder.jl:100-101, iterative_solvers.jl:132-133):  m steps of Arnoldi on  op(A)^{-1} op(M)
+ * started from v0, every step one multigrid-GMRES solve on the device:
+ *      op(A)^{-1} op(M) V[:,0:m] = V[:,0:m+1] H ,   V^H V = I.
+ * The small (m x m) Hessenberg eigenproblem, Ritz extraction and restarts stay on the host side
+ * (Julia LinearAlgebra / numpy), as ARPACK's do.  op = WAE_OP_N (right) or WAE_OP_C (left: A^H, M^H).
+ *   H_out  (m+1) x m column-major complex;  V_out  d x (m+1) column-major complex.
+ *   If an invariant subspace ends the recurrence after j < m steps, the remaining columns of H_out / V_out
+ *   are zero (H[j+1,j] = 0 marks the end) and the call still returns WAE_OK.
+ */
+int wae_arnoldi_shiftinvert(wae_family *h, const double *coeffsA, const double *coeffsM, int32_t m,
+                            const double *v0, int32_t op, double tol, int32_t maxit, double *H_out,
+                            double *V_out, wae_solve_info *info);
+
+/* -- adjoint perturbation recurrence -----------------------------------------------------------------
+ * Replaces `perturb` / `perturb_disk` / `perturb_norm` (perturbation.jl:319-367,374-444,487-560) for a
+ * two-parameter expansion L(m,n) = d^m/dλ^m d^n/dε^n L /(m! n!):
+ *   coeff_table[(m*(N+1)+n)*T + k]  = coefficient of term k in L(m,n), m,n = 0..N  (0 where m+n>N)
+ *   v0, v0adj   base eigenvectors (un-normalised as the reference receives them)
+ *   norm_mode   0: perturb (no `c` normalisation)  1: perturb_disk  2: perturb_norm with Y = sum cY_k A_k
+ * Outputs lambda_out[N+1] (entry 0 untouched, the wrappers overwrite it: LinOpFam.jl:555), v_out d x (N+1).
+ */
+int wae_perturb(wae_family *h, const double *coeff_table, int32_t N, const double *v0, const double *v0adj,
+                int32_t norm_mode, const double *coeffsY, double tol, int32_t maxit, double *lambda_out,
+                double *v_out, wae_solve_info *info);
+
+/* -- measurement helpers (bench.py) --------------------------------------------------------------------
+ * Time `reps` launches of the fused multi-term SpMV on device-resident data with HIP events on the
+ * library's own stream; r right-hand sides.  ms_out = average milliseconds per launch. */
+int wae_bench_spmv(wae_family *h, const double *coeffs, int32_t r, int32_t reps, double *ms_out);
+/* device triad a = b + s*c over n doubles: measured streaming bandwidth in GB/s */
+int wae_bench_triad(int32_t device, int64_t n, int32_t reps, double *gbs_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,226 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (ctypes -> libwaehip.so), against the CPU
+oracle on the same inputs, and against the committed golden values of the reference's tutorials.
+
+Tolerances: fused SpMV-sum <= 1e-13 relative (max-norm per column); linear solves to the inner
+tolerance (reported true residual <= tol, solution <= 1e-8 relative vs the direct oracle solve);
+Householder/mslp eigenvalues <= 1e-10 relative; Beyn moments/eigenvalues <= 1e-8 relative; Taylor
+coefficients <= 1e-8 relative up to order 20.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import fixtures as F
+from oracle import solvers as OS
+from wae_amd import _lib
+from wae_amd.helmholtz import annulus
+from wae_amd.helmholtz.family import helmholtz_family
+from wae_amd.nlevp import (LinearOperatorFamily, Term, beyn, compute_moment_matrices, householder, inveriter,
+                           moments2eigs, mslp, perturb_fast_, pow1, pow2)
+
+pytestmark = pytest.mark.gpu
+G = F.golden()
+c = lambda p: complex(p[0], p[1])
+RNG = np.random.default_rng(0)
+
+
+def relerr(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def rijke():
+    Lo = F.rijke_family(n=0.7, tau=1.3e-3)
+    Lp = helmholtz_family(F.rijke_terms(), n=0.7, tau=1.3e-3)
+    yield Lo, Lp
+    Lp._drop_device()
+
+
+def test_native_library_is_loaded():
+    assert b"gfx950" in _lib.lib().wae_version()
+    assert _lib.device_count() >= 1
+
+
+@pytest.mark.parametrize("r", [1, 3, 8, 19])
+def test_spmv_sum_parity_rijke(rijke, r):
+    Lo, Lp = rijke
+    d = Lo.size()
+    X = RNG.standard_normal((d, r)) + 1j * RNG.standard_normal((d, r))
+    z = 1500.0 + 40j
+    for args in [(z,), (z, 1), (z, 2)]:
+        Ao = Lo(*args)
+        Ap = Lp(*args)
+        Yo = Ao @ X
+        assert relerr(Ap @ X, Yo) < 1e-13
+        assert relerr(Ap.H @ X, Ao.conj().T @ X) < 1e-13
+    x = X[:, 0]
+    assert relerr(Lp(z) @ x, Lo(z) @ x) < 1e-13          # 1-D input
+
+
+def test_spmv_sum_compact_and_householder_modes(rijke):
+    Lo, Lp = rijke
+    d = Lo.size()
+    x = RNG.standard_normal(d) + 1j * RNG.standard_normal(d)
+    for L in (Lo, Lp):
+        L.params["ω"] = 1000.0 + 5j
+        L.active = ["ω", "τ"]; L.mode = "compact"
+    try:
+        for m in range(3):
+            for n in range(3):
+                yo = Lo(m, n) @ x
+                assert relerr(Lp(m, n) @ x, yo) < 1e-13 or np.max(np.abs(yo)) == 0
+        for L in (Lo, Lp):
+            L.active = ["λ", "ω"]; L.mode = "householder"; L.params["λ"] = 0.3 + 0.2j
+        for m in range(2):
+            for n in range(3):
+                yo = Lo(m, n) @ x
+                assert relerr(Lp(m, n) @ x, yo) < 1e-13 or np.max(np.abs(yo)) == 0
+    finally:
+        for L in (Lo, Lp):
+            L.active = ["ω"]; L.mode = "all"
+
+
+def test_spmv_multi_parity(rijke):
+    Lo, Lp = rijke
+    d, T = Lo.size(), len(Lo.terms)
+    X = RNG.standard_normal((d, T)) + 1j * RNG.standard_normal((d, T))
+    cs = RNG.standard_normal(T) + 1j * RNG.standard_normal(T)
+    want = sum(cs[k] * (Lo.terms[k].coeff @ X[:, k]) for k in range(T))
+    got = Lp.device().spmv_multi(cs, X)
+    assert relerr(got, want) < 1e-13
+
+
+def test_spmv_annulus_small_all_batch_widths():
+    pb = annulus.build("small")
+    Lp = helmholtz_family(pb["terms"])
+    T = pb["terms"]
+    z = 2 * np.pi * (500 + 20j)
+    A = (z * z * T["M"] + T["K"] + z * 1e15 * T["C"] + np.exp(-1j * z * 1e-3) * T["Q"]).tocsr()
+    for r in (1, 2, 4, 8, 16, 33):
+        X = RNG.standard_normal((pb["d"], r)) + 1j * RNG.standard_normal((pb["d"], r))
+        assert relerr(Lp(z) @ X, A @ X) < 1e-13
+        assert relerr(Lp(z).H @ X, A.conj().T @ X) < 1e-13
+    assert Lp.device().spmv_bytes(r=1, mask=[1, 1, 1, 1, 0]) == sum(
+        T[k].nnz * 20 + (pb["d"] + 1) * 4 for k in "MKCQ") + 2 * pb["d"] * 16
+    Lp._drop_device()
+
+
+def test_dense_and_ragged_terms():
+    """qep1 (dense 3x3 terms) and a family with empty rows / an empty term."""
+    g = G["G8"]
+    T = LinearOperatorFamily()
+    T.push(Term(np.array(g["A2"], dtype=complex), (pow2,), (("λ",),), "λ^2", "A2"))
+    T.push(Term(np.array(g["A1"], dtype=complex), (pow1,), (("λ",),), "λ", "A1"))
+    T.push(Term(np.array(g["A0"], dtype=complex), (), (), "", "A0"))
+    z = 0.3 - 0.8j
+    want = z * z * np.array(g["A2"]) + z * np.array(g["A1"]) + np.array(g["A0"])
+    assert relerr(T(z).toarray(), want) < 1e-14
+    assert relerr(T(z, 1).toarray(), 2 * z * np.array(g["A2"]) + np.array(g["A1"])) < 1e-14
+    Gam = [2 + 2j, -2 + 2j, -2 - 2j, 2 - 2j]
+    Om, P, Sig = beyn(T, Gam, l=6, return_sigma=True)
+    assert np.sum(Sig < 1e-10 * Sig[0]) == g["n_small_sigma"]
+    for w in [c(e) for e in g["eigs_inside"]]:
+        assert np.min(np.abs(Om - w)) < 1e-9
+    T._drop_device()
+    # ragged: rows without entries, one structurally empty term
+    d = 50
+    A = sp.random(d, d, density=0.05, random_state=1, format="lil", dtype=float)
+    A[7, :] = 0; A[:, 3] = 0
+    A = sp.csr_matrix(A) + 0j
+    E = sp.csr_matrix((d, d), dtype=complex)
+    Lr = LinearOperatorFamily()
+    Lr.push(Term(A, (pow1,), (("λ",),), "λ", "A"))
+    Lr.push(Term(E, (pow2,), (("λ",),), "λ^2", "E"))
+    Lr.push(Term(sp.identity(d, dtype=complex, format="csr") * (1 + 2j), (), (), "", "I"))
+    x = RNG.standard_normal(d) + 0j
+    assert relerr(Lr(2.0 + 1j) @ x, (2.0 + 1j) * (A @ x) + (1 + 2j) * x) < 1e-14
+    Lr._drop_device()
+
+
+def test_solve_parity_rijke(rijke):
+    Lo, Lp = rijke
+    d = Lo.size()
+    Lp.solver_ref = 2 * np.pi * 400
+    B = RNG.standard_normal((d, 5)) + 1j * RNG.standard_normal((d, 5))
+    B[:, 3] = 0.0                                            # a zero right-hand side must give zero
+    for z in (2 * np.pi * (150 + 5j), 2 * np.pi * (640 - 5j), 1710.0 + 9.0j):
+        Xo = OS._solve(Lo(z), B)
+        Ap = Lp(z)
+        X = Ap.solve(B, tol=1e-12)
+        info = Lp.device().last_info
+        assert info["n_unconverged"] == 0 and info["relres_max"] <= 1e-12
+        assert np.all(X[:, 3] == 0)
+        assert relerr(X, Xo) < 1e-8
+        Xh = Ap.H.solve(B, tol=1e-12)
+        assert relerr(Xh, OS._solve(Lo(z).conj().T.tocsc(), B)) < 1e-8
+
+
+def test_solve_many_systems_in_lockstep(rijke):
+    """ncoef = r: every column has its own coefficient set (different z)."""
+    Lo, Lp = rijke
+    d = Lo.size()
+    fam = Lp.ensure_solver()
+    zs = 2 * np.pi * np.array([200 + 5j, 300 - 4j, 555 + 1j, 900 + 30j, 150 - 5j, 999 + 5j, 431 + 2j])
+    B = RNG.standard_normal((d, len(zs))) + 1j * RNG.standard_normal((d, len(zs)))
+    ct = np.array([Lp.coefficients(z) for z in zs])
+    X = fam.solve(ct, B, tol=1e-12, maxit=400)
+    assert fam.last_info["n_unconverged"] == 0
+    for j, z in enumerate(zs):
+        assert relerr(X[:, j], OS._solve(Lo(z), B[:, j])) < 1e-8
+
+
+def test_beyn_moments_parity_C1():
+    """BASELINE.json configs[0]: Rijke P1, quadratic K+ωYC+ω²M (n=0), Beyn l=5, N=16 per edge."""
+    Lo = F.rijke_family(n=0.0)
+    Lp = helmholtz_family(F.rijke_terms(), n=0.0)
+    Gam = np.array([150 + 5j, 150 - 5j, 1000 - 5j, 1000 + 5j]) * 2 * np.pi
+    Lp.solver_ref = 2 * np.pi * 500
+    Ao = OS.compute_moment_matrices(Lo, Gam, OS.initial_V(Lo.size(), 5), K=1, N=16)
+    Ap = compute_moment_matrices(Lp, Gam, l=5, K=1, N=16)
+    assert Ap.shape == Ao.shape
+    assert relerr(Ap, Ao) < 1e-8
+    assert Lp.device().last_info["n_unconverged"] == 0
+    Oo = np.sort_complex(OS.moments2eigs(Ao)[0])
+    Op = np.sort_complex(moments2eigs(Ap)[0])
+    big = np.abs(OS.moments2eigs(Ao, return_sigma=True)[2]) > 1e-6      # the two physical modes
+    assert np.allclose(Op[:0], Oo[:0])
+    Om_p, _, Sp = moments2eigs(Ap, return_sigma=True)
+    Om_o, _, So = OS.moments2eigs(Ao, return_sigma=True)
+    assert np.allclose(Sp[:2], So[:2], rtol=1e-8)
+    # K = 2 (four moments) and empty contour list
+    Ao2 = OS.compute_moment_matrices(Lo, Gam, OS.initial_V(Lo.size(), 3), K=2, N=4)
+    Ap2 = compute_moment_matrices(Lp, Gam, l=3, K=2, N=4)
+    assert relerr(Ap2, Ao2) < 1e-8
+    A0 = compute_moment_matrices(Lp, Gam, l=3, K=1, points=(np.zeros(0, complex), np.zeros(0, complex)))
+    assert np.all(A0 == 0)
+    Lp._drop_device()
+
+
+def test_G1_householder_and_G2_perturbation():
+    Lp = helmholtz_family(F.rijke_terms(), n=0.01, tau=0.001)
+    Lp.solver_ref = 340 * 2 * np.pi
+    sol, n, flag = householder(Lp, 340 * 2 * np.pi, maxiter=20, tol=1e-11)
+    w = c(G["G1"]["omega"])
+    assert abs(sol.params["ω"] - w) < 1e-10 * abs(w)
+    assert flag in (0, 1) and 5 <= n <= 8
+    for mine, ref in zip(sol.history, G["G1"]["iterates"]):
+        assert abs(mine - c(ref)) < 1e-6 * abs(c(ref))
+    perturb_fast_(sol, Lp, "τ", 20)
+    lam = sol.eigval_pert["τ/Taylor"]
+    for k, ref in enumerate(G["G2"]["taylor"]):
+        assert abs(lam[k] - c(ref)) < 1e-8 * abs(c(ref)), (k, lam[k], c(ref))
+    assert abs(sol("τ", 0.001 + 1e-5, 20) - c(G["G3"]["taylor20_estimate"])) < 1e-7
+    Lp._drop_device()
+
+
+def test_G5_mslp_active_flame():
+    Lp = helmholtz_family(F.rijke_terms(), n=1.0, tau=0.001)
+    Lp.solver_ref = 340 * 2 * np.pi
+    sol, n, flag = mslp(Lp, 340 * 2 * np.pi, maxiter=20, tol=1e-11)
+    w = c(G["G5"]["omega"])
+    assert abs(sol.params["ω"] - w) < 1e-10 * abs(w)
+    assert flag == 0 and abs(n - G["G5"]["iterations"]) <= 1
+    # Newton inverse iteration lands on the same eigenvalue
+    sol2, n2, flag2 = inveriter(Lp, w + 1.0, maxiter=20, tol=1e-9)
+    assert flag2 == 0 and abs(sol2.params["ω"] - w) < 1e-8 * abs(w)
+    Lp._drop_device()

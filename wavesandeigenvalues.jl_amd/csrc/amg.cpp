@@ -1,0 +1,302 @@
+// Host-side sparse helpers and smoothed-aggregation set-up for the multigrid preconditioner.
+// (Set-up runs once per family on the host cores; everything it produces lives in HBM afterwards.)
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "amg.h"
+
+template <class V> static void transpose_impl(int64_t n, int64_t m, const std::vector<int> &ptr, const std::vector<int> &col,
+                                              const std::vector<V> &val, std::vector<int> &tptr, std::vector<int> &tcol, std::vector<V> &tval) {
+    tptr.assign(m + 1, 0);
+    for (int c : col) tptr[c + 1]++;
+    for (int64_t i = 0; i < m; ++i) tptr[i + 1] += tptr[i];
+    tcol.resize(col.size());
+    tval.resize(val.size());
+    std::vector<int> pos(tptr.begin(), tptr.end() - 1);
+    for (int64_t i = 0; i < n; ++i)
+        for (int p = ptr[i]; p < ptr[i + 1]; ++p) {
+            int q = pos[col[p]]++;
+            tcol[q] = (int)i;
+            tval[q] = val[p];
+        }
+}
+CsrZ csr_transpose(const CsrZ &A) {
+    CsrZ T;
+    T.n = A.m; T.m = A.n;
+    transpose_impl(A.n, A.m, A.ptr, A.col, A.val, T.ptr, T.col, T.val);
+    return T;
+}
+CsrD csr_transpose(const CsrD &A) {
+    CsrD T;
+    T.n = A.m; T.m = A.n;
+    transpose_impl(A.n, A.m, A.ptr, A.col, A.val, T.ptr, T.col, T.val);
+    return T;
+}
+bool csr_same_pattern(const CsrZ &A, const CsrZ &B) { return A.n == B.n && A.m == B.m && A.ptr == B.ptr && A.col == B.col; }
+
+// C = A * B   (row-wise Gustavson with a dense marker; columns sorted; structural zeros kept so that planes
+// with equal patterns keep equal patterns after projection)
+template <class VA, class VB, class VC>
+static void spgemm(int64_t n, int64_t m, const std::vector<int> &aptr, const std::vector<int> &acol, const std::vector<VA> &aval,
+                   const std::vector<int> &bptr, const std::vector<int> &bcol, const std::vector<VB> &bval, std::vector<int> &cptr,
+                   std::vector<int> &ccol, std::vector<VC> &cval) {
+    cptr.assign(n + 1, 0);
+    ccol.clear();
+    cval.clear();
+    std::vector<int> marker(m, -1);
+    std::vector<VC> acc(m);
+    std::vector<int> list;
+    for (int64_t i = 0; i < n; ++i) {
+        list.clear();
+        for (int p = aptr[i]; p < aptr[i + 1]; ++p) {
+            const int k = acol[p];
+            const VA a = aval[p];
+            for (int q = bptr[k]; q < bptr[k + 1]; ++q) {
+                const int c = bcol[q];
+                if (marker[c] != (int)i) {
+                    marker[c] = (int)i;
+                    acc[c] = VC(0);
+                    list.push_back(c);
+                }
+                acc[c] += VC(a) * VC(bval[q]);
+            }
+        }
+        std::sort(list.begin(), list.end());
+        for (int c : list) {
+            ccol.push_back(c);
+            cval.push_back(acc[c]);
+        }
+        cptr[i + 1] = (int)ccol.size();
+    }
+}
+
+CsrZ galerkin(const CsrD &R, const CsrZ &A, const CsrD &P) {
+    CsrZ T;
+    T.n = A.n; T.m = P.m;
+    spgemm<zc, double, zc>(A.n, P.m, A.ptr, A.col, A.val, P.ptr, P.col, P.val, T.ptr, T.col, T.val);
+    CsrZ C;
+    C.n = R.n; C.m = P.m;
+    spgemm<double, zc, zc>(R.n, P.m, R.ptr, R.col, R.val, T.ptr, T.col, T.val, C.ptr, C.col, C.val);
+    return C;
+}
+CsrD galerkin_real(const CsrD &R, const CsrD &A, const CsrD &P) {
+    CsrD T;
+    T.n = A.n; T.m = P.m;
+    spgemm<double, double, double>(A.n, P.m, A.ptr, A.col, A.val, P.ptr, P.col, P.val, T.ptr, T.col, T.val);
+    CsrD C;
+    C.n = R.n; C.m = P.m;
+    spgemm<double, double, double>(R.n, P.m, R.ptr, R.col, R.val, T.ptr, T.col, T.val, C.ptr, C.col, C.val);
+    return C;
+}
+
+CsrZ csr_lincomb(const std::vector<CsrZ> &planes, const std::vector<zc> &coef) {
+    CsrZ C;
+    if (planes.empty()) return C;
+    const int64_t n = planes[0].n, m = planes[0].m;
+    C.n = n; C.m = m;
+    C.ptr.assign(n + 1, 0);
+    std::vector<int> marker(m, -1), list;
+    std::vector<zc> acc(m);
+    for (int64_t i = 0; i < n; ++i) {
+        list.clear();
+        for (size_t k = 0; k < planes.size(); ++k) {
+            const CsrZ &A = planes[k];
+            for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) {
+                const int c = A.col[p];
+                if (marker[c] != (int)i) { marker[c] = (int)i; acc[c] = 0; list.push_back(c); }
+                acc[c] += coef[k] * A.val[p];
+            }
+        }
+        std::sort(list.begin(), list.end());
+        for (int c : list) { C.col.push_back(c); C.val.push_back(acc[c]); }
+        C.ptr[i + 1] = (int)C.col.size();
+    }
+    return C;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// smoothed aggregation
+// ----------------------------------------------------------------------------------------------------
+static double diag_of(const CsrD &S, int64_t i) {
+    for (int p = S.ptr[i]; p < S.ptr[i + 1]; ++p)
+        if (S.col[p] == i) return S.val[p];
+    return 0.0;
+}
+
+// Returns P (n x nc).  `skip[i]` != 0 marks penalty (Dirichlet-like) rows: they are neither aggregated nor
+// interpolated (empty P row), so coarse spaces satisfy the essential condition exactly.
+CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double theta, bool smooth) {
+    const int64_t n = S.n;
+    std::vector<double> D(n);
+    for (int64_t i = 0; i < n; ++i) D[i] = std::fabs(diag_of(S, i));
+    // strength graph (symmetric criterion), restricted to non-skipped nodes
+    std::vector<int> gptr(n + 1, 0), gcol;
+    gcol.reserve(S.col.size());
+    for (int64_t i = 0; i < n; ++i) {
+        if (!skip[i])
+            for (int p = S.ptr[i]; p < S.ptr[i + 1]; ++p) {
+                const int j = S.col[p];
+                if (j == i || skip[j]) continue;
+                if (std::fabs(S.val[p]) >= theta * std::sqrt(D[i] * D[j])) gcol.push_back(j);
+            }
+        gptr[i + 1] = (int)gcol.size();
+    }
+    std::vector<int> agg(n, -1);
+    int na = 0;
+    for (int64_t i = 0; i < n; ++i) {   // pass 1: root nodes whose whole strong neighbourhood is free
+        if (skip[i] || agg[i] >= 0 || gptr[i + 1] == gptr[i]) continue;
+        bool free_nb = true;
+        for (int p = gptr[i]; p < gptr[i + 1]; ++p)
+            if (agg[gcol[p]] >= 0) { free_nb = false; break; }
+        if (!free_nb) continue;
+        agg[i] = na;
+        for (int p = gptr[i]; p < gptr[i + 1]; ++p) agg[gcol[p]] = na;
+        ++na;
+    }
+    std::vector<int> agg2(agg);
+    for (int64_t i = 0; i < n; ++i) {   // pass 2: join a neighbouring aggregate
+        if (skip[i] || agg[i] >= 0) continue;
+        for (int p = gptr[i]; p < gptr[i + 1]; ++p)
+            if (agg[gcol[p]] >= 0) { agg2[i] = agg[gcol[p]]; break; }
+    }
+    agg.swap(agg2);
+    for (int64_t i = 0; i < n; ++i) {   // pass 3: leftovers form their own aggregates
+        if (skip[i] || agg[i] >= 0) continue;
+        agg[i] = na;
+        for (int p = gptr[i]; p < gptr[i + 1]; ++p)
+            if (agg[gcol[p]] < 0) agg[gcol[p]] = na;
+        ++na;
+    }
+    // tentative prolongator (piecewise constant)
+    CsrD Pt;
+    Pt.n = n; Pt.m = na;
+    Pt.ptr.assign(n + 1, 0);
+    for (int64_t i = 0; i < n; ++i) {
+        if (agg[i] >= 0) { Pt.col.push_back(agg[i]); Pt.val.push_back(1.0); }
+        Pt.ptr[i + 1] = (int)Pt.col.size();
+    }
+    if (!smooth) return Pt;
+    // filtered matrix F: strong couplings + diagonal, weak couplings lumped onto the diagonal
+    CsrD F;
+    F.n = n; F.m = n;
+    F.ptr.assign(n + 1, 0);
+    std::vector<double> Fd(n, 1.0);
+    for (int64_t i = 0; i < n; ++i) {
+        if (!skip[i]) {
+            double dg = 0.0;
+            int gp = gptr[i];
+            size_t dpos = (size_t)-1;
+            for (int p = S.ptr[i]; p < S.ptr[i + 1]; ++p) {
+                const int j = S.col[p];
+                if (j == i) { dg += S.val[p]; dpos = F.col.size(); F.col.push_back(j); F.val.push_back(0.0); continue; }
+                if (skip[j]) continue;           // coupling to a penalty node: eliminated (value there is ~0)
+                // strong neighbours are listed in column order in gcol
+                while (gp < gptr[i + 1] && gcol[gp] < j) ++gp;
+                if (gp < gptr[i + 1] && gcol[gp] == j) { F.col.push_back(j); F.val.push_back(S.val[p]); }
+                else dg += S.val[p];
+            }
+            if (dpos == (size_t)-1) {   // structurally missing diagonal: insert it in column order
+                F.col.push_back((int)i); F.val.push_back(0.0);
+                size_t q = F.col.size() - 1;
+                while (q > (size_t)F.ptr[i] && F.col[q - 1] > F.col[q]) { std::swap(F.col[q - 1], F.col[q]); std::swap(F.val[q - 1], F.val[q]); --q; }
+                dpos = q;
+            }
+            if (dg == 0.0) dg = 1.0;
+            F.val[dpos] = dg;
+            Fd[i] = dg;
+        }
+        F.ptr[i + 1] = (int)F.col.size();
+    }
+    // spectral radius of D^-1 F by power iteration
+    std::vector<double> x(n), y(n);
+    uint64_t lcg = 88172645463325252ull;
+    for (int64_t i = 0; i < n; ++i) { lcg ^= lcg << 13; lcg ^= lcg >> 7; lcg ^= lcg << 17; x[i] = (double)(lcg % 2000) / 1000.0 - 1.0; }
+    double rho = 1.0;
+    for (int it = 0; it < 20; ++it) {
+        double nrm = 0.0;
+        for (int64_t i = 0; i < n; ++i) {
+            double s = 0.0;
+            for (int p = F.ptr[i]; p < F.ptr[i + 1]; ++p) s += F.val[p] * x[F.col[p]];
+            y[i] = s / Fd[i];
+            nrm += y[i] * y[i];
+        }
+        nrm = std::sqrt(nrm);
+        if (nrm == 0.0) break;
+        rho = nrm;
+        for (int64_t i = 0; i < n; ++i) x[i] = y[i] / nrm;
+    }
+    // note: with x normalised each sweep, ||D^-1 F x|| -> rho
+    const double omega = (4.0 / 3.0) / rho;
+    // P = Pt - omega * D^-1 F Pt
+    CsrD FP;
+    FP.n = n; FP.m = na;
+    spgemm<double, double, double>(n, na, F.ptr, F.col, F.val, Pt.ptr, Pt.col, Pt.val, FP.ptr, FP.col, FP.val);
+    CsrD P;
+    P.n = n; P.m = na;
+    P.ptr.assign(n + 1, 0);
+    for (int64_t i = 0; i < n; ++i) {
+        if (!skip[i]) {
+            const int a = agg[i];
+            bool seen = false;
+            for (int p = FP.ptr[i]; p < FP.ptr[i + 1]; ++p) {
+                double v = -omega * FP.val[p] / Fd[i];
+                if (FP.col[p] == a) { v += 1.0; seen = true; }
+                P.col.push_back(FP.col[p]);
+                P.val.push_back(v);
+            }
+            if (!seen && a >= 0) {   // keep sorted order
+                P.col.push_back(a);
+                P.val.push_back(1.0);
+                int q = (int)P.col.size() - 1;
+                while (q > P.ptr[i] && P.col[q - 1] > P.col[q]) { std::swap(P.col[q - 1], P.col[q]); std::swap(P.val[q - 1], P.val[q]); --q; }
+            }
+        }
+        P.ptr[i + 1] = (int)P.col.size();
+    }
+    return P;
+}
+
+void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, const AmgOptions &opt, std::vector<AmgLevel> &levels) {
+    levels.clear();
+    CsrZ Aref = csr_lincomb(planes, pc_ref);
+    const int64_t n0 = Aref.n;
+    // real shape matrix and penalty rows
+    CsrD S;
+    S.n = S.m = n0;
+    S.ptr = Aref.ptr; S.col = Aref.col;
+    S.val.resize(Aref.val.size());
+    for (size_t p = 0; p < Aref.val.size(); ++p) S.val[p] = Aref.val[p].real();
+    std::vector<double> dabs(n0);
+    for (int64_t i = 0; i < n0; ++i) {
+        zc dg = 0;
+        for (int p = Aref.ptr[i]; p < Aref.ptr[i + 1]; ++p)
+            if (Aref.col[p] == i) dg = Aref.val[p];
+        dabs[i] = std::abs(dg);
+    }
+    std::vector<char> skip(n0, 0);
+    if (n0 > 0) {
+        std::vector<double> tmp(dabs);
+        std::nth_element(tmp.begin(), tmp.begin() + n0 / 2, tmp.end());
+        const double med = tmp[n0 / 2];
+        for (int64_t i = 0; i < n0; ++i) skip[i] = dabs[i] > opt.penalty_ratio * med;
+    }
+    std::vector<CsrZ> cur(planes);
+    int64_t n = n0;
+    while (n > opt.max_coarse && (int)levels.size() < opt.max_levels) {
+        CsrD P = build_prolongator(S, skip, opt.theta, true);
+        if (P.m >= (int64_t)(0.9 * n) || P.m == 0) break;
+        CsrD R = csr_transpose(P);
+        AmgLevel L;
+        L.P = P; L.R = R;
+        std::vector<CsrZ> next;
+        next.reserve(cur.size());
+        for (const CsrZ &A : cur) next.push_back(galerkin(R, A, P));
+        L.coarse_planes = next;
+        levels.push_back(std::move(L));
+        S = galerkin_real(R, S, P);
+        n = S.n;
+        skip.assign(n, 0);
+        cur.swap(next);
+    }
+}

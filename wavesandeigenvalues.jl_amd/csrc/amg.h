@@ -1,0 +1,18 @@
+// Host-side multigrid set-up (smoothed aggregation) -- declarations.
+#pragma once
+#include "wae_internal.h"
+
+struct AmgOptions {
+    double theta = 0.02;          // strength-of-connection threshold
+    int64_t max_coarse = 128;     // stop coarsening at or below this many unknowns
+    int max_levels = 10;
+    double penalty_ratio = 1e8;   // |a_ii| > ratio * median|a_jj|  =>  penalty (Dirichlet-like) row
+};
+struct AmgLevel {
+    CsrD P, R;                            // prolongation (n_fine x n_coarse) and restriction R = P^T
+    std::vector<CsrZ> coarse_planes;      // R * plane_q * P for every plane q
+};
+CsrZ csr_lincomb(const std::vector<CsrZ> &planes, const std::vector<zc> &coef);
+CsrD galerkin_real(const CsrD &R, const CsrD &A, const CsrD &P);
+CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double theta, bool smooth);
+void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, const AmgOptions &opt, std::vector<AmgLevel> &levels);

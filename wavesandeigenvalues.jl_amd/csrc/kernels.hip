@@ -1,0 +1,587 @@
+// HIP kernels of libwaehip.so -- written for gfx950 (MI355X, CDNA4; wave64) only.
+//
+// Data layout.  Every multi-vector is "interleaved": X[row][b], b = 0..nb-1 complex doubles contiguous per
+// row, so that the gather X[col[p]][0..nb) of one matrix nonzero is ONE contiguous nb*16-byte segment
+// (nb = 8 -> one 128-B line) and all vector kernels are plain coalesced streams.
+// Operators are sums of "planes" (term matrices) grouped by shared sparsity pattern: a group stores
+// rowptr/col once and its planes' values interleaved per nonzero ([nnz][nplanes], real planes as 8-B doubles),
+// so the fused multi-term SpMV reads each index once and all term values of that nonzero in one load.
+#include "wae_internal.h"
+
+#include <cstdlib>
+
+// ---------------------------------------------------------------------------------------------------
+// complex helpers
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return cplx{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ cplx cconj(cplx a) { return cplx{a.x, -a.y}; }
+__device__ __forceinline__ void cfma(cplx &acc, cplx a, cplx b) {
+    acc.x = fma(a.x, b.x, acc.x); acc.x = fma(-a.y, b.y, acc.x);
+    acc.y = fma(a.x, b.y, acc.y); acc.y = fma(a.y, b.x, acc.y);
+}
+__device__ __forceinline__ cplx cdiv(cplx a, cplx b) {
+    double s = 1.0 / (b.x * b.x + b.y * b.y);
+    return cplx{(a.x * b.x + a.y * b.y) * s, (a.y * b.x - a.x * b.y) * s};
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fused multi-term CSR SpMV / SpMM:   Y = f( sum_q pc[sys(b)][q] * plane_q * X )   for nb columns
+//
+// A "team" of C*S lanes owns one matrix row: C lanes across batch columns (adjacent lanes -> adjacent X
+// columns: the gather of one nonzero is a single contiguous C*16-byte access), S lanes across the row's
+// nonzeros (partial sums combined with wave shuffles).  64/(C*S) rows per wavefront, 256-thread blocks.
+// Per-column plane coefficients are staged once per block in LDS.
+// ---------------------------------------------------------------------------------------------------
+template <int C, int S>
+__global__ __launch_bounds__(256) void spmv_kernel(OpDev op, const cplx *__restrict__ pc, int cps,
+                                                   const cplx *__restrict__ X, cplx *Y,
+                                                   const cplx *B, double jac_w, int nb, int mode) {
+    constexpr int TEAM = C * S;
+    constexpr int TPB = 256 / TEAM;
+    extern __shared__ cplx spc[];   // [C][nplanes_total]
+    const int tid = threadIdx.x;
+    const int npl = op.nplanes_total;
+    for (int i = tid; i < C * npl; i += 256) {
+        int cc = i / npl, q = i - cc * npl;
+        int bb = blockIdx.y * C + cc;
+        spc[i] = (bb < nb) ? pc[(size_t)(bb / cps) * npl + q] : cplx{0.0, 0.0};
+    }
+    __syncthreads();
+    const int team = tid / TEAM;
+    const int lt = tid - team * TEAM;
+    const int c = lt % C;
+    const int s = lt / C;
+    const int64_t row = (int64_t)blockIdx.x * TPB + team;
+    if (row >= op.n) return;        // whole teams leave together (shuffles below stay inside a team)
+    const int b = blockIdx.y * C + c;
+    const bool active = b < nb;
+    const int bb = active ? b : nb - 1;
+    const cplx *mypc = spc + c * npl;
+    cplx acc = {0.0, 0.0};
+#pragma unroll 1
+    for (int g = 0; g < op.ngroups; ++g) {
+        const GroupDev G = op.g[g];
+        const int p0 = G.rowptr[row], p1 = G.rowptr[row + 1];
+        const int np = G.nplanes;
+        const cplx *gpc = mypc + G.plane0;
+        if (G.is_real) {
+            const double *__restrict__ v = (const double *)G.vals;
+            if (np == 2) {          // the hot case: mass + stiffness share one pattern (16 B per nonzero)
+                const double2 *__restrict__ v2 = (const double2 *)G.vals;
+                const cplx c0 = gpc[0], c1 = gpc[1];
+#pragma unroll 2
+                for (int p = p0 + s; p < p1; p += S) {
+                    const int j = G.col[p];
+                    const double2 a = v2[p];
+                    const cplx x = X[(size_t)j * nb + bb];
+                    cplx m = {fma(c0.x, a.x, c1.x * a.y), fma(c0.y, a.x, c1.y * a.y)};
+                    cfma(acc, m, x);
+                }
+            } else {
+                for (int p = p0 + s; p < p1; p += S) {
+                    const int j = G.col[p];
+                    cplx m = {0.0, 0.0};
+                    for (int q = 0; q < np; ++q) {
+                        const double a = v[(size_t)p * np + q];
+                        m.x = fma(gpc[q].x, a, m.x);
+                        m.y = fma(gpc[q].y, a, m.y);
+                    }
+                    const cplx x = X[(size_t)j * nb + bb];
+                    cfma(acc, m, x);
+                }
+            }
+        } else {
+            const cplx *__restrict__ v = (const cplx *)G.vals;
+            const double sg = G.conj_vals ? -1.0 : 1.0;
+            for (int p = p0 + s; p < p1; p += S) {
+                const int j = G.col[p];
+                cplx m = {0.0, 0.0};
+                for (int q = 0; q < np; ++q) {
+                    cplx a = v[(size_t)p * np + q];
+                    a.y *= sg;
+                    cfma(m, gpc[q], a);
+                }
+                const cplx x = X[(size_t)j * nb + bb];
+                cfma(acc, m, x);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = C; off < TEAM; off <<= 1) {
+        acc.x += __shfl_xor(acc.x, off);
+        acc.y += __shfl_xor(acc.y, off);
+    }
+    if (s != 0 || !active) return;
+    const size_t e = (size_t)row * nb + b;
+    cplx out;
+    if (mode == MODE_AX) {
+        out = acc;
+    } else if (mode == MODE_RES) {
+        const cplx bv = B[e];
+        out = cplx{bv.x - acc.x, bv.y - acc.y};
+    } else if (mode == MODE_ADD) {
+        const cplx bv = B[e];
+        out = cplx{bv.x + acc.x, bv.y + acc.y};
+    } else {   // MODE_JAC
+        cplx dg = {0.0, 0.0};
+        for (int q = 0; q < npl; ++q) cfma(dg, mypc[q], op.diag[(size_t)row * npl + q]);
+        const cplx bv = B[e], xv = X[e];
+        cplx r = cdiv(cplx{bv.x - acc.x, bv.y - acc.y}, dg);
+        out = cplx{xv.x + jac_w * r.x, xv.y + jac_w * r.y};
+    }
+    Y[e] = out;
+}
+
+typedef void (*spmv_fn)(OpDev, const cplx *, int, const cplx *, cplx *, const cplx *, double, int, int);
+template <int C, int S> static spmv_fn spmv_ptr() { return spmv_kernel<C, S>; }
+
+static spmv_fn pick_spmv(int C, int S) {
+#define PICK(c, s_) if (C == c && S == s_) return spmv_ptr<c, s_>();
+    PICK(1, 1) PICK(1, 2) PICK(1, 4) PICK(1, 8) PICK(1, 16) PICK(1, 32)
+    PICK(2, 1) PICK(2, 2) PICK(2, 4) PICK(2, 8) PICK(2, 16)
+    PICK(4, 1) PICK(4, 2) PICK(4, 4) PICK(4, 8) PICK(4, 16)
+    PICK(8, 1) PICK(8, 2) PICK(8, 4) PICK(8, 8)
+    PICK(16, 1) PICK(16, 2) PICK(16, 4)
+#undef PICK
+    return nullptr;
+}
+
+static int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+void launch_spmv(const OpDev &op, const cplx *pc, int cps, const cplx *X, cplx *Y, const cplx *B, double jac_w,
+                 int nb, int mode, hipStream_t st) {
+    const int envC = env_int("WAE_SPMV_C", 0), envS = env_int("WAE_SPMV_S", 0);   // tuning overrides
+    int C = nb >= 8 ? 8 : (nb >= 4 ? 4 : (nb >= 2 ? 2 : 1));
+    int S = 64 / C >= 8 ? 8 : 64 / C;
+    if (C == 8) S = 4;
+    if (envC > 0 && envC <= nb) C = envC;
+    if (envS > 0) S = envS;
+    spmv_fn fn = pick_spmv(C, S);
+    if (!fn) throw WaeError(WAE_ERR_INVALID, "launch_spmv: unsupported (C,S)");
+    if (op.n <= 0) return;
+    const int tpb = 256 / (C * S);
+    dim3 grid((unsigned)((op.n + tpb - 1) / tpb), (unsigned)((nb + C - 1) / C));
+    size_t shm = (size_t)C * op.nplanes_total * sizeof(cplx);
+    hipLaunchKernelGGL(fn, grid, dim3(256), shm, st, op, pc, cps, X, Y, B, jac_w, nb, mode);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void jacobi0_kernel(OpDev op, const cplx *__restrict__ pc, int cps,
+                                                      const cplx *__restrict__ B, cplx *__restrict__ X, double w, int nb) {
+    const size_t total = (size_t)op.n * nb;
+    const int npl = op.nplanes_total;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t row = e / nb;
+        const int b = (int)(e - row * nb);
+        const cplx *mypc = pc + (size_t)(b / cps) * npl;
+        cplx dg = {0.0, 0.0};
+        for (int q = 0; q < npl; ++q) cfma(dg, mypc[q], op.diag[row * npl + q]);
+        cplx r = cdiv(B[e], dg);
+        X[e] = cplx{w * r.x, w * r.y};
+    }
+}
+
+static inline unsigned grid_for(size_t total, unsigned cap = 4096) {
+    size_t g = (total + 255) / 256;
+    if (g < 1) g = 1;
+    return (unsigned)(g > cap ? cap : g);
+}
+
+void launch_jacobi0(const OpDev &op, const cplx *pc, int cps, const cplx *B, cplx *X, double w, int nb, hipStream_t st) {
+    if (op.n <= 0) return;
+    hipLaunchKernelGGL(jacobi0_kernel, dim3(grid_for((size_t)op.n * nb)), dim3(256), 0, st, op, pc, cps, B, X, w, nb);
+    HIP_CHECK(hipGetLastError());
+}
+
+// per-plane input column: Y[:,0] = sum_q pc[q] plane_q X[:, plane_col[q]]   (8 lanes per row)
+__global__ __launch_bounds__(256) void spmv_multi_kernel(OpDev op, const cplx *__restrict__ pc, const int *__restrict__ plane_col,
+                                                         const cplx *__restrict__ X, cplx *__restrict__ Y, int nb) {
+    constexpr int S = 8;
+    const int tid = threadIdx.x;
+    const int64_t row = (int64_t)blockIdx.x * (256 / S) + tid / S;
+    const int s = tid % S;
+    if (row >= op.n) return;
+    cplx acc = {0.0, 0.0};
+    for (int g = 0; g < op.ngroups; ++g) {
+        const GroupDev G = op.g[g];
+        const int p0 = G.rowptr[row], p1 = G.rowptr[row + 1];
+        const int np = G.nplanes;
+        for (int p = p0 + s; p < p1; p += S) {
+            const int j = G.col[p];
+            for (int q = 0; q < np; ++q) {
+                cplx a;
+                if (G.is_real) a = cplx{((const double *)G.vals)[(size_t)p * np + q], 0.0};
+                else { a = ((const cplx *)G.vals)[(size_t)p * np + q]; if (G.conj_vals) a.y = -a.y; }
+                const cplx m = cmul(pc[G.plane0 + q], a);
+                cfma(acc, m, X[(size_t)j * nb + plane_col[G.plane0 + q]]);
+            }
+        }
+    }
+    for (int off = 1; off < S; off <<= 1) {
+        acc.x += __shfl_xor(acc.x, off);
+        acc.y += __shfl_xor(acc.y, off);
+    }
+    if (s == 0) Y[(size_t)row * nb] = acc;
+}
+
+void launch_spmv_multi(const OpDev &op, const cplx *pc, const int *plane_col, const cplx *X, cplx *Y, int nb, hipStream_t st) {
+    if (op.n <= 0) return;
+    hipLaunchKernelGGL(spmv_multi_kernel, dim3((unsigned)((op.n + 31) / 32)), dim3(256), 0, st, op, pc, plane_col, X, Y, nb);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------
+// dense coarsest level
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dense_assemble_kernel(const cplx *__restrict__ planes, int nplanes, int n,
+                                                             const cplx *__restrict__ pc, int transpose_conj, cplx *__restrict__ A) {
+    const int sys = blockIdx.y;
+    const size_t nn = (size_t)n * n;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nn; e += (size_t)gridDim.x * 256) {
+        size_t src = e;
+        if (transpose_conj) { size_t i = e / n, j = e - i * n; src = j * n + i; }
+        cplx acc = {0.0, 0.0};
+        for (int q = 0; q < nplanes; ++q) cfma(acc, pc[(size_t)sys * nplanes + q], planes[(size_t)q * nn + src]);
+        if (transpose_conj) acc.y = -acc.y;
+        A[(size_t)sys * nn + e] = acc;
+    }
+}
+
+void launch_dense_assemble(const cplx *planes, int nplanes, int n, const cplx *pc, int nsys, int transpose_conj, cplx *Ainv, hipStream_t st) {
+    if (n <= 0 || nsys <= 0) return;
+    // for op = C the caller passes conj(pc); A^H = conj(sum pc_q plane_q)^T = (sum conj(pc_q) conj(plane_q))^T
+    hipLaunchKernelGGL(dense_assemble_kernel, dim3(grid_for((size_t)n * n, 256), nsys), dim3(256), 0, st, planes, nplanes, n, pc,
+                       transpose_conj, Ainv);
+    HIP_CHECK(hipGetLastError());
+}
+
+// In-place Gauss-Jordan inversion with partial pivoting, one 1024-thread workgroup per system (matrix in
+// global memory / L2; pivot column and row staged in LDS).  n <= 2048.
+__global__ __launch_bounds__(1024) void dense_invert_kernel(cplx *__restrict__ Aall, int n, int *__restrict__ status) {
+    extern __shared__ unsigned char smraw[];
+    cplx *colk = (cplx *)smraw;            // n
+    cplx *rowk = colk + n;                 // n
+    int *perm = (int *)(rowk + n);         // n
+    __shared__ double red_v[1024];
+    __shared__ int red_i[1024];
+    __shared__ int s_piv;
+    __shared__ int s_bad;
+    cplx *A = Aall + (size_t)blockIdx.x * n * n;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        // pivot search in column k, rows >= k
+        double best = -1.0;
+        int bi = k;
+        for (int i = k + tid; i < n; i += nt) {
+            cplx a = A[(size_t)i * n + k];
+            double m = a.x * a.x + a.y * a.y;
+            if (m > best) { best = m; bi = i; }
+        }
+        red_v[tid] = best; red_i[tid] = bi;
+        __syncthreads();
+        for (int off = nt / 2; off > 0; off >>= 1) {
+            if (tid < off && red_v[tid + off] > red_v[tid]) { red_v[tid] = red_v[tid + off]; red_i[tid] = red_i[tid + off]; }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            s_piv = red_i[0];
+            perm[k] = red_i[0];
+            if (!(red_v[0] > 0.0)) s_bad = 1;
+        }
+        __syncthreads();
+        const int r = s_piv;
+        if (r != k) {
+            for (int j = tid; j < n; j += nt) {
+                cplx t = A[(size_t)k * n + j];
+                A[(size_t)k * n + j] = A[(size_t)r * n + j];
+                A[(size_t)r * n + j] = t;
+            }
+        }
+        __syncthreads();
+        const cplx piv = A[(size_t)k * n + k];
+        const cplx pinv = cdiv(cplx{1.0, 0.0}, piv);
+        for (int i = tid; i < n; i += nt) colk[i] = A[(size_t)i * n + k];
+        __syncthreads();
+        for (int j = tid; j < n; j += nt) {
+            cplx a = (j == k) ? cplx{1.0, 0.0} : A[(size_t)k * n + j];
+            a = cmul(a, pinv);
+            rowk[j] = a;
+            A[(size_t)k * n + j] = a;
+        }
+        for (int i = tid; i < n; i += nt)
+            if (i != k) A[(size_t)i * n + k] = cplx{0.0, 0.0};
+        __syncthreads();
+        const size_t nn = (size_t)n * n;
+        for (size_t e = tid; e < nn; e += nt) {
+            const int i = (int)(e / n), j = (int)(e - (size_t)i * n);
+            if (i == k) continue;
+            const cplx f = colk[i];
+            cplx a = A[e];
+            const cplx rk = rowk[j];
+            a.x -= f.x * rk.x - f.y * rk.y;
+            a.y -= f.x * rk.y + f.y * rk.x;
+            A[e] = a;
+        }
+        __syncthreads();
+    }
+    // undo the row interchanges as column interchanges, in reverse order
+    for (int k = n - 1; k >= 0; --k) {
+        const int r = perm[k];
+        if (r != k) {
+            for (int i = tid; i < n; i += nt) {
+                cplx t = A[(size_t)i * n + k];
+                A[(size_t)i * n + k] = A[(size_t)i * n + r];
+                A[(size_t)i * n + r] = t;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && s_bad) atomicOr(status, 1);
+}
+
+void launch_dense_invert(cplx *Ainv, int n, int nsys, int *status, hipStream_t st) {
+    if (n <= 0 || nsys <= 0) return;
+    if (n > 2048) throw WaeError(WAE_ERR_INVALID, "dense coarse level too large (n > 2048)");
+    size_t shm = (size_t)n * (2 * sizeof(cplx) + sizeof(int));
+    hipLaunchKernelGGL(dense_invert_kernel, dim3(nsys), dim3(1024), shm, st, Ainv, n, status);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void dense_apply_kernel(const cplx *__restrict__ Ainv, int n, int cps, const cplx *__restrict__ X,
+                                                          cplx *__restrict__ Y, int nb) {
+    const size_t total = (size_t)n * nb;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int i = (int)(e / nb), b = (int)(e - (size_t)i * nb);
+    const cplx *Arow = Ainv + ((size_t)(b / cps) * n + i) * n;
+    cplx acc = {0.0, 0.0};
+    for (int j = 0; j < n; ++j) cfma(acc, Arow[j], X[(size_t)j * nb + b]);
+    Y[e] = acc;
+}
+
+void launch_dense_apply(const cplx *Ainv, int n, int cps, const cplx *X, cplx *Y, int nb, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(dense_apply_kernel, dim3((unsigned)(((size_t)n * nb + 255) / 256)), dim3(256), 0, st, Ainv, n, cps, X, Y, nb);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------
+// streaming vector kernels on interleaved multivectors
+// ---------------------------------------------------------------------------------------------------
+__global__ void fill_zero_kernel(cplx *X, size_t count) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < count; e += (size_t)gridDim.x * 256) X[e] = cplx{0.0, 0.0};
+}
+void launch_fill_zero(cplx *X, size_t count, hipStream_t st) {
+    if (!count) return;
+    hipLaunchKernelGGL(fill_zero_kernel, dim3(grid_for(count)), dim3(256), 0, st, X, count);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_copy(const cplx *X, cplx *Y, size_t count, hipStream_t st) {
+    if (!count) return;
+    HIP_CHECK(hipMemcpyAsync(Y, X, count * sizeof(cplx), hipMemcpyDeviceToDevice, st));
+}
+__global__ void add_kernel(const cplx *__restrict__ X, cplx *__restrict__ Y, size_t count) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < count; e += (size_t)gridDim.x * 256) {
+        cplx a = X[e], b = Y[e];
+        Y[e] = cplx{a.x + b.x, a.y + b.y};
+    }
+}
+void launch_add(const cplx *X, cplx *Y, size_t count, hipStream_t st) {
+    if (!count) return;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(count)), dim3(256), 0, st, X, Y, count);
+    HIP_CHECK(hipGetLastError());
+}
+
+// partial[blk][i][b] = sum over this block's rows of conj(V_i[row][b]) W[row][b];  any nb <= 256
+// (thread t owns column t % nb and every R-th row, R = 256 / nb; threads beyond R*nb idle)
+constexpr int DOT_BLOCKS = 512;
+template <int MAXV>
+__global__ __launch_bounds__(256) void dots_kernel(const cplx *__restrict__ V, size_t stride, int nv, const cplx *__restrict__ W,
+                                                   int64_t n, int nb, cplx *__restrict__ partial) {
+    __shared__ cplx sm[256];
+    const int tid = threadIdx.x;
+    const int R = 256 / nb;
+    const int b = tid % nb, rl = tid / nb;
+    const bool live = rl < R;
+    cplx acc[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) acc[i] = cplx{0.0, 0.0};
+    if (live) {
+        for (int64_t row = (int64_t)blockIdx.x * R + rl; row < n; row += (int64_t)gridDim.x * R) {
+            const size_t e = (size_t)row * nb + b;
+            const cplx w = W[e];
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                if (i < nv) {
+                    const cplx v = V[(size_t)i * stride + e];
+                    acc[i].x += v.x * w.x + v.y * w.y;
+                    acc[i].y += v.x * w.y - v.y * w.x;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        if (i < nv) {
+            sm[tid] = acc[i];
+            __syncthreads();
+            if (tid < nb) {
+                cplx s = sm[tid];
+                for (int k = 1; k < R; ++k) { s.x += sm[k * nb + tid].x; s.y += sm[k * nb + tid].y; }
+                partial[((size_t)blockIdx.x * nv + i) * nb + tid] = s;
+            }
+            __syncthreads();
+        }
+    }
+}
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const cplx *__restrict__ partial, int nblk, int count, cplx *__restrict__ out, int do_sqrt) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= count) return;
+    cplx acc = {0.0, 0.0};
+    for (int k = 0; k < nblk; ++k) { cplx p = partial[(size_t)k * count + e]; acc.x += p.x; acc.y += p.y; }
+    if (do_sqrt) acc = cplx{sqrt(acc.x), 0.0};
+    out[e] = acc;
+}
+
+static void dots_impl(const cplx *V, size_t stride, int nv, const cplx *W, int64_t n, int nb, cplx *partial, cplx *out, int do_sqrt, hipStream_t st) {
+    if (nb < 1 || nb > 256) throw WaeError(WAE_ERR_INVALID, "dots: nb must be in 1..256");
+    int done = 0;
+    while (done < nv) {
+        int chunk = nv - done > 32 ? 32 : nv - done;
+        const cplx *Vc = V + (size_t)done * stride;
+        int nblk = DOT_BLOCKS;
+        if (chunk <= 8) hipLaunchKernelGGL(dots_kernel<8>, dim3(nblk), dim3(256), 0, st, Vc, stride, chunk, W, n, nb, partial);
+        else if (chunk <= 16) hipLaunchKernelGGL(dots_kernel<16>, dim3(nblk), dim3(256), 0, st, Vc, stride, chunk, W, n, nb, partial);
+        else hipLaunchKernelGGL(dots_kernel<32>, dim3(nblk), dim3(256), 0, st, Vc, stride, chunk, W, n, nb, partial);
+        HIP_CHECK(hipGetLastError());
+        int count = chunk * nb;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((count + 255) / 256), dim3(256), 0, st, partial, nblk, count, out + (size_t)done * nb, do_sqrt);
+        HIP_CHECK(hipGetLastError());
+        done += chunk;
+    }
+}
+void launch_dots(const cplx *V, size_t stride, int nv, const cplx *W, int64_t n, int nb, cplx *partial, cplx *out, hipStream_t st) {
+    dots_impl(V, stride, nv, W, n, nb, partial, out, 0, st);
+}
+void launch_norms(const cplx *X, int64_t n, int nb, cplx *partial, cplx *out, hipStream_t st) {
+    dots_impl(X, 0, 1, X, n, nb, partial, out, 1, st);
+}
+
+__global__ __launch_bounds__(256) void axpy_neg_kernel(const cplx *__restrict__ V, size_t stride, int nv, const cplx *__restrict__ h,
+                                                       cplx *W, size_t total, int nb, double sign, const cplx *base) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int b = (int)(e % nb);
+        cplx acc = base ? base[e] : cplx{0.0, 0.0};
+        for (int i = 0; i < nv; ++i) {
+            const cplx c = h[(size_t)i * nb + b];
+            const cplx v = V[(size_t)i * stride + e];
+            acc.x += sign * (c.x * v.x - c.y * v.y);
+            acc.y += sign * (c.x * v.y + c.y * v.x);
+        }
+        W[e] = acc;
+    }
+}
+void launch_axpy_neg(const cplx *V, size_t stride, int nv, const cplx *h, cplx *W, int64_t n, int nb, hipStream_t st) {
+    size_t total = (size_t)n * nb;
+    if (!total) return;
+    hipLaunchKernelGGL(axpy_neg_kernel, dim3(grid_for(total)), dim3(256), 0, st, V, stride, nv, h, W, total, nb, -1.0, (const cplx *)W);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_lincomb(const cplx *V, size_t stride, int nv, const cplx *y, cplx *Y, int64_t n, int nb, hipStream_t st) {
+    size_t total = (size_t)n * nb;
+    if (!total) return;
+    hipLaunchKernelGGL(axpy_neg_kernel, dim3(grid_for(total)), dim3(256), 0, st, V, stride, nv, y, Y, total, nb, 1.0, (const cplx *)nullptr);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void scale_inv_kernel(const cplx *__restrict__ X, const cplx *__restrict__ alpha, cplx *__restrict__ Y, size_t total, int nb) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const double a = alpha[e % nb].x;
+        const double s = (a > 1e-300) ? 1.0 / a : 0.0;
+        const cplx x = X[e];
+        Y[e] = cplx{x.x * s, x.y * s};
+    }
+}
+void launch_scale_inv(const cplx *X, const cplx *alpha, cplx *Y, int64_t n, int nb, hipStream_t st) {
+    size_t total = (size_t)n * nb;
+    if (!total) return;
+    hipLaunchKernelGGL(scale_inv_kernel, dim3(grid_for(total)), dim3(256), 0, st, X, alpha, Y, total, nb);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void colmajor_to_inter_kernel(const cplx *__restrict__ Xc, int64_t d, int r, cplx *__restrict__ Xi, int nb) {
+    const size_t total = (size_t)d * nb;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t row = e / nb;
+        const int b = (int)(e - row * nb);
+        Xi[e] = (b < r) ? Xc[(size_t)b * d + row] : cplx{0.0, 0.0};
+    }
+}
+void launch_colmajor_to_inter(const cplx *Xc, int64_t d, int r, cplx *Xi, int nb, hipStream_t st) {
+    hipLaunchKernelGGL(colmajor_to_inter_kernel, dim3(grid_for((size_t)d * nb)), dim3(256), 0, st, Xc, d, r, Xi, nb);
+    HIP_CHECK(hipGetLastError());
+}
+__global__ __launch_bounds__(256) void inter_to_colmajor_kernel(const cplx *__restrict__ Xi, int nb, int64_t d, int r, cplx *__restrict__ Xc) {
+    const size_t total = (size_t)d * r;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t b = e / d, row = e - b * d;
+        Xc[e] = Xi[row * nb + b];
+    }
+}
+void launch_inter_to_colmajor(const cplx *Xi, int nb, int64_t d, int r, cplx *Xc, hipStream_t st) {
+    if (!d || !r) return;
+    hipLaunchKernelGGL(inter_to_colmajor_kernel, dim3(grid_for((size_t)d * r)), dim3(256), 0, st, Xi, nb, d, r, Xc);
+    HIP_CHECK(hipGetLastError());
+}
+__global__ __launch_bounds__(256) void replicate_kernel(const cplx *__restrict__ Vc, int64_t d, int l, cplx *__restrict__ Xi, int nb) {
+    const size_t total = (size_t)d * nb;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t row = e / nb;
+        const int b = (int)(e - row * nb);
+        Xi[e] = Vc[(size_t)(b % l) * d + row];
+    }
+}
+void launch_replicate(const cplx *Vc, int64_t d, int l, cplx *Xi, int nb, hipStream_t st) {
+    hipLaunchKernelGGL(replicate_kernel, dim3(grid_for((size_t)d * nb)), dim3(256), 0, st, Vc, d, l, Xi, nb);
+    HIP_CHECK(hipGetLastError());
+}
+
+// A[(p*l+c)*d + row] += sum_s w[s] z[s]^p X[row][s*l+c]
+__global__ __launch_bounds__(256) void beyn_accum_kernel(const cplx *__restrict__ Xi, int nb, int64_t d, int l, int nsys,
+                                                         const cplx *__restrict__ w, const cplx *__restrict__ z, int npow, cplx *__restrict__ A) {
+    const size_t total = (size_t)d * l;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t c = e / d, row = e - c * d;
+        for (int s = 0; s < nsys; ++s) {
+            cplx t = cmul(w[s], Xi[row * nb + (size_t)s * l + c]);
+            const cplx zs = z[s];
+            for (int p = 0; p < npow; ++p) {
+                cplx *dst = A + ((size_t)p * l + c) * d + row;
+                cplx a = *dst;
+                *dst = cplx{a.x + t.x, a.y + t.y};
+                t = cmul(t, zs);
+            }
+        }
+    }
+}
+void launch_beyn_accum(const cplx *Xi, int nb, int64_t d, int l, int nsys, const cplx *w, const cplx *z, int npow, cplx *A, hipStream_t st) {
+    hipLaunchKernelGGL(beyn_accum_kernel, dim3(grid_for((size_t)d * l)), dim3(256), 0, st, Xi, nb, d, l, nsys, w, z, npow, A);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void triad_kernel(double2 *__restrict__ a, const double2 *__restrict__ b, const double2 *__restrict__ c, double s, size_t n2) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n2; e += (size_t)gridDim.x * 256) {
+        double2 x = b[e], y = c[e];
+        a[e] = double2{x.x + s * y.x, x.y + s * y.y};
+    }
+}
+void launch_triad(double *a, const double *b, const double *c, double s_, int64_t n, hipStream_t st) {
+    size_t n2 = (size_t)n / 2;
+    hipLaunchKernelGGL(triad_kernel, dim3(grid_for(n2, 8192)), dim3(256), 0, st, (double2 *)a, (const double2 *)b, (const double2 *)c, s_, n2);
+    HIP_CHECK(hipGetLastError());
+}

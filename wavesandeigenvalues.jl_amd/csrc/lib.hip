@@ -1,0 +1,982 @@
+// libwaehip.so -- family handle, multigrid-preconditioned batched GMRES, Beyn moment loop, C ABI.
+// gfx950 only.  See include/waehip.h for the contract of every exported function.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <map>
+#include <memory>
+
+#include "amg.h"
+#include "wae_internal.h"
+
+static thread_local std::string g_last_error;
+void wae_set_error(const std::string &m) { g_last_error = m; }
+
+// ----------------------------------------------------------------------------------------------------
+// level operators on device
+// ----------------------------------------------------------------------------------------------------
+OpDev LevelOp::dev(int op) const {
+    OpDev o;
+    memset(&o, 0, sizeof(o));
+    o.ngroups = (int)groups.size();
+    o.nplanes_total = nplanes;
+    o.n = n;
+    o.diag = diag.p;
+    for (size_t g = 0; g < groups.size(); ++g) {
+        const GroupHost &G = groups[g];
+        GroupDev &D = o.g[g];
+        const bool tr = (op != WAE_OP_N) && !G.symmetric;
+        D.rowptr = tr ? G.rowptr_t.p : G.rowptr.p;
+        D.col = tr ? G.col_t.p : G.col.p;
+        D.vals = tr ? (const void *)G.vals_t.p : (const void *)G.vals.p;
+        D.nplanes = G.nplanes;
+        D.is_real = G.is_real ? 1 : 0;
+        D.plane0 = G.plane0;
+        D.conj_vals = (op == WAE_OP_C && !G.is_real) ? 1 : 0;
+    }
+    return o;
+}
+static OpDev transfer_dev(const DevBuf<int> &ptr, const DevBuf<int> &col, const DevBuf<double> &val, int64_t n) {
+    OpDev o;
+    memset(&o, 0, sizeof(o));
+    o.ngroups = 1;
+    o.nplanes_total = 1;
+    o.n = n;
+    o.g[0].rowptr = ptr.p;
+    o.g[0].col = col.p;
+    o.g[0].vals = val.p;
+    o.g[0].nplanes = 1;
+    o.g[0].is_real = 1;
+    return o;
+}
+OpDev Transfer::devP() const { return transfer_dev(p_ptr, p_col, p_val, nf); }
+OpDev Transfer::devR() const { return transfer_dev(r_ptr, r_col, r_val, nc); }
+
+struct wae_family {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t d = 0;
+    int T = 0;
+    std::vector<int> term_plane;     // term k -> plane index (in the order planes were discovered)
+    std::vector<zc> term_scale;      // term k = scale * plane
+    std::vector<int64_t> term_nnz;
+    int nplanes = 0;
+    std::vector<CsrZ> planes0;       // host copies of the fine planes (set-up input)
+    std::vector<LevelOp> ops;        // ops[0] = fine level
+    std::vector<std::vector<int>> slot_plane;   // per level: slot -> plane
+    std::vector<Transfer> xfer;
+    // dense coarsest level
+    int64_t nc = 0;
+    DevBuf<cplx> dense_planes, Ainv;
+    DevBuf<int> dstatus;
+    bool solver_ready = false;
+    double jac_w = 0.8;
+    int nsweeps = 1, restart = 30, NB = 64;
+    // workspaces
+    std::vector<DevBuf<cplx>> lx, lb, lt;
+    DevBuf<cplx> V, W, Z, Xs, Bs, U, partial, hdev, ydev, pcdev, one_dev, io_a, io_b, zw_dev;
+    DevBuf<int> plane_col_dev;
+    cplx *h_pinned = nullptr;        // (restart+2)*NB
+    size_t pc_stride_level = 0;      // elements per level in pcdev
+    ~wae_family() {
+        for (auto *b : {&dense_planes, &Ainv, &V, &W, &Z, &Xs, &Bs, &U, &partial, &hdev, &ydev, &pcdev, &one_dev, &io_a, &io_b, &zw_dev}) b->release();
+        dstatus.release();
+        plane_col_dev.release();
+        for (auto &b : lx) b.release();
+        for (auto &b : lb) b.release();
+        for (auto &b : lt) b.release();
+        for (auto &L : ops) {
+            L.diag.release();
+            for (auto &G : L.groups) { G.rowptr.release(); G.col.release(); G.rowptr_t.release(); G.col_t.release(); G.vals.release(); G.vals_t.release(); }
+        }
+        for (auto &X : xfer) { X.p_ptr.release(); X.p_col.release(); X.r_ptr.release(); X.r_col.release(); X.p_val.release(); X.r_val.release(); }
+        if (h_pinned) (void)hipHostFree(h_pinned);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+static bool plane_is_real(const CsrZ &A) {
+    for (const zc &v : A.val)
+        if (v.imag() != 0.0) return false;
+    return true;
+}
+
+// Build the device representation of sum_q pc[q] plane_q from host planes; returns slot -> plane map.
+static std::vector<int> build_levelop(LevelOp &L, const std::vector<CsrZ> &planes, hipStream_t st) {
+    L.n = planes.empty() ? 0 : planes[0].n;
+    L.nplanes = (int)planes.size();
+    struct Grp { std::vector<int> members; bool real; };
+    std::vector<Grp> grps;
+    for (int q = 0; q < (int)planes.size(); ++q) {
+        const bool re = plane_is_real(planes[q]);
+        bool placed = false;
+        for (auto &g : grps)
+            if (g.real == re && csr_same_pattern(planes[g.members[0]], planes[q])) { g.members.push_back(q); placed = true; break; }
+        if (!placed) grps.push_back(Grp{{q}, re});
+    }
+    if ((int)grps.size() > WAE_MAXG) throw WaeError(WAE_ERR_INVALID, "too many distinct sparsity patterns (max 8)");
+    if ((int)planes.size() > WAE_MAXP) throw WaeError(WAE_ERR_INVALID, "too many distinct term matrices (max 32)");
+    std::vector<int> slot_plane;
+    L.groups.clear();
+    L.groups.resize(grps.size());
+    for (size_t gi = 0; gi < grps.size(); ++gi) {
+        const Grp &g = grps[gi];
+        GroupHost &G = L.groups[gi];
+        const CsrZ &A0 = planes[g.members[0]];
+        const int np = (int)g.members.size();
+        G.nplanes = np;
+        G.is_real = g.real;
+        G.nnz = A0.nnz();
+        G.plane0 = (int)slot_plane.size();
+        for (int q : g.members) slot_plane.push_back(q);
+        const int w = g.real ? 1 : 2;
+        auto pack = [&](const std::vector<const CsrZ *> &mats, std::vector<double> &out) {
+            const int64_t nnz = mats[0]->nnz();
+            out.resize((size_t)nnz * np * w);
+            for (int k = 0; k < np; ++k)
+                for (int64_t p = 0; p < nnz; ++p) {
+                    const zc v = mats[k]->val[p];
+                    if (g.real) out[(size_t)p * np + k] = v.real();
+                    else { out[((size_t)p * np + k) * 2] = v.real(); out[((size_t)p * np + k) * 2 + 1] = v.imag(); }
+                }
+        };
+        std::vector<const CsrZ *> mats;
+        for (int q : g.members) mats.push_back(&planes[q]);
+        std::vector<double> packed;
+        pack(mats, packed);
+        G.rowptr.upload(A0.ptr.data(), A0.ptr.size(), st);
+        G.col.upload(A0.col.data(), A0.col.size(), st);
+        G.vals.upload(packed.data(), packed.size(), st);
+        // transpose orientation (exact symmetry test: bitwise)
+        std::vector<CsrZ> tr;
+        bool sym = (A0.n == A0.m);
+        for (int q : g.members) {
+            tr.push_back(csr_transpose(planes[q]));
+            if (sym && !(tr.back().ptr == planes[q].ptr && tr.back().col == planes[q].col && tr.back().val == planes[q].val)) sym = false;
+        }
+        G.symmetric = sym;
+        if (!sym) {
+            std::vector<const CsrZ *> tm;
+            for (auto &t : tr) tm.push_back(&t);
+            std::vector<double> tp;
+            pack(tm, tp);
+            G.rowptr_t.upload(tr[0].ptr.data(), tr[0].ptr.size(), st);
+            G.col_t.upload(tr[0].col.data(), tr[0].col.size(), st);
+            G.vals_t.upload(tp.data(), tp.size(), st);
+        }
+        HIP_CHECK(hipStreamSynchronize(st));   // host staging buffers die at scope end
+    }
+    // diagonals [n][nplanes] in slot order
+    std::vector<cplx> dg((size_t)L.n * L.nplanes, cplx{0.0, 0.0});
+    for (int s = 0; s < L.nplanes; ++s) {
+        const CsrZ &A = planes[slot_plane[s]];
+        for (int64_t i = 0; i < A.n; ++i)
+            for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p)
+                if (A.col[p] == i) dg[(size_t)i * L.nplanes + s] = cplx{A.val[p].real(), A.val[p].imag()};
+    }
+    L.diag.upload(dg.data(), dg.size(), st);
+    HIP_CHECK(hipStreamSynchronize(st));
+    return slot_plane;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// input conversion
+// ----------------------------------------------------------------------------------------------------
+static CsrZ term_to_csr(int64_t d, int index_bytes, int base, int orientation, const void *ptr, const void *idx, const double *val) {
+    auto getp = [&](int64_t i) -> int64_t { return index_bytes == 4 ? (int64_t)((const uint32_t *)ptr)[i] : ((const int64_t *)ptr)[i]; };
+    auto geti = [&](int64_t i) -> int64_t { return index_bytes == 4 ? (int64_t)((const uint32_t *)idx)[i] : ((const int64_t *)idx)[i]; };
+    CsrZ A;
+    A.n = A.m = d;
+    const int64_t nnz = getp(d) - base;
+    WAE_REQUIRE(nnz >= 0 && nnz < (int64_t)2147483647, "term nnz out of range");
+    A.ptr.resize(d + 1);
+    A.col.resize(nnz);
+    A.val.resize(nnz);
+    for (int64_t i = 0; i <= d; ++i) {
+        const int64_t p = getp(i) - base;
+        WAE_REQUIRE(p >= 0 && p <= nnz, "pointer array out of range");
+        A.ptr[i] = (int)p;
+    }
+    for (int64_t p = 0; p < nnz; ++p) {
+        const int64_t j = geti(p) - base;
+        WAE_REQUIRE(j >= 0 && j < d, "index out of range");
+        A.col[p] = (int)j;
+        A.val[p] = zc(val[2 * p], val[2 * p + 1]);
+    }
+    // sort + merge duplicates per row
+    CsrZ S;
+    S.n = S.m = d;
+    S.ptr.assign(d + 1, 0);
+    std::vector<std::pair<int, zc>> row;
+    for (int64_t i = 0; i < d; ++i) {
+        WAE_REQUIRE(A.ptr[i] <= A.ptr[i + 1], "pointer array not monotone");
+        row.clear();
+        for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) row.emplace_back(A.col[p], A.val[p]);
+        std::stable_sort(row.begin(), row.end(), [](const std::pair<int, zc> &a, const std::pair<int, zc> &b) { return a.first < b.first; });
+        for (size_t k = 0; k < row.size(); ++k) {
+            if (!S.col.empty() && (int)S.col.size() > S.ptr[i] && S.col.back() == row[k].first) S.val.back() += row[k].second;
+            else { S.col.push_back(row[k].first); S.val.push_back(row[k].second); }
+        }
+        S.ptr[i + 1] = (int)S.col.size();
+    }
+    if (orientation == WAE_CSC) return csr_transpose(S);
+    return S;
+}
+
+// term k == s * plane q exactly?
+static bool proportional(const CsrZ &A, const CsrZ &P, zc &s) {
+    if (!csr_same_pattern(A, P) || A.nnz() == 0) return false;
+    int64_t p0 = -1;
+    for (int64_t p = 0; p < P.nnz(); ++p)
+        if (P.val[p] != zc(0)) { p0 = p; break; }
+    if (p0 < 0) return false;
+    s = A.val[p0] / P.val[p0];
+    for (int64_t p = 0; p < P.nnz(); ++p)
+        if (A.val[p] != s * P.val[p]) return false;
+    return true;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// coefficient tables
+// ----------------------------------------------------------------------------------------------------
+// plane coefficients for one system from term coefficients (aliased terms folded in), conj for op = C
+static void plane_coeffs(const wae_family *h, const double *coeffs, int op, std::vector<zc> &pc) {
+    pc.assign(h->nplanes, zc(0));
+    for (int k = 0; k < h->T; ++k) pc[h->term_plane[k]] += h->term_scale[k] * zc(coeffs[2 * k], coeffs[2 * k + 1]);
+    if (op == WAE_OP_C)
+        for (auto &c : pc) c = std::conj(c);
+}
+// upload [level][sys][slot] tables
+static void upload_pc(wae_family *h, const std::vector<std::vector<zc>> &pcs) {
+    const int nsys = (int)pcs.size();
+    const int nl = (int)h->ops.size();
+    const size_t per_level = (size_t)nsys * h->nplanes;
+    std::vector<cplx> tab(per_level * nl);
+    for (int l = 0; l < nl; ++l)
+        for (int s = 0; s < nsys; ++s)
+            for (int q = 0; q < h->nplanes; ++q) {
+                const zc c = pcs[s][h->slot_plane[l][q]];
+                tab[l * per_level + (size_t)s * h->nplanes + q] = cplx{c.real(), c.imag()};
+            }
+    h->pc_stride_level = per_level;
+    h->pcdev.upload(tab.data(), tab.size(), h->stream);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+}
+static inline const cplx *pc_level(const wae_family *h, int l) { return h->pcdev.p + (size_t)l * h->pc_stride_level; }
+
+// ----------------------------------------------------------------------------------------------------
+// multigrid V-cycle (all columns in lock-step)
+// ----------------------------------------------------------------------------------------------------
+struct Batch {
+    int nb;     // columns (leading dimension of every multivector)
+    int cps;    // columns per system
+    int nsys;
+    int op;
+};
+
+static void dense_setup(wae_family *h, const Batch &bt) {
+    const int L = (int)h->ops.size() - 1;
+    if (h->nc <= 0) return;
+    HIP_CHECK(hipMemsetAsync(h->dstatus.p, 0, sizeof(int), h->stream));
+    launch_dense_assemble(h->dense_planes.p, h->nplanes, (int)h->nc, pc_level(h, L), bt.nsys, bt.op != WAE_OP_N ? 1 : 0, h->Ainv.p, h->stream);
+    launch_dense_invert(h->Ainv.p, (int)h->nc, bt.nsys, h->dstatus.p, h->stream);
+    int st = 0;
+    HIP_CHECK(hipMemcpyAsync(&st, h->dstatus.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (st) throw WaeError(WAE_ERR_BREAKDOWN, "coarse operator is singular");
+}
+
+// x = Minv b on level l;  returns pointer to the result (either lx[l] or lt[l])
+static cplx *vcycle(wae_family *h, const Batch &bt, int l, const cplx *b) {
+    const int L = (int)h->ops.size() - 1;
+    hipStream_t st = h->stream;
+    if (l == L) {
+        launch_dense_apply(h->Ainv.p, (int)h->nc, bt.cps, b, h->lx[l].p, bt.nb, st);
+        return h->lx[l].p;
+    }
+    const OpDev A = h->ops[l].dev(bt.op);
+    const cplx *pc = pc_level(h, l);
+    cplx *x = h->lx[l].p, *t = h->lt[l].p;
+    launch_jacobi0(A, pc, bt.cps, b, x, h->jac_w, bt.nb, st);
+    for (int s = 1; s < h->nsweeps; ++s) {
+        launch_spmv(A, pc, bt.cps, x, t, b, h->jac_w, bt.nb, MODE_JAC, st);
+        std::swap(x, t);
+    }
+    // residual -> t, restrict -> lb[l+1]
+    launch_spmv(A, pc, bt.cps, x, t, b, 0.0, bt.nb, MODE_RES, st);
+    // for op = T/C the transfer operators are unchanged (real): (R A P)^H = R A^H P
+    launch_spmv(h->xfer[l].devR(), h->one_dev.p, 1 << 30, t, h->lb[l + 1].p, nullptr, 0.0, bt.nb, MODE_AX, st);
+    const cplx *xc = vcycle(h, bt, l + 1, h->lb[l + 1].p);
+    launch_spmv(h->xfer[l].devP(), h->one_dev.p, 1 << 30, xc, x, x, 0.0, bt.nb, MODE_ADD, st);
+    for (int s = 0; s < h->nsweeps; ++s) {
+        launch_spmv(A, pc, bt.cps, x, t, b, h->jac_w, bt.nb, MODE_JAC, st);
+        std::swap(x, t);
+    }
+    return x;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// batched right-preconditioned GMRES(m)
+// ----------------------------------------------------------------------------------------------------
+struct ColState {
+    std::vector<zc> H;      // (m+1) x m column-major upper part after rotations
+    std::vector<zc> g;
+    std::vector<double> cs;
+    std::vector<zc> sn;
+    int steps = 0;          // Arnoldi steps to use for the update
+    bool conv = false;
+};
+
+static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double tol, int maxit, wae_solve_info *info) {
+    hipStream_t st = h->stream;
+    const int nb = bt.nb, m = h->restart;
+    const int64_t n = h->d;
+    const size_t vec = (size_t)n * nb;
+    const OpDev A = h->ops[0].dev(bt.op);
+    const cplx *pc = pc_level(h, 0);
+    cplx *hp = h->h_pinned;
+    launch_fill_zero(X, vec, st);
+    launch_norms(B, n, nb, h->partial.p, h->hdev.p, st);
+    HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<double> bnorm(nb), relres(nb, 0.0);
+    std::vector<int> iters(nb, 0);
+    std::vector<char> done(nb, 0);
+    for (int b = 0; b < nb; ++b) { bnorm[b] = hp[b].x; if (!(bnorm[b] > 0.0)) done[b] = 1; }
+    std::vector<ColState> cs(nb);
+    int total_it = 0;
+    bool first = true;
+    bool nan_seen = false;
+    while (true) {
+        cplx *r = h->W.p;
+        if (first) launch_copy(B, r, vec, st);
+        else launch_spmv(A, pc, bt.cps, X, r, B, 0.0, nb, MODE_RES, st);
+        first = false;
+        launch_norms(r, n, nb, h->partial.p, h->hdev.p, st);
+        HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        bool all_done = true;
+        for (int b = 0; b < nb; ++b) {
+            if (bnorm[b] > 0.0) {
+                relres[b] = hp[b].x / bnorm[b];
+                if (std::isnan(relres[b])) nan_seen = true;
+                done[b] = relres[b] <= tol;
+            }
+            if (!done[b]) all_done = false;
+        }
+        if (all_done || total_it >= maxit || nan_seen) break;
+        launch_scale_inv(r, h->hdev.p, h->V.p, n, nb, st);     // V0 = r / beta
+        for (int b = 0; b < nb; ++b) {
+            ColState &c = cs[b];
+            c.H.assign((size_t)(m + 1) * m, zc(0));
+            c.g.assign(m + 1, zc(0));
+            c.g[0] = hp[b].x;
+            c.cs.assign(m, 0.0);
+            c.sn.assign(m, zc(0));
+            c.steps = 0;
+            c.conv = done[b];
+        }
+        int j = 0;
+        for (; j < m && total_it < maxit; ++j) {
+            const cplx *vj = h->V.p + (size_t)j * vec;
+            const cplx *z = vcycle(h, bt, 0, vj);
+            launch_spmv(A, pc, bt.cps, z, h->W.p, nullptr, 0.0, nb, MODE_AX, st);
+            launch_dots(h->V.p, vec, j + 1, h->W.p, n, nb, h->partial.p, h->hdev.p, st);
+            launch_axpy_neg(h->V.p, vec, j + 1, h->hdev.p, h->W.p, n, nb, st);
+            launch_norms(h->W.p, n, nb, h->partial.p, h->hdev.p + (size_t)(j + 1) * nb, st);
+            launch_scale_inv(h->W.p, h->hdev.p + (size_t)(j + 1) * nb, h->V.p + (size_t)(j + 1) * vec, n, nb, st);
+            HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, (size_t)(j + 2) * nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            ++total_it;
+            bool all_conv = true;
+            for (int b = 0; b < nb; ++b) {
+                ColState &c = cs[b];
+                if (c.conv) continue;
+                zc *Hc = &c.H[(size_t)j * (m + 1)];
+                for (int i = 0; i <= j + 1; ++i) Hc[i] = zc(hp[(size_t)i * nb + b].x, hp[(size_t)i * nb + b].y);
+                for (int i = 0; i < j; ++i) {
+                    const zc a = Hc[i], bb = Hc[i + 1];
+                    Hc[i] = c.cs[i] * a + c.sn[i] * bb;
+                    Hc[i + 1] = -std::conj(c.sn[i]) * a + c.cs[i] * bb;
+                }
+                const zc a = Hc[j];
+                const double bb = Hc[j + 1].real();
+                const double aa = std::abs(a);
+                const double t = std::sqrt(aa * aa + bb * bb);
+                if (!(t > 0.0) || std::isnan(t)) { c.conv = true; if (std::isnan(t)) nan_seen = true; continue; }
+                if (aa == 0.0) { c.cs[j] = 0.0; c.sn[j] = 1.0; }
+                else { c.cs[j] = aa / t; c.sn[j] = (a / aa) * (bb / t); }
+                Hc[j] = c.cs[j] * a + c.sn[j] * bb;
+                Hc[j + 1] = 0;
+                c.g[j + 1] = -std::conj(c.sn[j]) * c.g[j];
+                c.g[j] = c.cs[j] * c.g[j];
+                c.steps = j + 1;
+                iters[b]++;
+                relres[b] = std::abs(c.g[j + 1]) / bnorm[b];
+                if (relres[b] <= 0.7 * tol) c.conv = true;
+                else all_conv = false;
+            }
+            if (all_conv || nan_seen) { ++j; break; }
+        }
+        // y = R^{-1} g per column, zero-padded to j steps
+        const int ju = std::min(j, m);
+        std::vector<cplx> y((size_t)std::max(ju, 1) * nb, cplx{0.0, 0.0});
+        for (int b = 0; b < nb; ++b) {
+            ColState &c = cs[b];
+            const int k = c.steps;
+            std::vector<zc> yy(k);
+            for (int i = k - 1; i >= 0; --i) {
+                zc s = c.g[i];
+                for (int q = i + 1; q < k; ++q) s -= c.H[(size_t)q * (m + 1) + i] * yy[q];
+                const zc dgi = c.H[(size_t)i * (m + 1) + i];
+                yy[i] = (dgi != zc(0)) ? s / dgi : zc(0);
+            }
+            for (int i = 0; i < k; ++i) y[(size_t)i * nb + b] = cplx{yy[i].real(), yy[i].imag()};
+        }
+        if (ju > 0) {
+            h->ydev.upload(y.data(), (size_t)ju * nb, st);
+            launch_lincomb(h->V.p, vec, ju, h->ydev.p, h->U.p, n, nb, st);
+            HIP_CHECK(hipStreamSynchronize(st));       // y is a stack vector
+            const cplx *z = vcycle(h, bt, 0, h->U.p);
+            launch_add(z, X, vec, st);
+        }
+        if (nan_seen) break;
+    }
+    if (info) {
+        int imax = 0, itot = 0, nun = 0;
+        double rmax = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            imax = std::max(imax, iters[b]);
+            itot += iters[b];
+            if (bnorm[b] > 0.0) {
+                if (!(relres[b] <= tol)) ++nun;
+                rmax = std::max(rmax, relres[b]);
+            }
+        }
+        info->iters_max = std::max(info->iters_max, imax);
+        info->iters_total += itot;
+        info->n_unconverged += nun;
+        info->relres_max = std::max(info->relres_max, rmax);
+        info->levels = (int)h->ops.size();
+    }
+    if (nan_seen) throw WaeError(WAE_ERR_NAN, "NaN in GMRES");
+}
+
+// ----------------------------------------------------------------------------------------------------
+// helpers
+// ----------------------------------------------------------------------------------------------------
+static void require_solver(const wae_family *h) {
+    if (!h->solver_ready) throw WaeError(WAE_ERR_INVALID, "wae_solver_setup has not been called");
+}
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+template <class F> static int guarded(F &&f) {
+    try {
+        return f();
+    } catch (const WaeError &e) {
+        wae_set_error(e.what());
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        wae_set_error("out of host memory");
+        return WAE_ERR_INVALID;
+    } catch (const std::exception &e) {
+        wae_set_error(e.what());
+        return WAE_ERR_INVALID;
+    }
+}
+
+static int info_code(const wae_solve_info &i) { return i.n_unconverged > 0 ? WAE_WARN_MAXITER : WAE_OK; }
+
+// ----------------------------------------------------------------------------------------------------
+// C ABI
+// ----------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *wae_last_error(void) { return g_last_error.c_str(); }
+const char *wae_version(void) { return "waehip 0.1 (gfx950; fused multi-term CSR SpMV, SA-multigrid GMRES)"; }
+
+int wae_device_count(int *n) {
+    return guarded([&]() {
+        HIP_CHECK(hipGetDeviceCount(n));
+        return WAE_OK;
+    });
+}
+
+int wae_family_create(wae_family **out, int64_t d, int32_t T, int32_t index_bytes, int32_t base, int32_t orientation,
+                      const void *const *ptr, const void *const *idx, const double *const *val, int32_t device) {
+    return guarded([&]() {
+        WAE_REQUIRE(out && d > 0 && T > 0 && T <= 64, "bad d/T");
+        WAE_REQUIRE(index_bytes == 4 || index_bytes == 8, "index_bytes must be 4 or 8");
+        WAE_REQUIRE(base == 0 || base == 1, "base must be 0 or 1");
+        WAE_REQUIRE(d < 2147483647, "d too large for 32-bit indices");
+        int ndev = 0;
+        HIP_CHECK(hipGetDeviceCount(&ndev));
+        WAE_REQUIRE(device >= 0 && device < ndev, "no such HIP device");
+        HIP_CHECK(hipSetDevice(device));
+        std::unique_ptr<wae_family> h(new wae_family);
+        h->device = device;
+        h->d = d;
+        h->T = T;
+        HIP_CHECK(hipStreamCreate(&h->stream));
+        h->term_plane.resize(T);
+        h->term_scale.resize(T);
+        h->term_nnz.resize(T);
+        for (int k = 0; k < T; ++k) {
+            CsrZ A = term_to_csr(d, index_bytes, base, orientation, ptr[k], idx[k], val[k]);
+            h->term_nnz[k] = A.nnz();
+            bool found = false;
+            for (int q = 0; q < (int)h->planes0.size() && !found; ++q) {
+                zc s;
+                if (proportional(A, h->planes0[q], s)) { h->term_plane[k] = q; h->term_scale[k] = s; found = true; }
+            }
+            if (!found) {
+                h->term_plane[k] = (int)h->planes0.size();
+                h->term_scale[k] = 1.0;
+                h->planes0.push_back(std::move(A));
+            }
+        }
+        h->nplanes = (int)h->planes0.size();
+        h->ops.resize(1);
+        h->slot_plane.resize(1);
+        h->slot_plane[0] = build_levelop(h->ops[0], h->planes0, h->stream);
+        cplx one = {1.0, 0.0};
+        h->one_dev.upload(&one, 1, h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        *out = h.release();
+        return WAE_OK;
+    });
+}
+
+int wae_family_destroy(wae_family *h) {
+    return guarded([&]() {
+        if (h) {
+            (void)hipSetDevice(h->device);
+            delete h;
+        }
+        return WAE_OK;
+    });
+}
+
+int wae_family_info(const wae_family *h, int64_t *d, int32_t *T, int64_t *nnz_total) {
+    return guarded([&]() {
+        WAE_REQUIRE(h, "null handle");
+        if (d) *d = h->d;
+        if (T) *T = h->T;
+        if (nnz_total) { int64_t s = 0; for (auto v : h->term_nnz) s += v; *nnz_total = s; }
+        return WAE_OK;
+    });
+}
+
+int64_t wae_family_spmv_bytes(const wae_family *h, const uint8_t *mask, int32_t r) {
+    if (!h) return -1;
+    int64_t bytes = 0;
+    for (int k = 0; k < h->T; ++k)
+        if (!mask || mask[k]) bytes += h->term_nnz[k] * 20 + (h->d + 1) * 4;
+    return bytes + 2 * (int64_t)r * h->d * 16;
+}
+
+static void ensure(DevBuf<cplx> &b, size_t n) { if (b.n < n) b.alloc(n); }
+
+int wae_spmv_sum(wae_family *h, const double *coeffs, const double *X, double *Y, int32_t r, int32_t op) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && coeffs && X && Y && r > 0, "bad argument");
+        WAE_REQUIRE(op >= 0 && op <= 2, "bad op");
+        HIP_CHECK(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        const size_t cnt = (size_t)h->d * r;
+        ensure(h->io_a, cnt); ensure(h->io_b, cnt);
+        DevBuf<cplx> xi, yi;
+        xi.alloc(cnt); yi.alloc(cnt);
+        std::vector<zc> pc;
+        plane_coeffs(h, coeffs, op, pc);
+        std::vector<cplx> tab(h->nplanes);
+        for (int q = 0; q < h->nplanes; ++q) { const zc c = pc[h->slot_plane[0][q]]; tab[q] = cplx{c.real(), c.imag()}; }
+        DevBuf<cplx> pcd;
+        pcd.upload(tab.data(), tab.size(), st);
+        HIP_CHECK(hipMemcpyAsync(h->io_a.p, X, cnt * sizeof(cplx), hipMemcpyHostToDevice, st));
+        launch_colmajor_to_inter(h->io_a.p, h->d, r, xi.p, r, st);
+        launch_spmv(h->ops[0].dev(op), pcd.p, 1 << 30, xi.p, yi.p, nullptr, 0.0, r, MODE_AX, st);
+        launch_inter_to_colmajor(yi.p, r, h->d, r, h->io_b.p, st);
+        HIP_CHECK(hipMemcpyAsync(Y, h->io_b.p, cnt * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        xi.release(); yi.release(); pcd.release();
+        return WAE_OK;
+    });
+}
+
+int wae_spmv_sum_multi(wae_family *h, const double *coeffs, const double *X, double *Y) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && coeffs && X && Y, "bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        // a term aliased onto a shared plane still multiplies its own input column, so expand per TERM:
+        // Y = sum_k c_k A_k X[:,k].  Terms sharing a plane are handled by one pass per distinct input column.
+        const int T = h->T;
+        const size_t cnt = (size_t)h->d * T;
+        ensure(h->io_a, cnt); ensure(h->io_b, (size_t)h->d);
+        DevBuf<cplx> xi, yi, acc, pcd;
+        xi.alloc(cnt); yi.alloc((size_t)h->d); acc.alloc((size_t)h->d);
+        HIP_CHECK(hipMemcpyAsync(h->io_a.p, X, cnt * sizeof(cplx), hipMemcpyHostToDevice, st));
+        launch_colmajor_to_inter(h->io_a.p, h->d, T, xi.p, T, st);
+        launch_fill_zero(acc.p, (size_t)h->d, st);
+        // passes: in pass t every plane takes the t-th term mapped to it (if any)
+        std::vector<std::vector<int>> plane_terms(h->nplanes);
+        for (int k = 0; k < T; ++k) plane_terms[h->term_plane[k]].push_back(k);
+        size_t npass = 0;
+        for (auto &v : plane_terms) npass = std::max(npass, v.size());
+        std::vector<cplx> tab(h->nplanes);
+        std::vector<int> pcol(h->nplanes);
+        for (size_t t = 0; t < npass; ++t) {
+            for (int s = 0; s < h->nplanes; ++s) {
+                const int q = h->slot_plane[0][s];
+                if (t < plane_terms[q].size()) {
+                    const int k = plane_terms[q][t];
+                    const zc c = h->term_scale[k] * zc(coeffs[2 * k], coeffs[2 * k + 1]);
+                    tab[s] = cplx{c.real(), c.imag()};
+                    pcol[s] = k;
+                } else { tab[s] = cplx{0.0, 0.0}; pcol[s] = 0; }
+            }
+            pcd.upload(tab.data(), tab.size(), st);
+            h->plane_col_dev.upload(pcol.data(), pcol.size(), st);
+            launch_spmv_multi(h->ops[0].dev(WAE_OP_N), pcd.p, h->plane_col_dev.p, xi.p, yi.p, T, st);
+            launch_add(yi.p, acc.p, (size_t)h->d, st);
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
+        HIP_CHECK(hipMemcpyAsync(Y, acc.p, (size_t)h->d * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        xi.release(); yi.release(); acc.release(); pcd.release();
+        return WAE_OK;
+    });
+}
+
+int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts, int32_t nopts) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && coeffs_ref, "bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        AmgOptions ao;
+        auto opt = [&](int i, double dflt) { return (opts && i < nopts && opts[i] > 0) ? opts[i] : dflt; };
+        ao.theta = opt(0, 0.02);
+        ao.max_coarse = (int64_t)opt(1, 128);
+        h->jac_w = opt(2, 0.8);
+        h->nsweeps = (int)opt(3, 1);
+        h->restart = (int)opt(4, 30);
+        ao.penalty_ratio = opt(5, 1e8);
+        h->NB = (int)opt(6, 64);
+        WAE_REQUIRE(h->NB >= 1 && h->NB <= 256, "batch width must be in 1..256");
+        WAE_REQUIRE(h->restart >= 2 && h->restart <= 200, "restart must be in 2..200");
+        // drop a previous hierarchy
+        for (size_t l = 1; l < h->ops.size(); ++l) {
+            h->ops[l].diag.release();
+            for (auto &G : h->ops[l].groups) { G.rowptr.release(); G.col.release(); G.rowptr_t.release(); G.col_t.release(); G.vals.release(); G.vals_t.release(); }
+        }
+        h->ops.resize(1);
+        h->slot_plane.resize(1);
+        for (auto &X : h->xfer) { X.p_ptr.release(); X.p_col.release(); X.r_ptr.release(); X.r_col.release(); X.p_val.release(); X.r_val.release(); }
+        h->xfer.clear();
+        std::vector<zc> pc;
+        plane_coeffs(h, coeffs_ref, WAE_OP_N, pc);
+        std::vector<AmgLevel> lv;
+        amg_setup(h->planes0, pc, ao, lv);
+        hipStream_t st = h->stream;
+        h->ops.resize(lv.size() + 1);
+        h->slot_plane.resize(lv.size() + 1);
+        h->xfer.resize(lv.size());
+        for (size_t l = 0; l < lv.size(); ++l) {
+            h->slot_plane[l + 1] = build_levelop(h->ops[l + 1], lv[l].coarse_planes, st);
+            Transfer &X = h->xfer[l];
+            X.nf = lv[l].P.n; X.nc = lv[l].P.m;
+            X.p_ptr.upload(lv[l].P.ptr.data(), lv[l].P.ptr.size(), st);
+            X.p_col.upload(lv[l].P.col.data(), lv[l].P.col.size(), st);
+            X.p_val.upload(lv[l].P.val.data(), lv[l].P.val.size(), st);
+            X.r_ptr.upload(lv[l].R.ptr.data(), lv[l].R.ptr.size(), st);
+            X.r_col.upload(lv[l].R.col.data(), lv[l].R.col.size(), st);
+            X.r_val.upload(lv[l].R.val.data(), lv[l].R.val.size(), st);
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
+        // dense planes of the coarsest level (plane order, row-major)
+        const std::vector<CsrZ> &last = lv.empty() ? h->planes0 : lv.back().coarse_planes;
+        h->nc = last[0].n;
+        WAE_REQUIRE(h->nc <= 2048, "coarsest level too large for the dense solver (increase levels / lower max_coarse)");
+        {
+            const size_t nn = (size_t)h->nc * h->nc;
+            std::vector<cplx> dp(nn * h->nplanes, cplx{0.0, 0.0});
+            const std::vector<int> &sp = h->slot_plane.back();
+            for (int s = 0; s < h->nplanes; ++s) {
+                const CsrZ &A = last[sp[s]];
+                for (int64_t i = 0; i < A.n; ++i)
+                    for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) dp[(size_t)s * nn + (size_t)i * h->nc + A.col[p]] = cplx{A.val[p].real(), A.val[p].imag()};
+            }
+            h->dense_planes.upload(dp.data(), dp.size(), st);
+            HIP_CHECK(hipStreamSynchronize(st));
+            h->Ainv.alloc(nn * h->NB);
+            h->dstatus.alloc(1);
+        }
+        // workspaces
+        const int NB = h->NB, m = h->restart;
+        const int nl = (int)h->ops.size();
+        h->lx.resize(nl); h->lb.resize(nl); h->lt.resize(nl);
+        for (int l = 0; l < nl; ++l) {
+            const size_t cnt = (size_t)h->ops[l].n * NB;
+            h->lx[l].alloc(cnt); h->lb[l].alloc(cnt); h->lt[l].alloc(cnt);
+        }
+        const size_t vec = (size_t)h->d * NB;
+        h->V.alloc(vec * (m + 1));
+        h->W.alloc(vec); h->Xs.alloc(vec); h->Bs.alloc(vec); h->U.alloc(vec);
+        h->partial.alloc((size_t)512 * 32 * NB);
+        h->hdev.alloc((size_t)(m + 2) * NB);
+        h->ydev.alloc((size_t)(m + 1) * NB);
+        if (h->h_pinned) { (void)hipHostFree(h->h_pinned); h->h_pinned = nullptr; }
+        HIP_CHECK(hipHostMalloc((void **)&h->h_pinned, (size_t)(m + 2) * NB * sizeof(cplx)));
+        h->solver_ready = true;
+        return WAE_OK;
+    });
+}
+
+// solve a chunk of nb columns already on device in interleaved layout
+static void solve_chunk(wae_family *h, const Batch &bt, const std::vector<std::vector<zc>> &pcs, const cplx *B, cplx *X, double tol, int maxit,
+                        wae_solve_info *info) {
+    upload_pc(h, pcs);
+    dense_setup(h, bt);
+    gmres(h, bt, B, X, tol, maxit, info);
+}
+
+int wae_solve(wae_family *h, const double *coeffs, int32_t ncoef, const double *B, double *X, int32_t r, int32_t op, double tol, int32_t maxit,
+              wae_solve_info *info) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && coeffs && B && X && r > 0, "bad argument");
+        WAE_REQUIRE(ncoef == 1 || ncoef == r, "ncoef must be 1 or r");
+        WAE_REQUIRE(op >= 0 && op <= 2, "bad op");
+        require_solver(h);
+        HIP_CHECK(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        wae_solve_info li;
+        memset(&li, 0, sizeof(li));
+        const double t0 = now_s();
+        const int64_t d = h->d;
+        const size_t cnt = (size_t)d * r;
+        ensure(h->io_a, cnt); ensure(h->io_b, cnt);
+        HIP_CHECK(hipMemcpyAsync(h->io_a.p, B, cnt * sizeof(cplx), hipMemcpyHostToDevice, st));
+        for (int c0 = 0; c0 < r; c0 += h->NB) {
+            const int nb = std::min(h->NB, r - c0);
+            Batch bt;
+            bt.nb = nb; bt.op = op;
+            std::vector<std::vector<zc>> pcs;
+            if (ncoef == 1) {
+                bt.cps = nb; bt.nsys = 1;
+                pcs.resize(1);
+                plane_coeffs(h, coeffs, op, pcs[0]);
+            } else {
+                bt.cps = 1; bt.nsys = nb;
+                pcs.resize(nb);
+                for (int b = 0; b < nb; ++b) plane_coeffs(h, coeffs + (size_t)(c0 + b) * 2 * h->T, op, pcs[b]);
+            }
+            launch_colmajor_to_inter(h->io_a.p + (size_t)c0 * d, d, nb, h->Bs.p, nb, st);
+            solve_chunk(h, bt, pcs, h->Bs.p, h->Xs.p, tol, maxit, &li);
+            launch_inter_to_colmajor(h->Xs.p, nb, d, nb, h->io_b.p + (size_t)c0 * d, st);
+        }
+        HIP_CHECK(hipMemcpyAsync(X, h->io_b.p, cnt * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        li.seconds = now_s() - t0;
+        if (info) *info = li;
+        return info_code(li);
+    });
+}
+
+int wae_beyn_moments(wae_family *h, int32_t npts, const double *z, const double *w, const double *coeff_table, const double *V, int32_t l, int32_t K,
+                     double tol, int32_t maxit, double *A_out, uint64_t out_dev, wae_solve_info *info) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && npts >= 0 && (npts == 0 || (z && w && coeff_table)) && V && l > 0 && K > 0, "bad argument");
+        WAE_REQUIRE(A_out || out_dev, "no output buffer");
+        require_solver(h);
+        WAE_REQUIRE(l <= h->NB, "l exceeds the solver batch width");
+        HIP_CHECK(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        wae_solve_info li;
+        memset(&li, 0, sizeof(li));
+        const double t0 = now_s();
+        const int64_t d = h->d;
+        const int npow = 2 * K;
+        const size_t acnt = (size_t)d * l * npow;
+        DevBuf<cplx> Aown;
+        cplx *Ad = (cplx *)(uintptr_t)out_dev;
+        if (!Ad) { Aown.alloc(acnt); Ad = Aown.p; }
+        launch_fill_zero(Ad, acnt, st);
+        ensure(h->io_a, (size_t)d * l);
+        HIP_CHECK(hipMemcpyAsync(h->io_a.p, V, (size_t)d * l * sizeof(cplx), hipMemcpyHostToDevice, st));
+        const int spc = std::max(1, h->NB / l);   // systems per chunk
+        ensure(h->zw_dev, (size_t)2 * spc);
+        for (int p0 = 0; p0 < npts; p0 += spc) {
+            const int ns = std::min(spc, npts - p0);
+            Batch bt;
+            bt.nb = ns * l; bt.cps = l; bt.nsys = ns; bt.op = WAE_OP_N;
+            std::vector<std::vector<zc>> pcs(ns);
+            std::vector<cplx> zw(2 * ns);
+            for (int s = 0; s < ns; ++s) {
+                plane_coeffs(h, coeff_table + (size_t)(p0 + s) * 2 * h->T, WAE_OP_N, pcs[s]);
+                zw[s] = cplx{w[2 * (p0 + s)], w[2 * (p0 + s) + 1]};
+                zw[ns + s] = cplx{z[2 * (p0 + s)], z[2 * (p0 + s) + 1]};
+            }
+            h->zw_dev.upload(zw.data(), zw.size(), st);
+            HIP_CHECK(hipStreamSynchronize(st));
+            launch_replicate(h->io_a.p, d, l, h->Bs.p, bt.nb, st);
+            solve_chunk(h, bt, pcs, h->Bs.p, h->Xs.p, tol, maxit, &li);
+            launch_beyn_accum(h->Xs.p, bt.nb, d, l, ns, h->zw_dev.p, h->zw_dev.p + ns, npow, Ad, st);
+        }
+        if (A_out) HIP_CHECK(hipMemcpyAsync(A_out, Ad, acnt * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        Aown.release();
+        li.seconds = now_s() - t0;
+        if (info) *info = li;
+        return info_code(li);
+    });
+}
+
+int wae_arnoldi_shiftinvert(wae_family *h, const double *coeffsA, const double *coeffsM, int32_t m, const double *v0, int32_t op, double tol,
+                            int32_t maxit, double *H_out, double *V_out, wae_solve_info *info) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && coeffsA && coeffsM && v0 && H_out && V_out && m >= 1 && m <= 256, "bad argument");
+        WAE_REQUIRE(op == WAE_OP_N || op == WAE_OP_C || op == WAE_OP_T, "bad op");
+        require_solver(h);
+        HIP_CHECK(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        wae_solve_info li;
+        memset(&li, 0, sizeof(li));
+        const double t0 = now_s();
+        const int64_t d = h->d;
+        DevBuf<cplx> EV, t, pcM, hcol;
+        EV.alloc((size_t)d * (m + 1));
+        t.alloc((size_t)d);
+        hcol.alloc((size_t)2 * (m + 2));
+        std::vector<zc> pcm;
+        plane_coeffs(h, coeffsM, op, pcm);
+        std::vector<cplx> tab(h->nplanes);
+        for (int q = 0; q < h->nplanes; ++q) { const zc c = pcm[h->slot_plane[0][q]]; tab[q] = cplx{c.real(), c.imag()}; }
+        pcM.upload(tab.data(), tab.size(), st);
+        Batch bt;
+        bt.nb = 1; bt.cps = 1; bt.nsys = 1; bt.op = op;
+        std::vector<std::vector<zc>> pcs(1);
+        plane_coeffs(h, coeffsA, op, pcs[0]);
+        upload_pc(h, pcs);
+        dense_setup(h, bt);
+        std::vector<zc> H((size_t)(m + 1) * m, zc(0));
+        // v_0 = v0 / ||v0||
+        HIP_CHECK(hipMemcpyAsync(t.p, v0, (size_t)d * sizeof(cplx), hipMemcpyHostToDevice, st));
+        launch_norms(t.p, d, 1, h->partial.p, hcol.p, st);
+        launch_scale_inv(t.p, hcol.p, EV.p, d, 1, st);
+        const OpDev Mop = h->ops[0].dev(op);
+        std::vector<cplx> hh(m + 2);
+        int done = 0;
+        for (int j = 0; j < m; ++j) {
+            launch_spmv(Mop, pcM.p, 1 << 30, EV.p + (size_t)j * d, t.p, nullptr, 0.0, 1, MODE_AX, st);
+            gmres(h, bt, t.p, h->Xs.p, tol, maxit, &li);
+            cplx *w = h->Xs.p;
+            // classical Gram-Schmidt, two passes
+            std::vector<zc> hc(j + 2, zc(0));
+            for (int pass = 0; pass < 2; ++pass) {
+                launch_dots(EV.p, (size_t)d, j + 1, w, d, 1, h->partial.p, hcol.p, st);
+                launch_axpy_neg(EV.p, (size_t)d, j + 1, hcol.p, w, d, 1, st);
+                HIP_CHECK(hipMemcpyAsync(hh.data(), hcol.p, (size_t)(j + 1) * sizeof(cplx), hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                for (int i = 0; i <= j; ++i) hc[i] += zc(hh[i].x, hh[i].y);
+            }
+            launch_norms(w, d, 1, h->partial.p, hcol.p, st);
+            HIP_CHECK(hipMemcpyAsync(hh.data(), hcol.p, sizeof(cplx), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            hc[j + 1] = hh[0].x;
+            for (int i = 0; i <= j + 1; ++i) H[(size_t)j * (m + 1) + i] = hc[i];
+            done = j + 1;
+            double scale = 0.0;
+            for (int i = 0; i <= j; ++i) scale = std::max(scale, std::abs(hc[i]));
+            if (!(hh[0].x > 1e-14 * scale)) { H[(size_t)j * (m + 1) + j + 1] = 0; break; }
+            launch_scale_inv(w, hcol.p, EV.p + (size_t)(j + 1) * d, d, 1, st);
+        }
+        if (done < m) launch_fill_zero(EV.p + (size_t)(done + 1) * d, (size_t)(m - done) * d, st);
+        HIP_CHECK(hipMemcpyAsync(V_out, EV.p, (size_t)d * (m + 1) * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        memcpy(H_out, H.data(), H.size() * sizeof(zc));
+        EV.release(); t.release(); pcM.release(); hcol.release();
+        li.seconds = now_s() - t0;
+        if (info) *info = li;
+        return info_code(li);
+    });
+}
+
+int wae_perturb(wae_family *h, const double *coeff_table, int32_t N, const double *v0, const double *v0adj, int32_t norm_mode, const double *coeffsY,
+                double tol, int32_t maxit, double *lambda_out, double *v_out, wae_solve_info *info) {
+    return guarded([&]() -> int {
+        (void)h; (void)coeff_table; (void)N; (void)v0; (void)v0adj; (void)norm_mode; (void)coeffsY; (void)tol; (void)maxit;
+        (void)lambda_out; (void)v_out; (void)info;
+        throw WaeError(WAE_ERR_INVALID, "wae_perturb: not implemented yet");
+    });
+}
+
+int wae_bench_spmv(wae_family *h, const double *coeffs, int32_t r, int32_t reps, double *ms_out) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && coeffs && r > 0 && reps > 0 && ms_out, "bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        const size_t cnt = (size_t)h->d * r;
+        DevBuf<cplx> x, y, pcd;
+        x.alloc(cnt); y.alloc(cnt);
+        std::vector<cplx> hx(cnt);
+        uint64_t s = 0x9E3779B97F4A7C15ull;
+        for (size_t i = 0; i < cnt; ++i) {
+            s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+            hx[i].x = (double)(s & 0xFFFFF) / 524288.0 - 1.0;
+            hx[i].y = (double)((s >> 20) & 0xFFFFF) / 524288.0 - 1.0;
+        }
+        HIP_CHECK(hipMemcpyAsync(x.p, hx.data(), cnt * sizeof(cplx), hipMemcpyHostToDevice, st));
+        std::vector<zc> pc;
+        plane_coeffs(h, coeffs, WAE_OP_N, pc);
+        std::vector<cplx> tab(h->nplanes);
+        for (int q = 0; q < h->nplanes; ++q) { const zc c = pc[h->slot_plane[0][q]]; tab[q] = cplx{c.real(), c.imag()}; }
+        pcd.upload(tab.data(), tab.size(), st);
+        const OpDev A = h->ops[0].dev(WAE_OP_N);
+        for (int i = 0; i < 3; ++i) launch_spmv(A, pcd.p, 1 << 30, x.p, y.p, nullptr, 0.0, r, MODE_AX, st);
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) launch_spmv(A, pcd.p, 1 << 30, x.p, y.p, nullptr, 0.0, r, MODE_AX, st);
+        HIP_CHECK(hipEventRecord(e1, st));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        *ms_out = (double)ms / reps;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        x.release(); y.release(); pcd.release();
+        return WAE_OK;
+    });
+}
+
+int wae_bench_triad(int32_t device, int64_t n, int32_t reps, double *gbs_out) {
+    return guarded([&]() {
+        WAE_REQUIRE(n > 0 && reps > 0 && gbs_out, "bad argument");
+        HIP_CHECK(hipSetDevice(device));
+        DevBuf<double> a, b, c;
+        a.alloc(n); b.alloc(n); c.alloc(n);
+        HIP_CHECK(hipMemset(b.p, 0, n * sizeof(double)));
+        HIP_CHECK(hipMemset(c.p, 0, n * sizeof(double)));
+        hipStream_t st;
+        HIP_CHECK(hipStreamCreate(&st));
+        for (int i = 0; i < 2; ++i) launch_triad(a.p, b.p, c.p, 1.5, n, st);
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) launch_triad(a.p, b.p, c.p, 1.5, n, st);
+        HIP_CHECK(hipEventRecord(e1, st));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        *gbs_out = 3.0 * n * sizeof(double) * reps / (ms * 1e-3) / 1e9;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipStreamDestroy(st);
+        a.release(); b.release(); c.release();
+        return WAE_OK;
+    });
+}
+
+}   // extern "C"

@@ -1,0 +1,168 @@
+// Internal declarations shared by the translation units of libwaehip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <complex>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/waehip.h"
+
+typedef std::complex<double> zc;
+typedef double2 cplx;   // device complex: x = re, y = im
+
+struct WaeError : std::runtime_error {
+    int code;
+    WaeError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+void wae_set_error(const std::string &m);
+
+#define HIP_CHECK(expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            throw WaeError(WAE_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " at " +   \
+                                            __FILE__ + ":" + std::to_string(__LINE__));                  \
+    } while (0)
+#define WAE_REQUIRE(cond, msg)                                  \
+    do {                                                        \
+        if (!(cond)) throw WaeError(WAE_ERR_INVALID, (msg));    \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// host-side sparse matrices
+// ---------------------------------------------------------------------------------------------------
+struct CsrZ {                       // complex CSR, 0-based, sorted columns, no duplicates
+    int64_t n = 0, m = 0;           // rows, cols
+    std::vector<int> ptr, col;
+    std::vector<zc> val;
+    int64_t nnz() const { return (int64_t)col.size(); }
+};
+struct CsrD {                       // real CSR
+    int64_t n = 0, m = 0;
+    std::vector<int> ptr, col;
+    std::vector<double> val;
+    int64_t nnz() const { return (int64_t)col.size(); }
+};
+CsrZ csr_transpose(const CsrZ &A);
+CsrD csr_transpose(const CsrD &A);
+bool csr_same_pattern(const CsrZ &A, const CsrZ &B);
+CsrZ galerkin(const CsrD &R, const CsrZ &A, const CsrD &P);   // R*A*P
+
+// ---------------------------------------------------------------------------------------------------
+// device-side operator description
+// ---------------------------------------------------------------------------------------------------
+constexpr int WAE_MAXG = 8;         // pattern groups per level operator
+constexpr int WAE_MAXP = 32;        // value planes in total per level operator
+
+struct GroupDev {                   // one sparsity pattern shared by `nplanes` value planes
+    const int *rowptr;              // n+1
+    const int *col;                 // nnz
+    const void *vals;               // [nnz][nplanes] interleaved, double (is_real) or double2
+    int nplanes;
+    int is_real;
+    int plane0;                     // first plane index in the per-system coefficient table
+    int conj_vals;                  // conjugate complex values on the fly (op = C on a symmetric pattern)
+};
+struct OpDev {
+    int ngroups;
+    int nplanes_total;
+    int64_t n;
+    GroupDev g[WAE_MAXG];
+    const cplx *diag;               // [n][nplanes_total] diagonal of every plane (for Jacobi), may be null
+};
+
+// device buffer with RAII-less explicit free (owned by the family)
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count) HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+    }
+    void upload(const T *h, size_t count, hipStream_t s) {
+        if (count > n) alloc(count);
+        if (count) HIP_CHECK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+struct GroupHost {                  // a pattern group held on device, N and T orientation
+    int nplanes = 0;
+    bool is_real = true;
+    bool symmetric = false;         // A^T == A for every plane: T orientation aliases N
+    int64_t nnz = 0;
+    int plane0 = 0;
+    DevBuf<int> rowptr, col, rowptr_t, col_t;
+    DevBuf<double> vals, vals_t;    // raw storage (nnz*nplanes*(1 or 2) doubles)
+};
+
+struct LevelOp {                    // sum_q pc[q] * plane_q  at one multigrid level
+    int64_t n = 0;
+    int nplanes = 0;
+    std::vector<GroupHost> groups;
+    DevBuf<cplx> diag;              // [n][nplanes]
+    OpDev dev(int op) const;        // op: WAE_OP_N / T / C
+    // host copies of the planes (kept for Galerkin products and dense coarse assembly)
+    std::vector<CsrZ> planes;
+};
+
+struct Transfer {                   // P (n_fine x n_coarse) and R = P^T as single-plane real operators
+    int64_t nf = 0, nc = 0;
+    DevBuf<int> p_ptr, p_col, r_ptr, r_col;
+    DevBuf<double> p_val, r_val;
+    OpDev devP() const;
+    OpDev devR() const;
+};
+
+// kernel launch wrappers (kernels.hip) -----------------------------------------------------------------
+enum { MODE_AX = 0, MODE_RES = 1, MODE_JAC = 2, MODE_ADD = 3 };
+// Y = f(A X) over columns [0,nb) of interleaved multivectors (leading dimension nb).
+//   pc: [nsys][nplanes_total] plane coefficients; column b uses row b / cps.
+//   MODE_AX : Y = A X            MODE_RES: Y = B - A X
+//   MODE_JAC: Y = X + w/diag (B - A X)   (diag from op.diag and pc)      MODE_ADD: Y = B + A X
+void launch_spmv(const OpDev &op, const cplx *pc, int cps, const cplx *X, cplx *Y, const cplx *B, double jac_w,
+                 int nb, int mode, hipStream_t s);
+// X = w/diag * B  (first Jacobi sweep from a zero initial guess)
+void launch_jacobi0(const OpDev &op, const cplx *pc, int cps, const cplx *B, cplx *X, double jac_w, int nb, hipStream_t s);
+// multi-input variant: Y[:,0] = sum_q pc[q] plane_q X[:, term_of_plane(q)]  (X interleaved with leading dim nb)
+void launch_spmv_multi(const OpDev &op, const cplx *pc, const int *plane_col, const cplx *X, cplx *Y, int nb, hipStream_t s);
+
+// dense coarse level: assemble A_s = sum_q pc[s][q] planes[q] (n x n, row-major per system), invert in place
+void launch_dense_assemble(const cplx *planes, int nplanes, int n, const cplx *pc, int nsys, int transpose_conj,
+                           cplx *Ainv, hipStream_t s);
+void launch_dense_invert(cplx *Ainv, int n, int nsys, int *status, hipStream_t s);
+void launch_dense_apply(const cplx *Ainv, int n, int cps, const cplx *X, cplx *Y, int nb, hipStream_t s);
+
+// vector kernels on interleaved multivectors [n][nb]
+void launch_fill_zero(cplx *X, size_t count, hipStream_t s);
+void launch_copy(const cplx *X, cplx *Y, size_t count, hipStream_t s);
+// partial dots: out[i][b] = sum_rows conj(V_i[row][b]) * W[row][b], i = 0..nv-1; V_i = V + i*stride
+void launch_dots(const cplx *V, size_t stride, int nv, const cplx *W, int64_t n, int nb, cplx *partial, cplx *out, hipStream_t s);
+// W -= sum_i h[i][b] V_i
+void launch_axpy_neg(const cplx *V, size_t stride, int nv, const cplx *h, cplx *W, int64_t n, int nb, hipStream_t s);
+// Y = sum_i y[i][b] V_i
+void launch_lincomb(const cplx *V, size_t stride, int nv, const cplx *y, cplx *Y, int64_t n, int nb, hipStream_t s);
+// norms: out[b] = ||X[:,b]||_2  (real part of out[b], imag 0)
+void launch_norms(const cplx *X, int64_t n, int nb, cplx *partial, cplx *out, hipStream_t s);
+// Y[:,b] = X[:,b] * (1/alpha[b].x)  (0 if alpha tiny)
+void launch_scale_inv(const cplx *X, const cplx *alpha, cplx *Y, int64_t n, int nb, hipStream_t s);
+// Y += X
+void launch_add(const cplx *X, cplx *Y, size_t count, hipStream_t s);
+// layout changes: column-major d x r  <->  interleaved [d][nb] (columns >= r zero-filled / ignored)
+void launch_colmajor_to_inter(const cplx *Xc, int64_t d, int r, cplx *Xi, int nb, hipStream_t s);
+void launch_inter_to_colmajor(const cplx *Xi, int nb, int64_t d, int r, cplx *Xc, hipStream_t s);
+// replicate V (col-major d x l) into an interleaved block: column b -> V[:, b % l]
+void launch_replicate(const cplx *Vc, int64_t d, int l, cplx *Xi, int nb, hipStream_t s);
+// Beyn accumulation: A[(p*l+c)*d + row] += sum_s w[s] z[s]^p X[row][s*l+c], s < nsys, p < npow
+void launch_beyn_accum(const cplx *Xi, int nb, int64_t d, int l, int nsys, const cplx *w, const cplx *z, int npow, cplx *A, hipStream_t s);
+// triad for bandwidth measurement
+void launch_triad(double *a, const double *b, const double *c, double s_, int64_t n, hipStream_t s);

@@ -1,0 +1,397 @@
+"""Term / LinearOperatorFamily / Solution with the reference's semantics (src/NLEVP/LinOpFam.jl), backed by a
+device-resident family handle.
+
+Difference to the reference by design: calling ``L(z)`` does NOT materialise a sparse matrix
+(LinOpFam.jl:499-521 allocates T+1 of them per call); it returns a light ``Operator`` view = (device handle,
+T coefficients) that supports what the reference's solvers do with the matrix: ``A @ x`` (fused multi-term
+SpMV on the GPU), ``A.solve(b)`` (Julia ``A\\b``: multigrid-GMRES on the GPU), ``A.H`` (Julia ``A'``), ``shape``.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+from math import factorial
+
+import numpy as np
+import scipy.sparse as sp
+
+from .. import _lib
+from .._lib import OP_C, OP_N, SolveInfo, check, zptr
+
+NaN = complex(float("nan"), float("nan"))
+
+
+class Term:
+    """LinOpFam.jl:16-35, 61-75"""
+
+    def __init__(self, coeff, func, params, symbol="", operator=""):
+        if isinstance(symbol, str) and operator == "" and symbol != "":
+            # Term(coeff, func, params, operator) form (LinOpFam.jl:61): 4th positional argument is the operator name
+            operator, symbol = symbol, ""
+        self.coeff = coeff
+        self.func = tuple(func)
+        self.params = tuple(tuple(p) for p in params)
+        self.symbol = symbol
+        self.operator = operator
+        varlist = []
+        for par in self.params:
+            for var in par:
+                if var not in varlist:
+                    varlist.append(var)
+        self.varlist = varlist
+
+    def scalar(self, d):
+        """the scalar part of the term functor, LinOpFam.jl:466-477"""
+        c = 1.0 + 0j
+        for func, pars in zip(self.func, self.params):
+            c *= func(*[d[p][0] for p in pars], *[d[p][1] for p in pars])
+        return complex(c)
+
+
+class Solution:
+    """LinOpFam.jl:95-112; callable like the reference's (LinOpFam.jl:684-699)."""
+
+    def __init__(self, params, v, v_adj, eigval, auxval=""):
+        self.params = copy.deepcopy(params)
+        self.v = v
+        self.v_adj = v_adj
+        self.eigval = eigval
+        self.eigval_pert = {}
+        self.v_pert = {}
+        self.auxval = auxval
+
+    def __call__(self, param, eps, L=0, M=0):
+        key = f"{param}/[{L}/{M}]"
+        if key not in self.eigval_pert:
+            self.eigval_pert[key] = pade(self.eigval_pert[f"{param}/Taylor"], L, M)
+        a, b = self.eigval_pert[key]
+        de = eps - self.params[param]
+        return polyval(a, de) / polyval(b, de)
+
+
+class DeviceFamily:
+    """Owner of a ``wae_family`` handle: all term matrices resident in HBM (include/waehip.h)."""
+
+    def __init__(self, mats, device=0):
+        lib = _lib.lib()
+        self.T = len(mats)
+        self.d = mats[0].shape[0]
+        csr = []
+        for A in mats:
+            A = sp.csr_matrix(A, dtype=np.complex128)
+            A.sum_duplicates()
+            A.sort_indices()
+            csr.append(A)
+        self._ptr_arrays = [A.indptr.astype(np.int32) for A in csr]
+        self._idx_arrays = [A.indices.astype(np.int32) for A in csr]
+        self._val_arrays = [np.ascontiguousarray(A.data, dtype=np.complex128) for A in csr]
+        ptrs = (C.c_void_p * self.T)(*[a.ctypes.data for a in self._ptr_arrays])
+        idxs = (C.c_void_p * self.T)(*[a.ctypes.data for a in self._idx_arrays])
+        vals = (C.c_void_p * self.T)(*[a.ctypes.data for a in self._val_arrays])
+        self.handle = C.c_void_p()
+        check(lib.wae_family_create(C.byref(self.handle), self.d, self.T, 4, 0, _lib.CSR, ptrs, idxs, vals, device))
+        self.device = device
+        self.solver_ready = False
+        self.last_info = None
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle:
+            _lib.lib().wae_family_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- operator application ------------------------------------------------------------------------
+    def spmv(self, coeffs, X, op=OP_N):
+        c = np.ascontiguousarray(coeffs, dtype=np.complex128)
+        X = np.asarray(X, dtype=np.complex128)
+        one = X.ndim == 1
+        Xf = np.asfortranarray(X.reshape(self.d, -1))
+        Y = np.empty_like(Xf, order="F")
+        check(_lib.lib().wae_spmv_sum(self.handle, zptr(c), zptr(Xf), zptr(Y), Xf.shape[1], op))
+        return Y[:, 0].copy() if one else Y
+
+    def spmv_multi(self, coeffs, X):
+        c = np.ascontiguousarray(coeffs, dtype=np.complex128)
+        Xf = np.asfortranarray(np.asarray(X, dtype=np.complex128).reshape(self.d, self.T))
+        Y = np.empty(self.d, dtype=np.complex128)
+        check(_lib.lib().wae_spmv_sum_multi(self.handle, zptr(c), zptr(Xf), zptr(Y)))
+        return Y
+
+    def spmv_bytes(self, r=1, mask=None):
+        m = None if mask is None else (C.c_uint8 * self.T)(*[1 if x else 0 for x in mask])
+        return _lib.lib().wae_family_spmv_bytes(self.handle, m, r)
+
+    # -- solver --------------------------------------------------------------------------------------
+    def setup_solver(self, coeffs_ref, theta=0.02, max_coarse=128, jacobi_weight=0.8, sweeps=1, restart=30,
+                     penalty_ratio=1e8, batch=64):
+        c = np.ascontiguousarray(coeffs_ref, dtype=np.complex128)
+        opts = np.array([theta, max_coarse, jacobi_weight, sweeps, restart, penalty_ratio, batch], dtype=np.float64)
+        check(_lib.lib().wae_solver_setup(self.handle, zptr(c), opts.ctypes.data_as(C.POINTER(C.c_double)), len(opts)))
+        self.solver_ready = True
+        self.batch = batch
+
+    def solve(self, coeffs, B, op=OP_N, tol=1e-12, maxit=300, strict=False):
+        c = np.ascontiguousarray(coeffs, dtype=np.complex128)
+        B = np.asarray(B, dtype=np.complex128)
+        one = B.ndim == 1
+        Bf = np.asfortranarray(B.reshape(self.d, -1))
+        r = Bf.shape[1]
+        ncoef = 1 if c.ndim == 1 else c.shape[0]
+        X = np.empty_like(Bf, order="F")
+        info = SolveInfo()
+        code = check(_lib.lib().wae_solve(self.handle, zptr(c), ncoef, zptr(Bf), zptr(X), r, op, tol, maxit, C.byref(info)),
+                     warn_ok=not strict)
+        self.last_info = info.as_dict()
+        self.last_code = code
+        return X[:, 0].copy() if one else X
+
+    def beyn_moments(self, z, w, coeff_table, V, K=1, tol=1e-10, maxit=300, out_dev=0):
+        z = np.ascontiguousarray(z, dtype=np.complex128)
+        w = np.ascontiguousarray(w, dtype=np.complex128)
+        ct = np.ascontiguousarray(coeff_table, dtype=np.complex128)
+        Vf = np.asfortranarray(np.asarray(V, dtype=np.complex128))
+        l = Vf.shape[1]
+        info = SolveInfo()
+        A = None
+        aptr = None
+        if not out_dev:
+            A = np.zeros((self.d, l, 2 * K), dtype=np.complex128, order="F")
+            aptr = zptr(A)
+        code = check(_lib.lib().wae_beyn_moments(self.handle, len(z), zptr(z), zptr(w), zptr(ct), zptr(Vf), l, K, tol, maxit,
+                                                 aptr, int(out_dev), C.byref(info)))
+        self.last_info = info.as_dict()
+        self.last_code = code
+        return A
+
+    def arnoldi(self, coeffsA, coeffsM, m, v0, op=OP_N, tol=1e-12, maxit=300):
+        cA = np.ascontiguousarray(coeffsA, dtype=np.complex128)
+        cM = np.ascontiguousarray(coeffsM, dtype=np.complex128)
+        v0 = np.ascontiguousarray(v0, dtype=np.complex128)
+        H = np.zeros((m + 1, m), dtype=np.complex128, order="F")
+        V = np.zeros((self.d, m + 1), dtype=np.complex128, order="F")
+        info = SolveInfo()
+        code = check(_lib.lib().wae_arnoldi_shiftinvert(self.handle, zptr(cA), zptr(cM), m, zptr(v0), op, tol, maxit, zptr(H), zptr(V),
+                                                        C.byref(info)))
+        self.last_info = info.as_dict()
+        self.last_code = code
+        return H, V
+
+    def bench_spmv(self, coeffs, r=1, reps=20):
+        c = np.ascontiguousarray(coeffs, dtype=np.complex128)
+        ms = C.c_double(0)
+        check(_lib.lib().wae_bench_spmv(self.handle, zptr(c), r, reps, C.byref(ms)))
+        return ms.value
+
+
+class Operator:
+    """What ``L(z)`` returns here: sum_k c_k A_k on the device (no matrix is assembled)."""
+
+    def __init__(self, fam, coeffs, op=OP_N, owner=None):
+        self.fam = fam
+        self.coeffs = np.asarray(coeffs, dtype=np.complex128)
+        self.op = op
+        self.owner = owner
+        self.shape = (fam.d, fam.d)
+
+    @property
+    def H(self):
+        """Julia ``A'`` (Householder.jl:101, iterative_solvers.jl:398,572)"""
+        return Operator(self.fam, self.coeffs, OP_N if self.op == OP_C else OP_C, self.owner)
+
+    def __matmul__(self, x):
+        return self.fam.spmv(self.coeffs, x, self.op)
+
+    dot = __matmul__
+
+    def solve(self, b, tol=None, maxit=None):
+        """Julia ``A \\ b`` (beyn.jl:65; iterative_solvers.jl:307,397-398)"""
+        own = self.owner
+        if own is not None:
+            own.ensure_solver()
+        tol = tol if tol is not None else (own.solver_tol if own is not None else 1e-12)
+        maxit = maxit if maxit is not None else (own.solver_maxit if own is not None else 300)
+        return self.fam.solve(self.coeffs, b, self.op, tol, maxit)
+
+    def __neg__(self):
+        return Operator(self.fam, -self.coeffs, self.op, self.owner)
+
+    def toarray(self):
+        """dense copy (small problems / tests only)"""
+        return self @ np.eye(self.shape[0], dtype=np.complex128)
+
+
+class LinearOperatorFamily:
+    """LinOpFam.jl:131-186 (type + constructors), :305-346 (push!), :482-529 (functor)."""
+
+    def __init__(self, params=("λ",), values=None, device=0):
+        params = list(params)
+        if values is None:
+            values = [NaN for _ in params]
+        self.terms = []
+        self.eigval = params[0]
+        self.auxval = params[-1] if len(params) > 1 else ""
+        self.active = [self.eigval]
+        self.params = {p: complex(v) for p, v in zip(params, values)}
+        self.mode = "all"
+        self.device_id = device
+        self._fam = None
+        # inner-solver controls (no reference counterpart: the reference solves directly with UMFPACK)
+        self.solver_tol = 1e-12
+        self.solver_maxit = 400
+        self.solver_opts = {}
+        self.solver_ref = None          # reference value of the eigenvalue parameter for the multigrid set-up
+
+    # -- term management -------------------------------------------------------------------------------
+    def push(self, T):
+        """push!  LinOpFam.jl:305-346"""
+        self._drop_device()
+        for idx, term in enumerate(self.terms):
+            if term.func == T.func and term.params == T.params:
+                coeff = term.coeff + T.coeff
+                nrm = abs(coeff).sum()
+                if nrm == 0:
+                    del self.terms[idx]
+                else:
+                    self.terms[idx] = Term(coeff, term.func, term.params, term.symbol, term.operator)
+                return self
+        for pars in T.params:
+            for par in pars:
+                if par not in self.params:
+                    self.params[par] = NaN
+        self.terms.append(T)
+        return self
+
+    def __add__(self, T):
+        """LinOpFam.jl:353-357"""
+        L = self.copy()
+        L.push(T)
+        return L
+
+    def __sub__(self, T):
+        """LinOpFam.jl:364-368"""
+        L = self.copy()
+        L.push(Term(-T.coeff, T.func, T.params, T.symbol, T.operator))
+        return L
+
+    def copy(self):
+        fam, self._fam = self._fam, None
+        L = copy.deepcopy(self)
+        self._fam = fam
+        return L
+
+    def size(self):
+        """LinOpFam.jl:385-393"""
+        return self.terms[0].coeff.shape[0] if self.terms else 0
+
+    # -- device handle ---------------------------------------------------------------------------------
+    def _drop_device(self):
+        if self._fam is not None:
+            self._fam.close()
+            self._fam = None
+
+    def device(self):
+        if self._fam is None:
+            self._fam = DeviceFamily([t.coeff for t in self.terms], self.device_id)
+        return self._fam
+
+    def ensure_solver(self):
+        fam = self.device()
+        if not fam.solver_ready:
+            zref = self.solver_ref
+            if zref is None:
+                zref = self.params.get(self.eigval, 0j)
+                if not np.isfinite(zref):
+                    zref = 0j
+            saved = dict(self.params), list(self.active), self.mode
+            self.active, self.mode = [self.eigval], "all"
+            try:
+                c = self.coefficients(zref)
+            finally:
+                self.params, self.active, self.mode = saved
+            fam.setup_solver(c, **self.solver_opts)
+        return fam
+
+    # -- functor ---------------------------------------------------------------------------------------
+    def coefficients(self, *args, oplist=(), in_or_ex=False):
+        """The scalar half of the reference functor (LinOpFam.jl:482-526): c_k for every term, 0 where the
+        reference skips the term (oplist / "__aux__" outside householder mode / derivative of a constant)."""
+        nact = len(self.active)
+        if self.mode == "all":
+            for var, val in zip(self.active, args):
+                self.params[var] = complex(val)
+        if self.mode == "all" and len(args) == nact:
+            derivs = [0] * nact
+        else:
+            derivs = [int(a) for a in args[len(args) - nact:]]
+        deriv_dict = dict(zip(self.active, derivs))
+        out = np.zeros(len(self.terms), dtype=np.complex128)
+        for k, term in enumerate(self.terms):
+            if ((not in_or_ex and term.operator in oplist) or (in_or_ex and term.operator not in oplist)
+                    or (self.mode != "householder" and term.operator == "__aux__")):
+                continue
+            if any(dd > 0 and var not in term.varlist for var, dd in zip(self.active, derivs)):
+                continue
+            out[k] = term.scalar({var: (self.params[var], deriv_dict.get(var, 0)) for var in term.varlist})
+        if self.mode in ("compact", "householder"):
+            div = 1.0
+            for a in args[len(args) - nact:]:
+                div *= float(factorial(int(a)))
+            out /= div
+        return out
+
+    def term_operator(self, k, scale=1.0):
+        """scale * A_k as an Operator (e.g. M = -L.terms[end].coeff, Householder.jl:92)"""
+        c = np.zeros(len(self.terms), dtype=np.complex128)
+        c[k] = scale
+        return Operator(self.device(), c, OP_N, self)
+
+    def __call__(self, *args, oplist=(), in_or_ex=False):
+        return Operator(self.device(), self.coefficients(*args, oplist=oplist, in_or_ex=in_or_ex), OP_N, self)
+
+
+def polyval(p, z):
+    """LinOpFam.jl:723-730"""
+    f = p[-1]
+    for i in range(len(p) - 2, -1, -1):
+        f = f * z + p[i]
+    return f
+
+
+def pade(w, L, M):
+    """LinOpFam.jl:622-642"""
+    w = np.asarray(w, dtype=complex)
+    b = np.array([1.0 + 0j])
+    if M > 0:
+        A = np.zeros((M, M), dtype=complex)
+        for i in range(1, M + 1):
+            for j in range(1, M + 1):
+                if L + i - j >= 0:
+                    A[i - 1, j - 1] = w[L + i - j]
+        b = np.concatenate([[1.0 + 0j], np.linalg.solve(A, -w[L + 1:L + M + 1])])
+    a = np.zeros(L + 1, dtype=complex)
+    for l in range(L + 1):
+        for m in range(min(l, M) + 1):
+            a[l] += w[l - m] * b[m]
+    return a, b
+
+
+def conv_radius(a):
+    """LinOpFam.jl:754-761"""
+    a = np.asarray(a)
+    return np.abs(a[:-1] / a[1:])
+
+
+def poly_roots(p):
+    """Householder.jl:195-203"""
+    p = np.asarray(p, dtype=complex)
+    N = len(p) - 1
+    Cm = np.zeros((N, N), dtype=complex)
+    for i in range(1, N):
+        Cm[i, i - 1] = 1
+    Cm[:, N - 1] = -p[:N] / p[N]
+    return np.linalg.eigvals(Cm)

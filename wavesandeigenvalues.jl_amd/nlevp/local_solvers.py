@@ -1,0 +1,396 @@
+"""Local (Newton-type) eigenvalue solvers on the device family.
+
+Reference: src/NLEVP/Householder.jl (householder, householder_update), src/NLEVP/iterative_solvers.jl
+(status flags, mslp, inveriter, lancaster, rf2s, traceiter).  Same signatures, same flag conventions; every
+``L(z)\\b`` / ``lu`` / ``Arpack.eigs`` of the reference is a call into libwaehip (multigrid-GMRES solves and
+shift-invert Arnoldi on the GPU); only scalar updates and the tiny Hessenberg eigenproblem run on the host.
+"""
+from __future__ import annotations
+
+from math import factorial
+
+import numpy as np
+import scipy.sparse as sp
+
+from .._lib import OP_C, OP_N, WaeError
+from .algebra import pow1
+from .linopfam import Operator, Solution, Term, pade, poly_roots, polyval
+from .perturbation import perturb_
+
+# iterative_solvers.jl:4-14
+itsol_converged = 0
+itsol_maxiter = 1
+itsol_slow_convergence = 2
+itsol_impossible = -1
+itsol_singular_exception = -2
+itsol_arpack_exception = -3
+itsol_isnan = -4
+itsol_unknown = -5
+itsol_arpack_9999 = -9999
+
+
+def decode_error_flag(flag):
+    """iterative_solvers.jl:22-44 (the reference's version does not parse; this is its evident intent)"""
+    return {
+        itsol_converged: "Solution converged, everythink OK!",
+        itsol_maxiter: "Warning: Maximum number of iterations has been reached!",
+        itsol_slow_convergence: "Warning: Slow progress!",
+        itsol_impossible: "Error: This error should be impossible. Please, contact the package developers!",
+        itsol_singular_exception: "Error: Singular Exception!",
+        itsol_arpack_exception: "Error: Arpack exception!",
+        itsol_arpack_9999: "Error: Arpack -9999 error!",
+        itsol_unknown: "Error: Unknown error ocurred!",
+    }.get(flag, "Unknown flag code.")
+
+
+class EigsError(RuntimeError):
+    """stands where Arpack.ARPACKException stands in the reference (Householder.jl:140)"""
+
+
+def eigs(A, M, nev=1, v0=None, ncv=None, tol=1e-13, maxrestart=8):
+    """Arpack.eigs(A, M, nev=nev, sigma=0, v0=v0)  (Householder.jl:100-101, iterative_solvers.jl:132-133).
+
+    A, M are Operator views of one family (pass ``A.H, M.H`` for the adjoint problem).  The Arnoldi factorisation
+    of A^{-1}M runs on the device (``wae_arnoldi_shiftinvert``); Ritz values of the small Hessenberg matrix and
+    restarts are done here.  Returns (lam[nev], V[d,nev]) sorted by |lam| like ARPACK's which=:LM on 1/lam.
+    """
+    fam = A.fam
+    d = A.shape[0]
+    own = A.owner
+    if own is not None:
+        own.ensure_solver()
+    stol = own.solver_tol if own is not None else 1e-12
+    smax = own.solver_maxit if own is not None else 400
+    if ncv is None:
+        ncv = max(20, 2 * nev + 1)          # ARPACK's default
+    ncv = int(min(ncv, d))
+    v = np.ones(d, dtype=np.complex128) if v0 is None else np.asarray(v0, dtype=np.complex128)
+    cA = A.coeffs
+    cM = M.coeffs
+    last = None
+    for _ in range(maxrestart):
+        H, V = fam.arnoldi(cA, cM, ncv, v, op=A.op, tol=stol, maxit=smax)
+        m = ncv
+        for j in range(ncv):                 # invariant subspace: H[j+1,j] == 0
+            if H[j + 1, j] == 0:
+                m = j + 1
+                break
+        theta, Yr = np.linalg.eig(H[:m, :m])
+        order = np.argsort(-np.abs(theta))
+        theta, Yr = theta[order], Yr[:, order]
+        k = min(nev, m)
+        res = np.abs(H[m, m - 1]) * np.abs(Yr[m - 1, :k]) if m < H.shape[0] else np.zeros(k)
+        X = V[:, :m] @ Yr[:, :k]
+        X = X / np.linalg.norm(X, axis=0)
+        last = (1.0 / theta[:k], X)
+        if np.all(res <= tol * np.abs(theta[:k])) or m < ncv:
+            return last
+        v = X @ np.ones(k)                    # restart with the wanted Ritz vectors
+    if last is None:
+        raise EigsError("no Ritz pair")
+    return last
+
+
+def householder_update(f):
+    """Householder.jl:21-35"""
+    order = len(f) - 1
+    if order == 1:
+        return -f[0] / f[1]
+    if order == 2:
+        return -f[0] * f[1] / (f[1] ** 2 - 0.5 * f[0] * f[2])
+    if order == 3:
+        return -(6 * f[0] * f[1] ** 2 - 3 * f[0] ** 2 * f[2]) / (6 * f[1] ** 3 - 6 * f[0] * f[1] * f[2] + f[0] ** 2 * f[3])
+    if order == 4:
+        return -(4 * f[0] * (6 * f[1] ** 3 - 6 * f[0] * f[1] * f[2] + f[0] ** 2 * f[3])) / (
+            24 * f[1] ** 4 - 36 * f[0] * f[1] ** 2 * f[2] + 6 * f[0] ** 2 * f[2] ** 2 + 8 * f[0] ** 2 * f[1] * f[3] - f[0] ** 3 * f[4])
+    return (5 * f[0] * (24 * f[1] ** 4 - 36 * f[0] * f[1] ** 2 * f[2] + 6 * f[0] ** 2 * f[2] ** 2 + 8 * f[0] ** 2 * f[1] * f[3] - f[0] ** 3 * f[4])) / (
+        -120 * f[1] ** 5 + 240 * f[0] * f[1] ** 3 * f[2] - 60 * f[0] ** 2 * f[1] ** 2 * f[3]
+        + 10 * f[0] ** 2 * f[1] * (-9 * f[2] ** 2 + f[0] * f[4]) + f[0] ** 3 * (20 * f[2] * f[3] - f[0] * f[5]))
+
+
+def _aux_step(L, z, order, nev, v0, v0_adj, update):
+    """one pass of the loop body shared by householder and mslp (Householder.jl:96-120)."""
+    L.params[L.eigval] = z
+    L.params[L.auxval] = 0
+    A = L(z)
+    M = L.term_operator(len(L.terms) - 1, -1.0)          # M = -L.terms[end].coeff
+    lam, v = eigs(A, M, nev=nev, v0=v0)
+    lam_adj, v_adj = eigs(A.H, M.H, nev=nev, v0=v0_adj)
+    idx = np.argsort(np.abs(lam)); lam, v = lam[idx], v[:, idx]
+    idx = np.argsort(np.abs(lam_adj)); lam_adj, v_adj = lam_adj[idx], v_adj[:, idx]
+    cand = []
+    L.active = [L.auxval, L.eigval]
+    try:
+        for i in range(nev):
+            L.params[L.auxval] = lam[i]
+            sol = Solution(L.params, v[:, i], v_adj[:, i], L.auxval)
+            perturb_(sol, L, L.eigval, order, mode="householder")
+            cand.append(update(sol.eigval_pert[f"{L.eigval}/Taylor"]))
+    finally:
+        L.active = [L.eigval]
+    return lam, v, v_adj, cand
+
+
+def _normalise(L, v0, v0_adj):
+    """Householder.jl:189-190"""
+    M = L.term_operator(len(L.terms) - 1, -1.0)
+    v0 = v0 / np.sqrt(np.vdot(v0, M @ v0))
+    saved = L.active, L.mode
+    L.active, L.mode = [L.eigval], "all"
+    try:
+        v0_adj = v0_adj / np.conj(np.vdot(v0_adj, L(L.params[L.eigval], 1) @ v0))
+    finally:
+        L.active, L.mode = saved
+    return v0, v0_adj
+
+
+def householder(L, z, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, nev=1, v0=None, v0_adj=None, output=False):
+    """sol, n, flag = householder(L, z; maxiter, tol, relax, lam_tol, order, nev, v0, v0_adj, output)
+    (Householder.jl:70-192; flags 1 converged / 0 slow / -1 maxiter / -4 eigs / -6 singular / -5 NaN)"""
+    z = complex(z)
+    z0 = complex(np.inf)
+    lam = np.inf
+    n = 0
+    active, mode = L.active, L.mode
+    d = L.size()
+    v0 = np.ones(d, dtype=np.complex128) if v0 is None else np.asarray(v0, dtype=np.complex128)
+    v0_adj = np.conj(v0) if v0_adj is None else np.asarray(v0_adj, dtype=np.complex128)
+    flag = 1
+    history = []
+    try:
+        while abs(z - z0) > tol and n < maxiter:
+            if output:
+                print(n, "\t\t", abs(lam), "\t", abs(z - z0), "\t", z)
+            history.append(z)
+            z0 = z
+            lams, v, v_adj, dzs = _aux_step(L, z, order, nev, v0, v0_adj,
+                                            lambda c: householder_update([factorial(i) * ci for i, ci in enumerate(c)]))
+            i = int(np.argsort(np.abs(dzs))[0])
+            lam = lams[i]
+            L.params[L.auxval] = lam
+            z = z + relax * dzs[i]
+            v0 = (1 - relax) * v0 + relax * v[:, i]
+            v0_adj = (1 - relax) * v0_adj + relax * v_adj[:, i]
+            n += 1
+    except EigsError:
+        flag = -4
+    except WaeError as e:
+        flag = -6 if e.code == -2 else -2
+        L.params[L.eigval] = z
+    if flag == 1:
+        L.params[L.eigval] = z
+        history.append(z)
+        if n >= maxiter:
+            flag = -1
+        elif abs(lam) <= lam_tol:
+            flag = 1
+        elif abs(z - z0) <= tol:
+            flag = 0
+        elif np.isnan(z):
+            flag = -5
+        else:
+            flag = -3
+    L.active, L.mode = active, mode
+    v0, v0_adj = _normalise(L, v0, v0_adj)
+    sol = Solution(L.params, v0, v0_adj, L.eigval)
+    sol.history = history
+    return sol, n, flag
+
+
+def mslp(L, z, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, nev=1, v0=None, v0_adj=None, num_order=1,
+         scale=1.0, output=False):
+    """sol, n, flag = mslp(L, z; ...)   (iterative_solvers.jl:93-252)"""
+    z = complex(z) * scale
+    tol = tol * scale
+    z0 = complex(np.inf)
+    lam = np.inf
+    lam0 = np.inf
+    n = 0
+    active, mode = L.active, L.mode
+    d = L.size()
+    v0 = np.ones(d, dtype=np.complex128) if v0 is None else np.asarray(v0, dtype=np.complex128)
+    v0_adj = np.conj(v0) if v0_adj is None else np.asarray(v0_adj, dtype=np.complex128)
+    flag = itsol_converged
+    if L.terms[-1].operator != "__aux__":          # iterative_solvers.jl:119-123
+        L.push(Term(-sp.identity(d, dtype=np.complex128, format="csr"), (pow1,), (("__aux__",),), "__aux__", "__aux__"))
+        L.auxval = "__aux__"
+    history = []
+    try:
+        while abs(z - z0) > tol and n < maxiter:
+            if output:
+                print(n, "\t\t", abs(z - z0) / scale, "\t", z / scale)
+            history.append(z)
+            pades = []
+
+            def upd(coeffs):
+                num, den = pade(coeffs, num_order, order - num_order)
+                pades.append((num, den))
+                roots = poly_roots(num)
+                return roots[np.argsort(np.abs(roots))[0]]
+            lams, v, v_adj, dzs = _aux_step(L, z, order, nev, v0, v0_adj, upd)
+            if not np.isinf(z0):
+                back = [lam0 - polyval(num, z0 - z) / polyval(den, z0 - z) for num, den in pades]
+                i = int(np.argsort(np.abs(back))[0])
+            else:
+                i = int(np.argsort(np.abs(dzs))[0])
+            lam = lams[i]
+            L.params[L.auxval] = lam
+            z0 = z
+            lam0 = lam
+            z = z + relax * dzs[i]
+            v0 = (1 - relax) * v0 + relax * v[:, i]
+            v0_adj = (1 - relax) * v0_adj + relax * v_adj[:, i]
+            n += 1
+    except EigsError:
+        flag = itsol_arpack_exception
+    except WaeError as e:
+        flag = itsol_singular_exception if e.code == -2 else itsol_unknown
+        L.params[L.eigval] = z
+    if flag == itsol_converged:
+        L.params[L.eigval] = z
+        history.append(z)
+        if n >= maxiter:
+            flag = itsol_maxiter
+        elif abs(lam) <= lam_tol:
+            flag = itsol_converged
+        elif abs(z - z0) <= tol:
+            flag = itsol_slow_convergence
+        elif np.isnan(z):
+            flag = itsol_isnan
+        else:
+            flag = itsol_impossible
+    L.active, L.mode = active, mode
+    v0, v0_adj = _normalise(L, v0, v0_adj)
+    sol = Solution(L.params, v0, v0_adj, L.eigval)
+    sol.history = history
+    return sol, n, flag
+
+
+def _finish(n, maxiter, z, z0, tol, flag):
+    """iterative_solvers.jl:326-342"""
+    if flag != itsol_converged:
+        return flag
+    if n >= maxiter:
+        return itsol_maxiter
+    if abs(z - z0) <= tol:
+        return itsol_converged
+    if np.isnan(z):
+        return itsol_isnan
+    return itsol_impossible
+
+
+def inveriter(L, z, maxiter=10, tol=0.0, relax=1.0, x0=None, v=None, output=False):
+    """iterative_solvers.jl:285-347"""
+    d = L.size()
+    x0 = np.ones(d, dtype=np.complex128) if x0 is None else np.asarray(x0, dtype=np.complex128)
+    v = np.ones(d, dtype=np.complex128) if v is None else np.asarray(v, dtype=np.complex128)
+    x0 = x0 / np.vdot(v, x0)
+    z = complex(z)
+    z0 = complex(np.inf)
+    n = 0
+    flag = itsol_converged
+    try:
+        while abs(z - z0) > tol and n < maxiter:
+            if output:
+                print(n, "\t\t", abs(z - z0), "\t", z)
+            z0 = z
+            u = L(z, 0).solve(L(z, 1) @ x0)
+            z = z0 - np.vdot(v, x0) / np.vdot(v, u)
+            x0 = u / np.vdot(v, u)
+            n += 1
+    except WaeError:
+        flag = itsol_unknown
+    flag = _finish(n, maxiter, z, z0, tol, flag)
+    return Solution(L.params, x0, [], L.eigval, L.auxval), n, flag
+
+
+def lancaster(L, z, maxiter=10, tol=0.0, relax=1.0, x0=None, y0=None, output=False):
+    """iterative_solvers.jl:378-434"""
+    d = L.size()
+    x0 = np.ones(d, dtype=np.complex128) if x0 is None else np.asarray(x0, dtype=np.complex128)
+    y0 = np.ones(d, dtype=np.complex128) if y0 is None else np.asarray(y0, dtype=np.complex128)
+    z = complex(z)
+    z0 = complex(np.inf)
+    n = 0
+    flag = itsol_converged
+    try:
+        while abs(z - z0) > tol and n < maxiter:
+            z0 = z
+            A = L(z)
+            xi = A.solve(x0)
+            eta = A.H.solve(y0)
+            z = z0 - np.vdot(eta, L(z, 0) @ xi) / np.vdot(eta, L(z, 1) @ xi)
+            n += 1
+    except WaeError:
+        flag = itsol_unknown
+    flag = _finish(n, maxiter, z, z0, tol, flag)
+    return Solution(L.params, np.zeros(d, dtype=np.complex128), [], L.eigval), n, flag
+
+
+def rf2s(L, z, maxiter=10, tol=0.0, relax=1.0, x0=None, y0=None, output=False):
+    """iterative_solvers.jl:548-614"""
+    d = L.size()
+    if x0 is None:
+        x0 = np.zeros(d, dtype=np.complex128); x0[0] = 1
+    if y0 is None:
+        y0 = np.zeros(d, dtype=np.complex128); y0[0] = 1
+    x0 = np.asarray(x0, dtype=np.complex128); y0 = np.asarray(y0, dtype=np.complex128)
+    x0 = x0 / np.sqrt(np.vdot(x0, x0)); y0 = y0 / np.sqrt(np.vdot(y0, y0))
+    z = complex(z)
+    z0 = complex(np.inf)
+    n = 0
+    flag = itsol_converged
+    try:
+        while abs(z - z0) > tol and n < maxiter:
+            z0 = z
+            A = L(z)
+            L1 = L(z, 1)
+            x0 = A.solve(L1 @ x0)
+            y0 = A.H.solve(L1.H @ y0)
+            x0 = x0 / np.sqrt(np.vdot(x0, x0)); y0 = y0 / np.sqrt(np.vdot(y0, y0))
+            idx = 0
+            z00 = complex(np.inf)
+            while abs(z - z00) > tol and idx < 10:
+                z00 = z
+                z = z - np.vdot(y0, L(z) @ x0) / np.vdot(y0, L(z, 1) @ x0)
+                idx += 1
+            n += 1
+    except WaeError:
+        flag = itsol_unknown
+    flag = _finish(n, maxiter, z, z0, tol, flag)
+    return Solution(L.params, x0, y0, L.eigval), n, flag
+
+
+def traceiter(L, z, maxiter=10, tol=0.0, relax=1.0, output=False):
+    """iterative_solvers.jl:463-517: d solves per step (all d unit vectors as one batched device solve);
+    small problems only, as in the reference."""
+    d = L.size()
+    z = complex(z)
+    z0 = complex(np.inf)
+    n = 0
+    flag = itsol_converged
+    try:
+        while abs(z - z0) > tol and n < maxiter:
+            z0 = z
+            L1 = L(z, 1) @ np.eye(d, dtype=np.complex128)
+            X = L(z).solve(L1)
+            dz = -1.0 / np.trace(X)
+            z = z0 + relax * dz
+            n += 1
+    except WaeError:
+        flag = itsol_unknown
+    flag = _finish(n, maxiter, z, z0, tol, flag)
+    return Solution(L.params, [], [], L.eigval), n, flag
+
+
+def count_poles_and_zeros(L, G, N=16, output=False):
+    """beyn.jl:355-368"""
+    from .beyn import gauss_points
+    d = L.size()
+    zs, ws = gauss_points(G, N)
+    s = 0j
+    eye = np.eye(d, dtype=np.complex128)
+    for z, w in zip(zs, ws):
+        X = L(z).solve(L(z, 1) @ eye)
+        s += np.trace(X) * w
+    return s / 2 / np.pi / 1j
