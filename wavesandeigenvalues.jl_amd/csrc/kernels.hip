@@ -51,7 +51,11 @@ __global__ __launch_bounds__(256) void spmv_kernel(OpDev op, const cplx *__restr
     const int lt = tid - team * TEAM;
     const int c = lt % C;
     const int s = lt / C;
-    const int64_t row = (int64_t)blockIdx.x * TPB + team;
+    // XCD-aware row-block order: workgroups are dealt round-robin over the 8 XCDs (gridDim.x is a multiple of 8),
+    // so give XCD k the k-th contiguous eighth of the rows: its L2 then holds one slab of X instead of all of it.
+    const unsigned per_xcd = gridDim.x >> 3;
+    const int64_t rb = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const int64_t row = rb * TPB + team;
     if (row >= op.n) return;        // whole teams leave together (shuffles below stay inside a team)
     const int b = blockIdx.y * C + c;
     const bool active = b < nb;
@@ -124,7 +128,8 @@ __global__ __launch_bounds__(256) void spmv_kernel(OpDev op, const cplx *__restr
         out = cplx{bv.x + acc.x, bv.y + acc.y};
     } else {   // MODE_JAC
         cplx dg = {0.0, 0.0};
-        for (int q = 0; q < npl; ++q) cfma(dg, mypc[q], op.diag[(size_t)row * npl + q]);
+        const double dsg = op.conj_diag ? -1.0 : 1.0;
+        for (int q = 0; q < npl; ++q) { cplx dq = op.diag[(size_t)row * npl + q]; dq.y *= dsg; cfma(dg, mypc[q], dq); }
         const cplx bv = B[e], xv = X[e];
         cplx r = cdiv(cplx{bv.x - acc.x, bv.y - acc.y}, dg);
         out = cplx{xv.x + jac_w * r.x, xv.y + jac_w * r.y};
@@ -156,14 +161,15 @@ void launch_spmv(const OpDev &op, const cplx *pc, int cps, const cplx *X, cplx *
     const int envC = env_int("WAE_SPMV_C", 0), envS = env_int("WAE_SPMV_S", 0);   // tuning overrides
     int C = nb >= 8 ? 8 : (nb >= 4 ? 4 : (nb >= 2 ? 2 : 1));
     int S = 64 / C >= 8 ? 8 : 64 / C;
-    if (C == 8) S = 4;
+    if (C == 8) S = 1;
     if (envC > 0 && envC <= nb) C = envC;
     if (envS > 0) S = envS;
     spmv_fn fn = pick_spmv(C, S);
     if (!fn) throw WaeError(WAE_ERR_INVALID, "launch_spmv: unsupported (C,S)");
     if (op.n <= 0) return;
     const int tpb = 256 / (C * S);
-    dim3 grid((unsigned)((op.n + tpb - 1) / tpb), (unsigned)((nb + C - 1) / C));
+    const unsigned nrb = (unsigned)((op.n + tpb - 1) / tpb);
+    dim3 grid((nrb + 7u) / 8u * 8u, (unsigned)((nb + C - 1) / C));
     size_t shm = (size_t)C * op.nplanes_total * sizeof(cplx);
     hipLaunchKernelGGL(fn, grid, dim3(256), shm, st, op, pc, cps, X, Y, B, jac_w, nb, mode);
     HIP_CHECK(hipGetLastError());
@@ -178,7 +184,8 @@ __global__ __launch_bounds__(256) void jacobi0_kernel(OpDev op, const cplx *__re
         const int b = (int)(e - row * nb);
         const cplx *mypc = pc + (size_t)(b / cps) * npl;
         cplx dg = {0.0, 0.0};
-        for (int q = 0; q < npl; ++q) cfma(dg, mypc[q], op.diag[row * npl + q]);
+        const double dsg = op.conj_diag ? -1.0 : 1.0;
+        for (int q = 0; q < npl; ++q) { cplx dq = op.diag[row * npl + q]; dq.y *= dsg; cfma(dg, mypc[q], dq); }
         cplx r = cdiv(B[e], dg);
         X[e] = cplx{w * r.x, w * r.y};
     }
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(256) void spmv_multi_kernel(OpDev op, const cplx *_
         acc.x += __shfl_xor(acc.x, off);
         acc.y += __shfl_xor(acc.y, off);
     }
-    if (s == 0) Y[(size_t)row * nb] = acc;
+    if (s == 0) Y[row] = acc;          // single contiguous output column
 }
 
 void launch_spmv_multi(const OpDev &op, const cplx *pc, const int *plane_col, const cplx *X, cplx *Y, int nb, hipStream_t st) {
@@ -236,25 +243,28 @@ void launch_spmv_multi(const OpDev &op, const cplx *pc, const int *plane_col, co
 // ---------------------------------------------------------------------------------------------------
 // dense coarsest level
 // ---------------------------------------------------------------------------------------------------
+// A_s = sum_q pc[s][q] * op(plane_q):  op = N: plane, T: plane^T, C: conj(plane)^T (pc arrives conjugated for C)
 __global__ __launch_bounds__(256) void dense_assemble_kernel(const cplx *__restrict__ planes, int nplanes, int n,
-                                                             const cplx *__restrict__ pc, int transpose_conj, cplx *__restrict__ A) {
+                                                             const cplx *__restrict__ pc, int op, cplx *__restrict__ A) {
     const int sys = blockIdx.y;
     const size_t nn = (size_t)n * n;
+    const double sg = (op == WAE_OP_C) ? -1.0 : 1.0;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nn; e += (size_t)gridDim.x * 256) {
         size_t src = e;
-        if (transpose_conj) { size_t i = e / n, j = e - i * n; src = j * n + i; }
+        if (op != WAE_OP_N) { size_t i = e / n, j = e - i * n; src = j * n + i; }
         cplx acc = {0.0, 0.0};
-        for (int q = 0; q < nplanes; ++q) cfma(acc, pc[(size_t)sys * nplanes + q], planes[(size_t)q * nn + src]);
-        if (transpose_conj) acc.y = -acc.y;
+        for (int q = 0; q < nplanes; ++q) {
+            cplx a = planes[(size_t)q * nn + src];
+            a.y *= sg;
+            cfma(acc, pc[(size_t)sys * nplanes + q], a);
+        }
         A[(size_t)sys * nn + e] = acc;
     }
 }
 
-void launch_dense_assemble(const cplx *planes, int nplanes, int n, const cplx *pc, int nsys, int transpose_conj, cplx *Ainv, hipStream_t st) {
+void launch_dense_assemble(const cplx *planes, int nplanes, int n, const cplx *pc, int nsys, int op, cplx *Ainv, hipStream_t st) {
     if (n <= 0 || nsys <= 0) return;
-    // for op = C the caller passes conj(pc); A^H = conj(sum pc_q plane_q)^T = (sum conj(pc_q) conj(plane_q))^T
-    hipLaunchKernelGGL(dense_assemble_kernel, dim3(grid_for((size_t)n * n, 256), nsys), dim3(256), 0, st, planes, nplanes, n, pc,
-                       transpose_conj, Ainv);
+    hipLaunchKernelGGL(dense_assemble_kernel, dim3(grid_for((size_t)n * n, 256), nsys), dim3(256), 0, st, planes, nplanes, n, pc, op, Ainv);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -22,6 +22,7 @@ OpDev LevelOp::dev(int op) const {
     o.nplanes_total = nplanes;
     o.n = n;
     o.diag = diag.p;
+    o.conj_diag = (op == WAE_OP_C) ? 1 : 0;
     for (size_t g = 0; g < groups.size(); ++g) {
         const GroupHost &G = groups[g];
         GroupDev &D = o.g[g];
@@ -278,7 +279,7 @@ static void dense_setup(wae_family *h, const Batch &bt) {
     const int L = (int)h->ops.size() - 1;
     if (h->nc <= 0) return;
     HIP_CHECK(hipMemsetAsync(h->dstatus.p, 0, sizeof(int), h->stream));
-    launch_dense_assemble(h->dense_planes.p, h->nplanes, (int)h->nc, pc_level(h, L), bt.nsys, bt.op != WAE_OP_N ? 1 : 0, h->Ainv.p, h->stream);
+    launch_dense_assemble(h->dense_planes.p, h->nplanes, (int)h->nc, pc_level(h, L), bt.nsys, bt.op, h->Ainv.p, h->stream);
     launch_dense_invert(h->Ainv.p, (int)h->nc, bt.nsys, h->dstatus.p, h->stream);
     int st = 0;
     HIP_CHECK(hipMemcpyAsync(&st, h->dstatus.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -329,9 +330,13 @@ struct ColState {
 
 static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double tol, int maxit, wae_solve_info *info) {
     hipStream_t st = h->stream;
-    const int nb = bt.nb, m = h->restart;
+    const int nb = bt.nb;
     const int64_t n = h->d;
     const size_t vec = (size_t)n * nb;
+    // narrow batches get a longer recurrence from the same workspace (near-singular systems in the Newton-type
+    // solvers stall under short restarts); they also afford a second Gram-Schmidt pass
+    const int m = (int)std::min<size_t>(150, h->V.n / vec - 1);
+    const bool reorth = nb <= 8;
     const OpDev A = h->ops[0].dev(bt.op);
     const cplx *pc = pc_level(h, 0);
     cplx *hp = h->h_pinned;
@@ -341,7 +346,8 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
     HIP_CHECK(hipStreamSynchronize(st));
     std::vector<double> bnorm(nb), relres(nb, 0.0);
     std::vector<int> iters(nb, 0);
-    std::vector<char> done(nb, 0);
+    std::vector<char> done(nb, 0), stalled(nb, 0);
+    std::vector<std::vector<double>> hist(nb);
     for (int b = 0; b < nb; ++b) { bnorm[b] = hp[b].x; if (!(bnorm[b] > 0.0)) done[b] = 1; }
     std::vector<ColState> cs(nb);
     int total_it = 0;
@@ -360,7 +366,7 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
             if (bnorm[b] > 0.0) {
                 relres[b] = hp[b].x / bnorm[b];
                 if (std::isnan(relres[b])) nan_seen = true;
-                done[b] = relres[b] <= tol;
+                done[b] = relres[b] <= tol || stalled[b];
             }
             if (!done[b]) all_done = false;
         }
@@ -383,6 +389,12 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
             launch_spmv(A, pc, bt.cps, z, h->W.p, nullptr, 0.0, nb, MODE_AX, st);
             launch_dots(h->V.p, vec, j + 1, h->W.p, n, nb, h->partial.p, h->hdev.p, st);
             launch_axpy_neg(h->V.p, vec, j + 1, h->hdev.p, h->W.p, n, nb, st);
+            if (reorth) {   // CGS2: h += V^H w', w' -= V (V^H w')
+                cplx *h2 = h->hdev.p + (size_t)(m + 2) * nb;
+                launch_dots(h->V.p, vec, j + 1, h->W.p, n, nb, h->partial.p, h2, st);
+                launch_axpy_neg(h->V.p, vec, j + 1, h2, h->W.p, n, nb, st);
+                launch_add(h2, h->hdev.p, (size_t)(j + 1) * nb, st);
+            }
             launch_norms(h->W.p, n, nb, h->partial.p, h->hdev.p + (size_t)(j + 1) * nb, st);
             launch_scale_inv(h->W.p, h->hdev.p + (size_t)(j + 1) * nb, h->V.p + (size_t)(j + 1) * vec, n, nb, st);
             HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, (size_t)(j + 2) * nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
@@ -413,7 +425,10 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
                 c.steps = j + 1;
                 iters[b]++;
                 relres[b] = std::abs(c.g[j + 1]) / bnorm[b];
+                hist[b].push_back(relres[b]);
+                const size_t hs = hist[b].size();
                 if (relres[b] <= 0.7 * tol) c.conv = true;
+                else if (hs > 60 && relres[b] > 0.9 * hist[b][hs - 31]) { c.conv = true; stalled[b] = 1; }   // attainable accuracy reached
                 else all_conv = false;
             }
             if (all_conv || nan_seen) { ++j; break; }
@@ -456,8 +471,9 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
         info->iters_max = std::max(info->iters_max, imax);
         info->iters_total += itot;
         info->n_unconverged += nun;
+        for (int b = 0; b < nb; ++b) if (stalled[b] && !(relres[b] <= tol)) info->levels |= 1 << 16;   // stagnation marker (masked off below)
         info->relres_max = std::max(info->relres_max, rmax);
-        info->levels = (int)h->ops.size();
+        info->levels = (info->levels & (1 << 16)) | (int)h->ops.size();
     }
     if (nan_seen) throw WaeError(WAE_ERR_NAN, "NaN in GMRES");
 }
@@ -485,7 +501,12 @@ template <class F> static int guarded(F &&f) {
     }
 }
 
-static int info_code(const wae_solve_info &i) { return i.n_unconverged > 0 ? WAE_WARN_MAXITER : WAE_OK; }
+static int info_code(wae_solve_info &i) {
+    const bool stag = (i.levels & (1 << 16)) != 0;
+    i.levels &= 0xFFFF;
+    if (i.n_unconverged > 0) return stag ? WAE_WARN_STAGNATION : WAE_WARN_MAXITER;
+    return WAE_OK;
+}
 
 // ----------------------------------------------------------------------------------------------------
 // C ABI
@@ -723,7 +744,7 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
         h->V.alloc(vec * (m + 1));
         h->W.alloc(vec); h->Xs.alloc(vec); h->Bs.alloc(vec); h->U.alloc(vec);
         h->partial.alloc((size_t)512 * 32 * NB);
-        h->hdev.alloc((size_t)(m + 2) * NB);
+        h->hdev.alloc((size_t)2 * (m + 3) * NB);     // second half: scratch for the re-orthogonalisation pass
         h->ydev.alloc((size_t)(m + 1) * NB);
         if (h->h_pinned) { (void)hipHostFree(h->h_pinned); h->h_pinned = nullptr; }
         HIP_CHECK(hipHostMalloc((void **)&h->h_pinned, (size_t)(m + 2) * NB * sizeof(cplx)));

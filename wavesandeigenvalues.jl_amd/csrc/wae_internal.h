@@ -73,6 +73,7 @@ struct OpDev {
     int64_t n;
     GroupDev g[WAE_MAXG];
     const cplx *diag;               // [n][nplanes_total] diagonal of every plane (for Jacobi), may be null
+    int conj_diag;                  // op = C: use conj(diag) (coefficients arrive already conjugated)
 };
 
 // device buffer with RAII-less explicit free (owned by the family)
@@ -137,7 +138,7 @@ void launch_jacobi0(const OpDev &op, const cplx *pc, int cps, const cplx *B, cpl
 void launch_spmv_multi(const OpDev &op, const cplx *pc, const int *plane_col, const cplx *X, cplx *Y, int nb, hipStream_t s);
 
 // dense coarse level: assemble A_s = sum_q pc[s][q] planes[q] (n x n, row-major per system), invert in place
-void launch_dense_assemble(const cplx *planes, int nplanes, int n, const cplx *pc, int nsys, int transpose_conj,
+void launch_dense_assemble(const cplx *planes, int nplanes, int n, const cplx *pc, int nsys, int op,
                            cplx *Ainv, hipStream_t s);
 void launch_dense_invert(cplx *Ainv, int n, int nsys, int *status, hipStream_t s);
 void launch_dense_apply(const cplx *Ainv, int n, int cps, const cplx *X, cplx *Y, int nb, hipStream_t s);

@@ -1,0 +1,71 @@
+"""Multi-GPU Beyn: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).
+
+The quadrature points of the contour are independent (beyn.jl:126-134 is a plain sum), so they are dealt
+round-robin to the ranks; every rank holds a full replica of the family (0.07 GB at 200k DoF, 0.4 GB at 1M DoF --
+nothing against 288 GB of HBM) and accumulates a partial moment tensor d x l x 2K in its own HBM; the only
+exchange step of the whole path is ONE sum all-reduce of that tensor.  The Hankel SVD / eigen tail runs on the host.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .beyn import compute_moment_matrices, gauss_points, initialize_V, moments2eigs, pos_test
+
+
+def shard_points(zs, ws, rank, world):
+    """round-robin shard of the quadrature points (balances the per-edge conditioning differences)"""
+    return zs[rank::world], ws[rank::world]
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+def rank_world():
+    d = _dist()
+    return (d.get_rank(), d.get_world_size()) if d else (0, 1)
+
+
+def allreduce_sum_(t):
+    """in-place sum over ranks of a torch tensor (no-op for a single process)"""
+    d = _dist()
+    if d is not None and d.get_world_size() > 1:
+        d.all_reduce(t)
+    return t
+
+
+def device_moment_fn(L, G, V, K, N):
+    """default producer of a rank's partial moments: the HIP path writing straight into a torch CUDA buffer."""
+    import torch
+
+    def fn(zs, ws):
+        d, l = V.shape
+        dev = torch.device("cuda", L.device_id)
+        buf = torch.zeros(d * l * 2 * K * 2, dtype=torch.float64, device=dev)
+        compute_moment_matrices(L, G, V, K=K, N=N, points=(zs, ws), out_dev=buf.data_ptr())
+        return buf
+    return fn
+
+
+def beyn_moments_distributed(G, N, shape, moment_fn):
+    """Sharded moments: ``moment_fn(z_shard, w_shard)`` -> flat float64 torch tensor (interleaved re/im of the
+    column-major d x l x 2K tensor); returns the all-reduced tensor as a numpy complex array on every rank."""
+    rank, world = rank_world()
+    zs, ws = gauss_points(G, N)
+    zr, wr = shard_points(zs, ws, rank, world)
+    buf = moment_fn(zr, wr)
+    allreduce_sum_(buf)
+    return buf.cpu().numpy().view(np.complex128).reshape(shape, order="F")
+
+
+def beyn_distributed(L, G, l=5, K=1, N=16, V=None, pos_test_=True):
+    """Ω, P, Σ of `beyn` (beyn.jl:34-110) with the quadrature sharded over the process group."""
+    d = L.size()
+    if V is None:
+        V = initialize_V(d, l)
+    A = beyn_moments_distributed(G, N, (d, V.shape[1], 2 * K), device_moment_fn(L, G, V, K, N))
+    Om, P, S = moments2eigs(A, return_sigma=True)
+    if pos_test_:
+        Om, P = pos_test(Om, P, G)
+    return Om, P, S

@@ -47,12 +47,21 @@ class EigsError(RuntimeError):
     """stands where Arpack.ARPACKException stands in the reference (Householder.jl:140)"""
 
 
-def eigs(A, M, nev=1, v0=None, ncv=None, tol=1e-13, maxrestart=8):
+def eigs(A, M, nev=1, v0=None, ncv=None, tol=1e-12, maxiter=300, sigma=0.0, return_gap=False):
     """Arpack.eigs(A, M, nev=nev, sigma=0, v0=v0)  (Householder.jl:100-101, iterative_solvers.jl:132-133).
 
     A, M are Operator views of one family (pass ``A.H, M.H`` for the adjoint problem).  The Arnoldi factorisation
-    of A^{-1}M runs on the device (``wae_arnoldi_shiftinvert``); Ritz values of the small Hessenberg matrix and
-    restarts are done here.  Returns (lam[nev], V[d,nev]) sorted by |lam| like ARPACK's which=:LM on 1/lam.
+    of A^{-1}M runs on the device (``wae_arnoldi_shiftinvert``, one multigrid-GMRES solve per step); the Ritz
+    values of the small Hessenberg matrix and the restarts are done here.  Short factorisations (6 steps) are
+    restarted with the wanted Ritz vectors until the Ritz residual is below ``tol``: close to an eigenvalue of
+    the NLEVP the wanted pair is separated by many orders of magnitude and one or two short runs suffice
+    (ARPACK would spend ncv = 20 solves regardless).  Returns (lam[nev], V[d,nev]).
+
+    ``sigma``: the factorisation is built for (A - sigma*M)^{-1} M, lam = sigma + 1/theta.  The reference always
+    uses sigma = 0 and relies on UMFPACK factorising the (numerically singular) A once the Newton iteration
+    has converged (Householder.jl:145 catches the SingularException); an iterative inner solver needs a
+    regular operator, so the Newton-type callers pass a shift far smaller than the spectral gap as soon as
+    |lam| itself falls below it -- the wanted eigenvalue is still the one nearest 0.
     """
     fam = A.fam
     d = A.shape[0]
@@ -63,15 +72,19 @@ def eigs(A, M, nev=1, v0=None, ncv=None, tol=1e-13, maxrestart=8):
     smax = own.solver_maxit if own is not None else 400
     if ncv is None:
         ncv = max(20, 2 * nev + 1)          # ARPACK's default
-    ncv = int(min(ncv, d))
+    step = int(min(d, ncv, max(6, 2 * nev + 2)))
     v = np.ones(d, dtype=np.complex128) if v0 is None else np.asarray(v0, dtype=np.complex128)
-    cA = A.coeffs
     cM = M.coeffs
+    cA = A.coeffs - sigma * cM              # (A - sigma M)^H is formed by the library when A.op == OP_C
+    sig_out = np.conj(sigma) if A.op == OP_C else sigma
     last = None
-    for _ in range(maxrestart):
-        H, V = fam.arnoldi(cA, cM, ncv, v, op=A.op, tol=stol, maxit=smax)
-        m = ncv
-        for j in range(ncv):                 # invariant subspace: H[j+1,j] == 0
+    gap = np.inf
+    total = 0
+    while total < maxiter:
+        H, V = fam.arnoldi(cA, cM, step, v, op=A.op, tol=stol, maxit=smax)
+        total += step
+        m = step
+        for j in range(step):                # invariant subspace: H[j+1,j] == 0
             if H[j + 1, j] == 0:
                 m = j + 1
                 break
@@ -79,16 +92,18 @@ def eigs(A, M, nev=1, v0=None, ncv=None, tol=1e-13, maxrestart=8):
         order = np.argsort(-np.abs(theta))
         theta, Yr = theta[order], Yr[:, order]
         k = min(nev, m)
-        res = np.abs(H[m, m - 1]) * np.abs(Yr[m - 1, :k]) if m < H.shape[0] else np.zeros(k)
+        res = np.abs(H[m, m - 1]) * np.abs(Yr[m - 1, :k])
         X = V[:, :m] @ Yr[:, :k]
         X = X / np.linalg.norm(X, axis=0)
-        last = (1.0 / theta[:k], X)
-        if np.all(res <= tol * np.abs(theta[:k])) or m < ncv:
-            return last
+        last = (sig_out + 1.0 / theta[:k], X)
+        if m > k:
+            gap = abs(1.0 / theta[k])          # crude estimate of the next eigenvalue's modulus
+        if np.all(res <= tol * np.abs(theta[:k])) or m < step or m >= d:
+            return last + (gap,) if return_gap else last
         v = X @ np.ones(k)                    # restart with the wanted Ritz vectors
     if last is None:
         raise EigsError("no Ritz pair")
-    return last
+    return last + (gap,) if return_gap else last
 
 
 def householder_update(f):
@@ -108,14 +123,21 @@ def householder_update(f):
         + 10 * f[0] ** 2 * f[1] * (-9 * f[2] ** 2 + f[0] * f[4]) + f[0] ** 3 * (20 * f[2] * f[3] - f[0] * f[5]))
 
 
-def _aux_step(L, z, order, nev, v0, v0_adj, update):
-    """one pass of the loop body shared by householder and mslp (Householder.jl:96-120)."""
+def _aux_step(L, z, order, nev, v0, v0_adj, update, state):
+    """one pass of the loop body shared by householder and mslp (Householder.jl:96-120).
+    ``state`` carries |lam| and the gap estimate of the previous pass to choose the regularising shift."""
     L.params[L.eigval] = z
     L.params[L.auxval] = 0
     A = L(z)
     M = L.term_operator(len(L.terms) - 1, -1.0)          # M = -L.terms[end].coeff
-    lam, v = eigs(A, M, nev=nev, v0=v0)
-    lam_adj, v_adj = eigs(A.H, M.H, nev=nev, v0=v0_adj)
+    sigma = 0.0
+    gap_prev, lam_prev = state.get("gap", np.inf), state.get("lam", np.inf)
+    if np.isfinite(gap_prev) and lam_prev < 1e-4 * gap_prev:
+        sigma = 1e-5 * gap_prev
+    lam, v, gap = eigs(A, M, nev=nev, v0=v0, sigma=sigma, return_gap=True)
+    lam_adj, v_adj = eigs(A.H, M.H, nev=nev, v0=v0_adj, sigma=sigma)
+    state["gap"] = gap if np.isfinite(gap) else gap_prev
+    state["lam"] = float(np.min(np.abs(lam)))
     idx = np.argsort(np.abs(lam)); lam, v = lam[idx], v[:, idx]
     idx = np.argsort(np.abs(lam_adj)); lam_adj, v_adj = lam_adj[idx], v_adj[:, idx]
     cand = []
@@ -157,6 +179,7 @@ def householder(L, z, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, n
     v0_adj = np.conj(v0) if v0_adj is None else np.asarray(v0_adj, dtype=np.complex128)
     flag = 1
     history = []
+    state = {}
     try:
         while abs(z - z0) > tol and n < maxiter:
             if output:
@@ -164,7 +187,7 @@ def householder(L, z, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, n
             history.append(z)
             z0 = z
             lams, v, v_adj, dzs = _aux_step(L, z, order, nev, v0, v0_adj,
-                                            lambda c: householder_update([factorial(i) * ci for i, ci in enumerate(c)]))
+                                            lambda c: householder_update([factorial(i) * ci for i, ci in enumerate(c)]), state)
             i = int(np.argsort(np.abs(dzs))[0])
             lam = lams[i]
             L.params[L.auxval] = lam
@@ -215,6 +238,7 @@ def mslp(L, z, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, nev=1, v
         L.push(Term(-sp.identity(d, dtype=np.complex128, format="csr"), (pow1,), (("__aux__",),), "__aux__", "__aux__"))
         L.auxval = "__aux__"
     history = []
+    state = {}
     try:
         while abs(z - z0) > tol and n < maxiter:
             if output:
@@ -227,7 +251,7 @@ def mslp(L, z, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, nev=1, v
                 pades.append((num, den))
                 roots = poly_roots(num)
                 return roots[np.argsort(np.abs(roots))[0]]
-            lams, v, v_adj, dzs = _aux_step(L, z, order, nev, v0, v0_adj, upd)
+            lams, v, v_adj, dzs = _aux_step(L, z, order, nev, v0, v0_adj, upd, state)
             if not np.isinf(z0):
                 back = [lam0 - polyval(num, z0 - z) / polyval(den, z0 - z) for num, den in pades]
                 i = int(np.argsort(np.abs(back))[0])
