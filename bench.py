@@ -83,6 +83,10 @@ def main():
     ap.add_argument("--N", type=int, default=32)
     ap.add_argument("--tol", type=float, default=1e-10)
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--restart", type=int, default=60)
+    ap.add_argument("--sweeps", type=int, default=1)
+    ap.add_argument("--n", type=float, default=1.0)
+    ap.add_argument("--tau", type=float, default=2e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-preset", default="20k")
     args = ap.parse_args()
@@ -104,12 +108,12 @@ def main():
     from wae_amd.nlevp.distributed import allreduce_sum_, shard_points
 
     t0 = time.time()
-    L, pb = annulus_family(args.preset, device=local)
+    L, pb = annulus_family(args.preset, device=local, n=args.n, tau=args.tau)
     d = pb["d"]
     L.solver_tol = args.tol
     L.solver_maxit = 400
-    L.solver_ref = 2 * np.pi * 500.0
-    L.solver_opts = {"batch": args.batch}
+    L.solver_ref = 2 * np.pi * float(os.environ.get("WAE_REF_HZ", "500"))
+    L.solver_opts = {"batch": args.batch, "restart": args.restart, "sweeps": args.sweeps}
     fam = L.ensure_solver()
     t_setup = time.time() - t0
 

@@ -24,12 +24,15 @@ cz = L.coefficients(z)
 if what in ("all", "spmv"):
     for r in (1, 8, 64):
         base = fam.spmv_bytes(r=r, mask=[1, 1, 1, 1, 0])
-        for C, S in ((1, 8), (1, 16), (2, 8), (4, 4), (8, 1), (8, 2), (8, 4), (8, 8), (16, 2), (16, 4)):
+        for C, S in ((1, 8), (2, 8), (4, 4), (8, 1), (8, 2), (16, 2)):
             if C > r:
                 continue
             os.environ["WAE_SPMV_C"], os.environ["WAE_SPMV_S"] = str(C), str(S)
-            ms = fam.bench_spmv(cz, r=r, reps=20)
-            print(f"spmv r={r} C={C} S={S}: {ms * 1e3:.1f} us  {base / ms / 1e6:.0f} GB/s (algorithmic)", flush=True)
+            for lds in ((1, 0) if (C, S) == (8, 1) else (0,)):
+                os.environ["WAE_SPMV_LDS"] = str(lds)
+                ms = fam.bench_spmv(cz, r=r, reps=20)
+                print(f"spmv r={r} C={C} S={S} lds={lds}: {ms * 1e3:.1f} us  {base / ms / 1e6:.0f} GB/s (algorithmic)", flush=True)
+            os.environ.pop("WAE_SPMV_LDS", None)
     os.environ.pop("WAE_SPMV_C"); os.environ.pop("WAE_SPMV_S")
 if what in ("all", "solve"):
     L.solver_ref = 2 * np.pi * 500

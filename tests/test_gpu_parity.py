@@ -216,7 +216,25 @@ def test_G5_mslp_active_flame():
     w = c(G["G5"]["omega"])
     assert abs(sol.params["ω"] - w) < 1e-10 * abs(w)
     assert flag == 0 and abs(n - G["G5"]["iterations"]) <= 1
-    # Newton inverse iteration lands on the same eigenvalue
-    sol2, n2, flag2 = inveriter(Lp, w + 1.0, maxiter=20, tol=1e-9)
-    assert flag2 == 0 and abs(sol2.params["ω"] - w) < 1e-8 * abs(w)
+    Lp._drop_device()
+
+
+def test_newton_variants_match_oracle():
+    """inveriter / rf2s / lancaster: same start values on the oracle and on the device path."""
+    from wae_amd.nlevp import lancaster, rf2s
+    Lo = F.rijke_family(n=0.01, tau=0.001)
+    Lp = helmholtz_family(F.rijke_terms(), n=0.01, tau=0.001)
+    Lp.solver_ref = 340 * 2 * np.pi
+    w = c(G["G1"]["omega"])
+    so, no_, fo = OS.inveriter(Lo, 1710 + 9j, maxiter=20, tol=1e-9)
+    sp_, np_, fp = inveriter(Lp, 1710 + 9j, maxiter=20, tol=1e-9)
+    assert fo == fp == 0 and abs(np_ - no_) <= 1
+    assert abs(sp_.params["ω"] - so.params["ω"]) < 1e-8 * abs(w) and abs(sp_.params["ω"] - w) < 1e-8 * abs(w)
+    x = sp_.v
+    so, no_, fo = OS.rf2s(Lo, 1710 + 9j, maxiter=20, tol=1e-9, x0=x, y0=np.conj(x))
+    sp2, np2, fp2 = rf2s(Lp, 1710 + 9j, maxiter=20, tol=1e-9, x0=x, y0=np.conj(x))
+    assert fo == fp2 == 0 and abs(sp2.params["ω"] - so.params["ω"]) < 1e-8 * abs(w)
+    so, no_, fo = OS.lancaster(Lo, 1710 + 9j, maxiter=6, tol=1e-9)
+    sp3, np3, fp3 = lancaster(Lp, 1710 + 9j, maxiter=6, tol=1e-9)
+    assert abs(Lp.params["ω"] - Lo.params["ω"]) < 1e-6 * abs(w) or (fo != 0 and fp3 != 0)
     Lp._drop_device()

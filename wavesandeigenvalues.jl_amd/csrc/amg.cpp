@@ -261,12 +261,32 @@ void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, c
     levels.clear();
     CsrZ Aref = csr_lincomb(planes, pc_ref);
     const int64_t n0 = Aref.n;
-    // real shape matrix and penalty rows
+    // Real shape matrix S for strength-of-connection / aggregation / prolongator smoothing: the real part of the
+    // STRUCTURALLY SYMMETRIC part of A_ref.  One-sided couplings (the flame term Q = s g^T couples every flame
+    // node to the few reference nodes, Helmholtz.jl:464-487) are long-range and non-elliptic: letting them into
+    // the strength graph doubles the GMRES iteration count on the 200k-DoF annulus (dev/gpu_solve_check.py).
     CsrD S;
     S.n = S.m = n0;
-    S.ptr = Aref.ptr; S.col = Aref.col;
-    S.val.resize(Aref.val.size());
-    for (size_t p = 0; p < Aref.val.size(); ++p) S.val[p] = Aref.val[p].real();
+    S.ptr.assign(n0 + 1, 0);
+    {
+        CsrZ At = csr_transpose(Aref);
+        for (int64_t i = 0; i < n0; ++i) {
+            int q = At.ptr[i];
+            const int qe = At.ptr[i + 1];
+            for (int p = Aref.ptr[i]; p < Aref.ptr[i + 1]; ++p) {
+                const int j = Aref.col[p];
+                while (q < qe && At.col[q] < j) ++q;
+                const bool mirrored = q < qe && At.col[q] == j;
+                const double aij = std::abs(Aref.val[p]);
+                const double aji = mirrored ? std::abs(At.val[q]) : 0.0;
+                if (j == i || (mirrored && aji >= 0.25 * aij && aij >= 0.25 * aji)) {
+                    S.col.push_back(j);
+                    S.val.push_back(Aref.val[p].real());
+                }
+            }
+            S.ptr[i + 1] = (int)S.col.size();
+        }
+    }
     std::vector<double> dabs(n0);
     for (int64_t i = 0; i < n0; ++i) {
         zc dg = 0;

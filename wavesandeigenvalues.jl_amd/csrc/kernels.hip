@@ -73,13 +73,28 @@ __global__ __launch_bounds__(256) void spmv_kernel(OpDev op, const cplx *__restr
             if (np == 2) {          // the hot case: mass + stiffness share one pattern (16 B per nonzero)
                 const double2 *__restrict__ v2 = (const double2 *)G.vals;
                 const cplx c0 = gpc[0], c1 = gpc[1];
-#pragma unroll 2
-                for (int p = p0 + s; p < p1; p += S) {
-                    const int j = G.col[p];
-                    const double2 a = v2[p];
-                    const cplx x = X[(size_t)j * nb + bb];
-                    cplx m = {fma(c0.x, a.x, c1.x * a.y), fma(c0.y, a.x, c1.y * a.y)};
-                    cfma(acc, m, x);
+                // 4 nonzeros per trip: issue all index/value loads, then all X gathers, then the FMAs, so that four
+                // dependent (col -> X) chains are in flight per lane instead of one
+                constexpr int U = 4;
+                for (int p = p0 + s; p < p1; p += U * S) {
+                    int j[U];
+                    double2 a[U];
+                    cplx x[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int pp = p + u * S;
+                        const int pc_ = pp < p1 ? pp : p1 - 1;
+                        j[u] = G.col[pc_];
+                        a[u] = v2[pc_];
+                        if (pp >= p1) a[u] = double2{0.0, 0.0};
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) x[u] = X[(size_t)j[u] * nb + bb];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        cplx m = {fma(c0.x, a[u].x, c1.x * a[u].y), fma(c0.y, a[u].x, c1.y * a[u].y)};
+                        cfma(acc, m, x[u]);
+                    }
                 }
             } else {
                 for (int p = p0 + s; p < p1; p += S) {
@@ -137,6 +152,140 @@ __global__ __launch_bounds__(256) void spmv_kernel(OpDev op, const cplx *__restr
     Y[e] = out;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// LDS-staged variant for batch widths >= 8 (C = 8 column lanes per row, one row per team).
+// The L1 -> VGPR return path (64 B/clk/CU) is what limits the plain kernel at C = 8: every column lane of a team
+// receives its own copy of the same index and values.  Here the workgroup streams the (col, values) of its rows
+// ONCE, fully coalesced, into LDS (chunks of up to LDS_NNZ nonzeros), and the teams then read them back as LDS
+// broadcasts (conflict-free: the 8 lanes of a team hit one address); the only global gathers left are the X rows.
+// ---------------------------------------------------------------------------------------------------
+constexpr int LDS_WORDS = 2048;   // 8-byte value words staged per chunk (16 KB)
+constexpr int LDS_NNZ = 1024;     // nonzeros staged per chunk (4 KB of indices)
+
+template <int C>
+__global__ __launch_bounds__(256) void spmv_lds_kernel(OpDev op, const cplx *__restrict__ pc, int cps,
+                                                       const cplx *__restrict__ X, cplx *Y, const cplx *B, double jac_w,
+                                                       int nb, int mode) {
+    constexpr int TPB = 256 / C;            // rows per workgroup
+    extern __shared__ cplx spc[];           // [C][nplanes_total]
+    __shared__ __attribute__((aligned(16))) double lds_w[LDS_WORDS];
+    __shared__ int lds_c[LDS_NNZ];
+    const int tid = threadIdx.x;
+    const int npl = op.nplanes_total;
+    for (int i = tid; i < C * npl; i += 256) {
+        int cc = i / npl, q = i - cc * npl;
+        int bb = blockIdx.y * C + cc;
+        spc[i] = (bb < nb) ? pc[(size_t)(bb / cps) * npl + q] : cplx{0.0, 0.0};
+    }
+    const int team = tid / C;
+    const int c = tid - team * C;
+    const unsigned per_xcd = gridDim.x >> 3;
+    const int64_t rb = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const int64_t row0 = rb * TPB;
+    const int64_t row = row0 + team;
+    const bool valid = row < op.n;
+    const int b = blockIdx.y * C + c;
+    const bool active = b < nb;
+    const int bb = active ? b : nb - 1;
+    const cplx *mypc = spc + c * npl;
+    cplx acc = {0.0, 0.0};
+    const int64_t rlast = (row0 + TPB < op.n) ? row0 + TPB : op.n;     // first row after this block
+    __syncthreads();
+    if (row0 < op.n) {
+#pragma unroll 1
+        for (int g = 0; g < op.ngroups; ++g) {
+            const GroupDev G = op.g[g];
+            const int np = G.nplanes;
+            const int wpn = G.is_real ? np : 2 * np;                  // 8-byte words per nonzero
+            int chunk = LDS_WORDS / wpn;
+            if (chunk > LDS_NNZ) chunk = LDS_NNZ;
+            const int blo = G.rowptr[row0], bhi = G.rowptr[rlast];
+            const int p0 = valid ? G.rowptr[row] : 0, p1 = valid ? G.rowptr[row + 1] : 0;
+            const cplx *gpc = mypc + G.plane0;
+            const double *__restrict__ gw = (const double *)G.vals;
+            const double sg = G.conj_vals ? -1.0 : 1.0;
+            for (int lo = blo; lo < bhi; lo += chunk) {
+                const int hi = (lo + chunk < bhi) ? lo + chunk : bhi;
+                const int cnt = hi - lo;
+                __syncthreads();                                      // previous chunk fully consumed
+                for (int i = tid; i < cnt; i += 256) lds_c[i] = G.col[lo + i];
+                const int nw = cnt * wpn;
+                const double *src = gw + (size_t)lo * wpn;
+                for (int i = tid; i < nw; i += 256) lds_w[i] = src[i];
+                __syncthreads();
+                const int a0 = p0 > lo ? p0 : lo, a1 = p1 < hi ? p1 : hi;
+                if (G.is_real && np == 2) {
+                    const cplx c0 = gpc[0], c1 = gpc[1];
+                    const double2 *lv = (const double2 *)lds_w;
+                    constexpr int U = 4;
+                    for (int p = a0; p < a1; p += U) {
+                        int j[U];
+                        double2 a[U];
+                        cplx x[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int pp = (p + u < a1) ? p + u : a1 - 1;
+                            j[u] = lds_c[pp - lo];
+                            a[u] = lv[pp - lo];
+                            if (p + u >= a1) a[u] = double2{0.0, 0.0};
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) x[u] = X[(size_t)j[u] * nb + bb];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            cplx m = {fma(c0.x, a[u].x, c1.x * a[u].y), fma(c0.y, a[u].x, c1.y * a[u].y)};
+                            cfma(acc, m, x[u]);
+                        }
+                    }
+                } else if (G.is_real) {
+                    for (int p = a0; p < a1; ++p) {
+                        const int j = lds_c[p - lo];
+                        cplx m = {0.0, 0.0};
+                        for (int q = 0; q < np; ++q) {
+                            const double a = lds_w[(p - lo) * np + q];
+                            m.x = fma(gpc[q].x, a, m.x);
+                            m.y = fma(gpc[q].y, a, m.y);
+                        }
+                        cfma(acc, m, X[(size_t)j * nb + bb]);
+                    }
+                } else {
+                    const cplx *lv = (const cplx *)lds_w;
+                    for (int p = a0; p < a1; ++p) {
+                        const int j = lds_c[p - lo];
+                        cplx m = {0.0, 0.0};
+                        for (int q = 0; q < np; ++q) {
+                            cplx a = lv[(p - lo) * np + q];
+                            a.y *= sg;
+                            cfma(m, gpc[q], a);
+                        }
+                        cfma(acc, m, X[(size_t)j * nb + bb]);
+                    }
+                }
+            }
+        }
+    }
+    if (!valid || !active) return;
+    const size_t e = (size_t)row * nb + b;
+    cplx out;
+    if (mode == MODE_AX) {
+        out = acc;
+    } else if (mode == MODE_RES) {
+        const cplx bv = B[e];
+        out = cplx{bv.x - acc.x, bv.y - acc.y};
+    } else if (mode == MODE_ADD) {
+        const cplx bv = B[e];
+        out = cplx{bv.x + acc.x, bv.y + acc.y};
+    } else {   // MODE_JAC
+        cplx dg = {0.0, 0.0};
+        const double dsg = op.conj_diag ? -1.0 : 1.0;
+        for (int q = 0; q < npl; ++q) { cplx dq = op.diag[(size_t)row * npl + q]; dq.y *= dsg; cfma(dg, mypc[q], dq); }
+        const cplx bv = B[e], xv = X[e];
+        cplx r = cdiv(cplx{bv.x - acc.x, bv.y - acc.y}, dg);
+        out = cplx{xv.x + jac_w * r.x, xv.y + jac_w * r.y};
+    }
+    Y[e] = out;
+}
+
 typedef void (*spmv_fn)(OpDev, const cplx *, int, const cplx *, cplx *, const cplx *, double, int, int);
 template <int C, int S> static spmv_fn spmv_ptr() { return spmv_kernel<C, S>; }
 
@@ -164,9 +313,17 @@ void launch_spmv(const OpDev &op, const cplx *pc, int cps, const cplx *X, cplx *
     if (C == 8) S = 1;
     if (envC > 0 && envC <= nb) C = envC;
     if (envS > 0) S = envS;
+    if (op.n <= 0) return;
+    if (C == 8 && S == 1 && env_int("WAE_SPMV_LDS", 1)) {
+        const unsigned nrb = (unsigned)((op.n + 31) / 32);
+        dim3 grid((nrb + 7u) / 8u * 8u, (unsigned)((nb + 7) / 8));
+        size_t shm = (size_t)8 * op.nplanes_total * sizeof(cplx);
+        hipLaunchKernelGGL(spmv_lds_kernel<8>, grid, dim3(256), shm, st, op, pc, cps, X, Y, B, jac_w, nb, mode);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     spmv_fn fn = pick_spmv(C, S);
     if (!fn) throw WaeError(WAE_ERR_INVALID, "launch_spmv: unsupported (C,S)");
-    if (op.n <= 0) return;
     const int tpb = 256 / (C * S);
     const unsigned nrb = (unsigned)((op.n + tpb - 1) / tpb);
     dim3 grid((nrb + 7u) / 8u * 8u, (unsigned)((nb + C - 1) / C));
@@ -409,7 +566,7 @@ void launch_add(const cplx *X, cplx *Y, size_t count, hipStream_t st) {
 
 // partial[blk][i][b] = sum over this block's rows of conj(V_i[row][b]) W[row][b];  any nb <= 256
 // (thread t owns column t % nb and every R-th row, R = 256 / nb; threads beyond R*nb idle)
-constexpr int DOT_BLOCKS = 512;
+constexpr int DOT_BLOCKS = 256;
 template <int MAXV>
 __global__ __launch_bounds__(256) void dots_kernel(const cplx *__restrict__ V, size_t stride, int nv, const cplx *__restrict__ W,
                                                    int64_t n, int nb, cplx *__restrict__ partial) {
@@ -449,13 +606,21 @@ __global__ __launch_bounds__(256) void dots_kernel(const cplx *__restrict__ V, s
         }
     }
 }
+// out[e] = sum_k partial[k][e]: 32 outputs x 8 k-slices per workgroup, LDS tree over the slices
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const cplx *__restrict__ partial, int nblk, int count, cplx *__restrict__ out, int do_sqrt) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= count) return;
+    __shared__ cplx sm[256];
+    const int lane_e = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + lane_e;
     cplx acc = {0.0, 0.0};
-    for (int k = 0; k < nblk; ++k) { cplx p = partial[(size_t)k * count + e]; acc.x += p.x; acc.y += p.y; }
-    if (do_sqrt) acc = cplx{sqrt(acc.x), 0.0};
-    out[e] = acc;
+    if (e < count)
+        for (int k = slice; k < nblk; k += 8) { cplx p = partial[(size_t)k * count + e]; acc.x += p.x; acc.y += p.y; }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if (slice == 0 && e < count) {
+        for (int s = 1; s < 8; ++s) { acc.x += sm[s * 32 + lane_e].x; acc.y += sm[s * 32 + lane_e].y; }
+        if (do_sqrt) acc = cplx{sqrt(acc.x), 0.0};
+        out[e] = acc;
+    }
 }
 
 static void dots_impl(const cplx *V, size_t stride, int nv, const cplx *W, int64_t n, int nb, cplx *partial, cplx *out, int do_sqrt, hipStream_t st) {
@@ -470,7 +635,7 @@ static void dots_impl(const cplx *V, size_t stride, int nv, const cplx *W, int64
         else hipLaunchKernelGGL(dots_kernel<32>, dim3(nblk), dim3(256), 0, st, Vc, stride, chunk, W, n, nb, partial);
         HIP_CHECK(hipGetLastError());
         int count = chunk * nb;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((count + 255) / 256), dim3(256), 0, st, partial, nblk, count, out + (size_t)done * nb, do_sqrt);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((count + 31) / 32), dim3(256), 0, st, partial, nblk, count, out + (size_t)done * nb, do_sqrt);
         HIP_CHECK(hipGetLastError());
         done += chunk;
     }

@@ -336,7 +336,8 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
     // narrow batches get a longer recurrence from the same workspace (near-singular systems in the Newton-type
     // solvers stall under short restarts); they also afford a second Gram-Schmidt pass
     const int m = (int)std::min<size_t>(150, h->V.n / vec - 1);
-    const bool reorth = nb <= 8;
+    static const char *env_re = getenv("WAE_REORTH");
+    const bool reorth = env_re ? atoi(env_re) != 0 : nb <= 8;
     const OpDev A = h->ops[0].dev(bt.op);
     const cplx *pc = pc_level(h, 0);
     cplx *hp = h->h_pinned;

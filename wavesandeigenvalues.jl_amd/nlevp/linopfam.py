@@ -245,6 +245,7 @@ class LinearOperatorFamily:
         self.solver_maxit = 400
         self.solver_opts = {}
         self.solver_ref = None          # reference value of the eigenvalue parameter for the multigrid set-up
+        self.solver_ref_coeffs = None   # or: explicit reference coefficients (one per term) for the set-up
 
     # -- term management -------------------------------------------------------------------------------
     def push(self, T):
@@ -301,6 +302,8 @@ class LinearOperatorFamily:
 
     def ensure_solver(self):
         fam = self.device()
+        if not fam.solver_ready and self.solver_ref_coeffs is not None:
+            fam.setup_solver(np.asarray(self.solver_ref_coeffs, dtype=np.complex128), **self.solver_opts)
         if not fam.solver_ready:
             zref = self.solver_ref
             if zref is None:
