@@ -96,7 +96,7 @@ typedef struct {
     int32_t iters_total;    /* sum over columns                              */
     int32_t n_unconverged;  /* columns that stopped at maxit                 */
     int32_t levels;         /* multigrid levels used                         */
-    double  relres_max;     /* max_b ||B_b - A X_b|| / ||B_b|| (true residual, recomputed)      */
+    double  relres_max;     /* max_b ||M^-1(B_b - A X_b)|| / ||M^-1 B_b||: preconditioned (error-like) residual, recomputed */
     double  seconds;        /* wall time of the device work                  */
 } wae_solve_info;
 
@@ -107,6 +107,14 @@ typedef struct {
  */
 int wae_solve(wae_family *h, const double *coeffs, int32_t ncoef, const double *B, double *X, int32_t r,
               int32_t op, double tol, int32_t maxit, wae_solve_info *info);
+
+/* wae_solve with an initial-guess direction per column: x0 = alpha_b * G[:,b], alpha_b = (A g_b)^H b_b / ||A g_b||^2.
+ * The Newton-type solvers know the dominant direction of the solution close to an eigenvalue (the current
+ * eigenvector iterate: `u = L(z)\(L(z,1)*x0)`, iterative_solvers.jl:307,571-572); an iterative inner solver then
+ * only has to produce the small remainder, where the reference relies on UMFPACK factorising a nearly singular L(z).
+ * G may be NULL (= wae_solve). */
+int wae_solve_guess(wae_family *h, const double *coeffs, int32_t ncoef, const double *B, const double *G, double *X,
+                    int32_t r, int32_t op, double tol, int32_t maxit, wae_solve_info *info);
 
 /* -- Beyn moments -------------------------------------------------------------------------------------
  * The whole quadrature loop of `beyn` / `compute_moment_matrices` (beyn.jl:62-74,112-138,251-268):

@@ -141,13 +141,20 @@ __global__ __launch_bounds__(256) void spmv_kernel(OpDev op, const cplx *__restr
     } else if (mode == MODE_ADD) {
         const cplx bv = B[e];
         out = cplx{bv.x + acc.x, bv.y + acc.y};
-    } else {   // MODE_JAC
+    } else {   // MODE_JAC / MODE_AX_DS / MODE_RES_DS need the diagonal of this column's operator
         cplx dg = {0.0, 0.0};
         const double dsg = op.conj_diag ? -1.0 : 1.0;
         for (int q = 0; q < npl; ++q) { cplx dq = op.diag[(size_t)row * npl + q]; dq.y *= dsg; cfma(dg, mypc[q], dq); }
-        const cplx bv = B[e], xv = X[e];
-        cplx r = cdiv(cplx{bv.x - acc.x, bv.y - acc.y}, dg);
-        out = cplx{xv.x + jac_w * r.x, xv.y + jac_w * r.y};
+        if (mode == MODE_AX_DS) {
+            out = cdiv(acc, dg);
+        } else if (mode == MODE_RES_DS) {
+            const cplx bv = B[e];
+            out = cdiv(cplx{bv.x - acc.x, bv.y - acc.y}, dg);
+        } else {
+            const cplx bv = B[e], xv = X[e];
+            cplx r = cdiv(cplx{bv.x - acc.x, bv.y - acc.y}, dg);
+            out = cplx{xv.x + jac_w * r.x, xv.y + jac_w * r.y};
+        }
     }
     Y[e] = out;
 }
@@ -275,13 +282,20 @@ __global__ __launch_bounds__(256) void spmv_lds_kernel(OpDev op, const cplx *__r
     } else if (mode == MODE_ADD) {
         const cplx bv = B[e];
         out = cplx{bv.x + acc.x, bv.y + acc.y};
-    } else {   // MODE_JAC
+    } else {   // MODE_JAC / MODE_AX_DS / MODE_RES_DS need the diagonal of this column's operator
         cplx dg = {0.0, 0.0};
         const double dsg = op.conj_diag ? -1.0 : 1.0;
         for (int q = 0; q < npl; ++q) { cplx dq = op.diag[(size_t)row * npl + q]; dq.y *= dsg; cfma(dg, mypc[q], dq); }
-        const cplx bv = B[e], xv = X[e];
-        cplx r = cdiv(cplx{bv.x - acc.x, bv.y - acc.y}, dg);
-        out = cplx{xv.x + jac_w * r.x, xv.y + jac_w * r.y};
+        if (mode == MODE_AX_DS) {
+            out = cdiv(acc, dg);
+        } else if (mode == MODE_RES_DS) {
+            const cplx bv = B[e];
+            out = cdiv(cplx{bv.x - acc.x, bv.y - acc.y}, dg);
+        } else {
+            const cplx bv = B[e], xv = X[e];
+            cplx r = cdiv(cplx{bv.x - acc.x, bv.y - acc.y}, dg);
+            out = cplx{xv.x + jac_w * r.x, xv.y + jac_w * r.y};
+        }
     }
     Y[e] = out;
 }

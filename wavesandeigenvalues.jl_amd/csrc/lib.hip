@@ -328,7 +328,13 @@ struct ColState {
     bool conv = false;
 };
 
-static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double tol, int maxit, wae_solve_info *info) {
+static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double tol, int maxit, wae_solve_info *info,
+                  const cplx *guess_dir = nullptr) {
+    // LEFT-preconditioned GMRES(m) on  M^-1 A x = M^-1 b  (M^-1 = one multigrid V-cycle), all columns in lock-step.
+    // Every norm is therefore a norm of the preconditioned residual M^-1 r ~ the error itself.  This matters here:
+    // the admittance rows carry 1e15-sized entries (Helmholtz.jl:151-156), so the plain residual norm is dominated
+    // by a handful of boundary rows and says nothing about the interior (a right-preconditioned version accepted
+    // x = x0/z as "converged" to 1e-17 in inveriter's first step).
     hipStream_t st = h->stream;
     const int nb = bt.nb;
     const int64_t n = h->d;
@@ -342,7 +348,10 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
     const cplx *pc = pc_level(h, 0);
     cplx *hp = h->h_pinned;
     launch_fill_zero(X, vec, st);
-    launch_norms(B, n, nb, h->partial.p, h->hdev.p, st);
+    {
+        const cplx *zb = vcycle(h, bt, 0, B);
+        launch_norms(zb, n, nb, h->partial.p, h->hdev.p, st);
+    }
     HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     std::vector<double> bnorm(nb), relres(nb, 0.0);
@@ -354,12 +363,37 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
     int total_it = 0;
     bool first = true;
     bool nan_seen = false;
-    while (true) {
-        cplx *r = h->W.p;
-        if (first) launch_copy(B, r, vec, st);
-        else launch_spmv(A, pc, bt.cps, X, r, B, 0.0, nb, MODE_RES, st);
+    if (guess_dir) {
+        // initial guess x0 = alpha * g, alpha = (M^-1 A g)^H (M^-1 b) / ||M^-1 A g||^2 per column: when the solution is
+        // dominated by a known direction (inverse iteration close to an eigenvalue) the Krylov solve only has to
+        // produce the small rest
+        launch_spmv(A, pc, bt.cps, guess_dir, h->W.p, nullptr, 0.0, nb, MODE_AX, st);
+        launch_copy(vcycle(h, bt, 0, h->W.p), h->U.p, vec, st);
+        const cplx *zb = vcycle(h, bt, 0, B);
+        launch_dots(h->U.p, 0, 1, zb, n, nb, h->partial.p, h->hdev.p, st);
+        launch_dots(h->U.p, 0, 1, h->U.p, n, nb, h->partial.p, h->hdev.p + nb, st);
+        HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, (size_t)2 * nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        std::vector<cplx> al(nb);
+        for (int b = 0; b < nb; ++b) {
+            const double den = hp[nb + b].x;
+            al[b] = den > 0.0 ? cplx{hp[b].x / den, hp[b].y / den} : cplx{0.0, 0.0};
+        }
+        h->ydev.upload(al.data(), nb, st);
+        launch_lincomb(guess_dir, 0, 1, h->ydev.p, X, n, nb, st);
+        HIP_CHECK(hipStreamSynchronize(st));
         first = false;
-        launch_norms(r, n, nb, h->partial.p, h->hdev.p, st);
+    }
+    while (true) {
+        const cplx *z0;
+        if (first) {
+            z0 = vcycle(h, bt, 0, B);
+        } else {
+            launch_spmv(A, pc, bt.cps, X, h->W.p, B, 0.0, nb, MODE_RES, st);
+            z0 = vcycle(h, bt, 0, h->W.p);
+        }
+        first = false;
+        launch_norms(z0, n, nb, h->partial.p, h->hdev.p, st);
         HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         bool all_done = true;
@@ -372,7 +406,7 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
             if (!done[b]) all_done = false;
         }
         if (all_done || total_it >= maxit || nan_seen) break;
-        launch_scale_inv(r, h->hdev.p, h->V.p, n, nb, st);     // V0 = r / beta
+        launch_scale_inv(z0, h->hdev.p, h->V.p, n, nb, st);     // V0 = M^-1 r / beta
         for (int b = 0; b < nb; ++b) {
             ColState &c = cs[b];
             c.H.assign((size_t)(m + 1) * m, zc(0));
@@ -386,18 +420,18 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
         int j = 0;
         for (; j < m && total_it < maxit; ++j) {
             const cplx *vj = h->V.p + (size_t)j * vec;
-            const cplx *z = vcycle(h, bt, 0, vj);
-            launch_spmv(A, pc, bt.cps, z, h->W.p, nullptr, 0.0, nb, MODE_AX, st);
-            launch_dots(h->V.p, vec, j + 1, h->W.p, n, nb, h->partial.p, h->hdev.p, st);
-            launch_axpy_neg(h->V.p, vec, j + 1, h->hdev.p, h->W.p, n, nb, st);
+            launch_spmv(A, pc, bt.cps, vj, h->W.p, nullptr, 0.0, nb, MODE_AX, st);
+            cplx *w = vcycle(h, bt, 0, h->W.p);                  // w = M^-1 A v_j  (lives in a V-cycle buffer)
+            launch_dots(h->V.p, vec, j + 1, w, n, nb, h->partial.p, h->hdev.p, st);
+            launch_axpy_neg(h->V.p, vec, j + 1, h->hdev.p, w, n, nb, st);
             if (reorth) {   // CGS2: h += V^H w', w' -= V (V^H w')
                 cplx *h2 = h->hdev.p + (size_t)(m + 2) * nb;
-                launch_dots(h->V.p, vec, j + 1, h->W.p, n, nb, h->partial.p, h2, st);
-                launch_axpy_neg(h->V.p, vec, j + 1, h2, h->W.p, n, nb, st);
+                launch_dots(h->V.p, vec, j + 1, w, n, nb, h->partial.p, h2, st);
+                launch_axpy_neg(h->V.p, vec, j + 1, h2, w, n, nb, st);
                 launch_add(h2, h->hdev.p, (size_t)(j + 1) * nb, st);
             }
-            launch_norms(h->W.p, n, nb, h->partial.p, h->hdev.p + (size_t)(j + 1) * nb, st);
-            launch_scale_inv(h->W.p, h->hdev.p + (size_t)(j + 1) * nb, h->V.p + (size_t)(j + 1) * vec, n, nb, st);
+            launch_norms(w, n, nb, h->partial.p, h->hdev.p + (size_t)(j + 1) * nb, st);
+            launch_scale_inv(w, h->hdev.p + (size_t)(j + 1) * nb, h->V.p + (size_t)(j + 1) * vec, n, nb, st);
             HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, (size_t)(j + 2) * nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
             ++total_it;
@@ -434,7 +468,7 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
             }
             if (all_conv || nan_seen) { ++j; break; }
         }
-        // y = R^{-1} g per column, zero-padded to j steps
+        // y = R^{-1} g per column, zero-padded to j steps;  x += V y
         const int ju = std::min(j, m);
         std::vector<cplx> y((size_t)std::max(ju, 1) * nb, cplx{0.0, 0.0});
         for (int b = 0; b < nb; ++b) {
@@ -452,9 +486,8 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
         if (ju > 0) {
             h->ydev.upload(y.data(), (size_t)ju * nb, st);
             launch_lincomb(h->V.p, vec, ju, h->ydev.p, h->U.p, n, nb, st);
+            launch_add(h->U.p, X, vec, st);
             HIP_CHECK(hipStreamSynchronize(st));       // y is a stack vector
-            const cplx *z = vcycle(h, bt, 0, h->U.p);
-            launch_add(z, X, vec, st);
         }
         if (nan_seen) break;
     }
@@ -502,7 +535,8 @@ template <class F> static int guarded(F &&f) {
     }
 }
 
-static int info_code(wae_solve_info &i) {
+static int info_code(wae_solve_info &i) {   // also clears the internal stagnation marker bit
+
     const bool stag = (i.levels & (1 << 16)) != 0;
     i.levels &= 0xFFFF;
     if (i.n_unconverged > 0) return stag ? WAE_WARN_STAGNATION : WAE_WARN_MAXITER;
@@ -756,14 +790,14 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
 
 // solve a chunk of nb columns already on device in interleaved layout
 static void solve_chunk(wae_family *h, const Batch &bt, const std::vector<std::vector<zc>> &pcs, const cplx *B, cplx *X, double tol, int maxit,
-                        wae_solve_info *info) {
+                        wae_solve_info *info, const cplx *guess_dir = nullptr) {
     upload_pc(h, pcs);
     dense_setup(h, bt);
-    gmres(h, bt, B, X, tol, maxit, info);
+    gmres(h, bt, B, X, tol, maxit, info, guess_dir);
 }
 
-int wae_solve(wae_family *h, const double *coeffs, int32_t ncoef, const double *B, double *X, int32_t r, int32_t op, double tol, int32_t maxit,
-              wae_solve_info *info) {
+int wae_solve_guess(wae_family *h, const double *coeffs, int32_t ncoef, const double *B, const double *Gd, double *X, int32_t r, int32_t op,
+                    double tol, int32_t maxit, wae_solve_info *info) {
     return guarded([&]() {
         WAE_REQUIRE(h && coeffs && B && X && r > 0, "bad argument");
         WAE_REQUIRE(ncoef == 1 || ncoef == r, "ncoef must be 1 or r");
@@ -778,6 +812,12 @@ int wae_solve(wae_family *h, const double *coeffs, int32_t ncoef, const double *
         const size_t cnt = (size_t)d * r;
         ensure(h->io_a, cnt); ensure(h->io_b, cnt);
         HIP_CHECK(hipMemcpyAsync(h->io_a.p, B, cnt * sizeof(cplx), hipMemcpyHostToDevice, st));
+        DevBuf<cplx> gcol, gint;
+        if (Gd) {
+            gcol.alloc(cnt);
+            gint.alloc((size_t)d * h->NB);
+            HIP_CHECK(hipMemcpyAsync(gcol.p, Gd, cnt * sizeof(cplx), hipMemcpyHostToDevice, st));
+        }
         for (int c0 = 0; c0 < r; c0 += h->NB) {
             const int nb = std::min(h->NB, r - c0);
             Batch bt;
@@ -793,15 +833,23 @@ int wae_solve(wae_family *h, const double *coeffs, int32_t ncoef, const double *
                 for (int b = 0; b < nb; ++b) plane_coeffs(h, coeffs + (size_t)(c0 + b) * 2 * h->T, op, pcs[b]);
             }
             launch_colmajor_to_inter(h->io_a.p + (size_t)c0 * d, d, nb, h->Bs.p, nb, st);
-            solve_chunk(h, bt, pcs, h->Bs.p, h->Xs.p, tol, maxit, &li);
+            if (Gd) launch_colmajor_to_inter(gcol.p + (size_t)c0 * d, d, nb, gint.p, nb, st);
+            solve_chunk(h, bt, pcs, h->Bs.p, h->Xs.p, tol, maxit, &li, Gd ? gint.p : nullptr);
             launch_inter_to_colmajor(h->Xs.p, nb, d, nb, h->io_b.p + (size_t)c0 * d, st);
         }
         HIP_CHECK(hipMemcpyAsync(X, h->io_b.p, cnt * sizeof(cplx), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
+        gcol.release(); gint.release();
         li.seconds = now_s() - t0;
+        const int rc_ = info_code(li);
         if (info) *info = li;
-        return info_code(li);
+        return rc_;
     });
+}
+
+int wae_solve(wae_family *h, const double *coeffs, int32_t ncoef, const double *B, double *X, int32_t r, int32_t op, double tol, int32_t maxit,
+              wae_solve_info *info) {
+    return wae_solve_guess(h, coeffs, ncoef, B, nullptr, X, r, op, tol, maxit, info);
 }
 
 int wae_beyn_moments(wae_family *h, int32_t npts, const double *z, const double *w, const double *coeff_table, const double *V, int32_t l, int32_t K,
@@ -848,8 +896,9 @@ int wae_beyn_moments(wae_family *h, int32_t npts, const double *z, const double 
         HIP_CHECK(hipStreamSynchronize(st));
         Aown.release();
         li.seconds = now_s() - t0;
+        const int rc_ = info_code(li);
         if (info) *info = li;
-        return info_code(li);
+        return rc_;
     });
 }
 
@@ -918,8 +967,9 @@ int wae_arnoldi_shiftinvert(wae_family *h, const double *coeffsA, const double *
         memcpy(H_out, H.data(), H.size() * sizeof(zc));
         EV.release(); t.release(); pcM.release(); hcol.release();
         li.seconds = now_s() - t0;
+        const int rc_ = info_code(li);
         if (info) *info = li;
-        return info_code(li);
+        return rc_;
     });
 }
 

@@ -125,11 +125,12 @@ struct Transfer {                   // P (n_fine x n_coarse) and R = P^T as sing
 };
 
 // kernel launch wrappers (kernels.hip) -----------------------------------------------------------------
-enum { MODE_AX = 0, MODE_RES = 1, MODE_JAC = 2, MODE_ADD = 3 };
+enum { MODE_AX = 0, MODE_RES = 1, MODE_JAC = 2, MODE_ADD = 3, MODE_AX_DS = 4, MODE_RES_DS = 5 };
 // Y = f(A X) over columns [0,nb) of interleaved multivectors (leading dimension nb).
 //   pc: [nsys][nplanes_total] plane coefficients; column b uses row b / cps.
 //   MODE_AX : Y = A X            MODE_RES: Y = B - A X
 //   MODE_JAC: Y = X + w/diag (B - A X)   (diag from op.diag and pc)      MODE_ADD: Y = B + A X
+//   MODE_AX_DS: Y = (A X)/diag          MODE_RES_DS: Y = (B - A X)/diag   (row-scaled operator / residual)
 void launch_spmv(const OpDev &op, const cplx *pc, int cps, const cplx *X, cplx *Y, const cplx *B, double jac_w,
                  int nb, int mode, hipStream_t s);
 // X = w/diag * B  (first Jacobi sweep from a zero initial guess)

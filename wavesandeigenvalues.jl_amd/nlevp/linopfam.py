@@ -135,7 +135,7 @@ class DeviceFamily:
         self.solver_ready = True
         self.batch = batch
 
-    def solve(self, coeffs, B, op=OP_N, tol=1e-12, maxit=300, strict=False):
+    def solve(self, coeffs, B, op=OP_N, tol=1e-12, maxit=300, strict=False, guess=None):
         c = np.ascontiguousarray(coeffs, dtype=np.complex128)
         B = np.asarray(B, dtype=np.complex128)
         one = B.ndim == 1
@@ -144,8 +144,14 @@ class DeviceFamily:
         ncoef = 1 if c.ndim == 1 else c.shape[0]
         X = np.empty_like(Bf, order="F")
         info = SolveInfo()
-        code = check(_lib.lib().wae_solve(self.handle, zptr(c), ncoef, zptr(Bf), zptr(X), r, op, tol, maxit, C.byref(info)),
-                     warn_ok=not strict)
+        if guess is None:
+            code = check(_lib.lib().wae_solve(self.handle, zptr(c), ncoef, zptr(Bf), zptr(X), r, op, tol, maxit, C.byref(info)),
+                         warn_ok=not strict)
+        else:
+            Gf = np.asfortranarray(np.asarray(guess, dtype=np.complex128).reshape(self.d, -1))
+            assert Gf.shape == Bf.shape
+            code = check(_lib.lib().wae_solve_guess(self.handle, zptr(c), ncoef, zptr(Bf), zptr(Gf), zptr(X), r, op, tol, maxit,
+                                                    C.byref(info)), warn_ok=not strict)
         self.last_info = info.as_dict()
         self.last_code = code
         return X[:, 0].copy() if one else X
@@ -208,14 +214,14 @@ class Operator:
 
     dot = __matmul__
 
-    def solve(self, b, tol=None, maxit=None):
+    def solve(self, b, tol=None, maxit=None, guess=None):
         """Julia ``A \\ b`` (beyn.jl:65; iterative_solvers.jl:307,397-398)"""
         own = self.owner
         if own is not None:
             own.ensure_solver()
         tol = tol if tol is not None else (own.solver_tol if own is not None else 1e-12)
         maxit = maxit if maxit is not None else (own.solver_maxit if own is not None else 300)
-        return self.fam.solve(self.coeffs, b, self.op, tol, maxit)
+        return self.fam.solve(self.coeffs, b, self.op, tol, maxit, guess=guess)
 
     def __neg__(self):
         return Operator(self.fam, -self.coeffs, self.op, self.owner)

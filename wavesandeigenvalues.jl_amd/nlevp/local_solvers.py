@@ -318,7 +318,7 @@ def inveriter(L, z, maxiter=10, tol=0.0, relax=1.0, x0=None, v=None, output=Fals
             if output:
                 print(n, "\t\t", abs(z - z0), "\t", z)
             z0 = z
-            u = L(z, 0).solve(L(z, 1) @ x0)
+            u = L(z, 0).solve(L(z, 1) @ x0, guess=x0)        # the solution is x0/(ω*-z) to first order
             z = z0 - np.vdot(v, x0) / np.vdot(v, u)
             x0 = u / np.vdot(v, u)
             n += 1
@@ -369,8 +369,8 @@ def rf2s(L, z, maxiter=10, tol=0.0, relax=1.0, x0=None, y0=None, output=False):
             z0 = z
             A = L(z)
             L1 = L(z, 1)
-            x0 = A.solve(L1 @ x0)
-            y0 = A.H.solve(L1.H @ y0)
+            x0 = A.solve(L1 @ x0, guess=x0)
+            y0 = A.H.solve(L1.H @ y0, guess=y0)
             x0 = x0 / np.sqrt(np.vdot(x0, x0)); y0 = y0 / np.sqrt(np.vdot(y0, y0))
             idx = 0
             z00 = complex(np.inf)
