@@ -169,19 +169,25 @@ __global__ __launch_bounds__(256) void spmv_kernel(OpDev op, const cplx *__restr
 constexpr int LDS_WORDS = 2048;   // 8-byte value words staged per chunk (16 KB)
 constexpr int LDS_NNZ = 1024;     // nonzeros staged per chunk (4 KB of indices)
 
-template <int C>
+// One workgroup = 32 rows x (8*NCH) batch columns: the staged matrix tile is reused for NCH column chunks, so the
+// matrix streams through the workgroup once per 8*NCH columns (once per launch at the default batch width 64) and
+// each gathered X row is consumed as NCH consecutive 128-B segments of one 1-KB interleaved row.
+template <int NCH>
 __global__ __launch_bounds__(256) void spmv_lds_kernel(OpDev op, const cplx *__restrict__ pc, int cps,
                                                        const cplx *__restrict__ X, cplx *Y, const cplx *B, double jac_w,
                                                        int nb, int mode) {
+    constexpr int C = 8;
     constexpr int TPB = 256 / C;            // rows per workgroup
-    extern __shared__ cplx spc[];           // [C][nplanes_total]
+    constexpr int CW = C * NCH;             // columns per workgroup
+    extern __shared__ cplx spc[];           // [CW][nplanes_total]
     __shared__ __attribute__((aligned(16))) double lds_w[LDS_WORDS];
     __shared__ int lds_c[LDS_NNZ];
     const int tid = threadIdx.x;
     const int npl = op.nplanes_total;
-    for (int i = tid; i < C * npl; i += 256) {
+    const int col0 = blockIdx.y * CW;
+    for (int i = tid; i < CW * npl; i += 256) {
         int cc = i / npl, q = i - cc * npl;
-        int bb = blockIdx.y * C + cc;
+        int bb = col0 + cc;
         spc[i] = (bb < nb) ? pc[(size_t)(bb / cps) * npl + q] : cplx{0.0, 0.0};
     }
     const int team = tid / C;
@@ -191,11 +197,17 @@ __global__ __launch_bounds__(256) void spmv_lds_kernel(OpDev op, const cplx *__r
     const int64_t row0 = rb * TPB;
     const int64_t row = row0 + team;
     const bool valid = row < op.n;
-    const int b = blockIdx.y * C + c;
-    const bool active = b < nb;
-    const int bb = active ? b : nb - 1;
-    const cplx *mypc = spc + c * npl;
-    cplx acc = {0.0, 0.0};
+    int bcol[NCH];                          // this lane's column in every chunk (clamped for loads)
+    bool act[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int b = col0 + k * C + c;
+        act[k] = b < nb;
+        bcol[k] = act[k] ? b : nb - 1;
+    }
+    cplx acc[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) acc[k] = cplx{0.0, 0.0};
     const int64_t rlast = (row0 + TPB < op.n) ? row0 + TPB : op.n;     // first row after this block
     __syncthreads();
     if (row0 < op.n) {
@@ -208,7 +220,6 @@ __global__ __launch_bounds__(256) void spmv_lds_kernel(OpDev op, const cplx *__r
             if (chunk > LDS_NNZ) chunk = LDS_NNZ;
             const int blo = G.rowptr[row0], bhi = G.rowptr[rlast];
             const int p0 = valid ? G.rowptr[row] : 0, p1 = valid ? G.rowptr[row + 1] : 0;
-            const cplx *gpc = mypc + G.plane0;
             const double *__restrict__ gw = (const double *)G.vals;
             const double sg = G.conj_vals ? -1.0 : 1.0;
             for (int lo = blo; lo < bhi; lo += chunk) {
@@ -222,13 +233,12 @@ __global__ __launch_bounds__(256) void spmv_lds_kernel(OpDev op, const cplx *__r
                 __syncthreads();
                 const int a0 = p0 > lo ? p0 : lo, a1 = p1 < hi ? p1 : hi;
                 if (G.is_real && np == 2) {
-                    const cplx c0 = gpc[0], c1 = gpc[1];
                     const double2 *lv = (const double2 *)lds_w;
-                    constexpr int U = 4;
+                    constexpr int U = (NCH >= 4) ? 2 : 4;             // U*NCH gathers in flight per lane
                     for (int p = a0; p < a1; p += U) {
                         int j[U];
                         double2 a[U];
-                        cplx x[U];
+                        cplx x[U][NCH];
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
                             const int pp = (p + u < a1) ? p + u : a1 - 1;
@@ -237,67 +247,80 @@ __global__ __launch_bounds__(256) void spmv_lds_kernel(OpDev op, const cplx *__r
                             if (p + u >= a1) a[u] = double2{0.0, 0.0};
                         }
 #pragma unroll
-                        for (int u = 0; u < U; ++u) x[u] = X[(size_t)j[u] * nb + bb];
+                        for (int u = 0; u < U; ++u)
 #pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            cplx m = {fma(c0.x, a[u].x, c1.x * a[u].y), fma(c0.y, a[u].x, c1.y * a[u].y)};
-                            cfma(acc, m, x[u]);
-                        }
-                    }
-                } else if (G.is_real) {
-                    for (int p = a0; p < a1; ++p) {
-                        const int j = lds_c[p - lo];
-                        cplx m = {0.0, 0.0};
-                        for (int q = 0; q < np; ++q) {
-                            const double a = lds_w[(p - lo) * np + q];
-                            m.x = fma(gpc[q].x, a, m.x);
-                            m.y = fma(gpc[q].y, a, m.y);
-                        }
-                        cfma(acc, m, X[(size_t)j * nb + bb]);
+                            for (int k = 0; k < NCH; ++k) x[u][k] = X[(size_t)j[u] * nb + bcol[k]];
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+#pragma unroll
+                            for (int k = 0; k < NCH; ++k) {
+                                const cplx *gpc = spc + (k * C + c) * npl + G.plane0;
+                                const cplx c0 = gpc[0], c1 = gpc[1];
+                                cplx m = {fma(c0.x, a[u].x, c1.x * a[u].y), fma(c0.y, a[u].x, c1.y * a[u].y)};
+                                cfma(acc[k], m, x[u][k]);
+                            }
                     }
                 } else {
-                    const cplx *lv = (const cplx *)lds_w;
                     for (int p = a0; p < a1; ++p) {
                         const int j = lds_c[p - lo];
-                        cplx m = {0.0, 0.0};
-                        for (int q = 0; q < np; ++q) {
-                            cplx a = lv[(p - lo) * np + q];
-                            a.y *= sg;
-                            cfma(m, gpc[q], a);
+#pragma unroll
+                        for (int k = 0; k < NCH; ++k) {
+                            const cplx *gpc = spc + (k * C + c) * npl + G.plane0;
+                            cplx m = {0.0, 0.0};
+                            if (G.is_real) {
+                                for (int q = 0; q < np; ++q) {
+                                    const double a = lds_w[(p - lo) * np + q];
+                                    m.x = fma(gpc[q].x, a, m.x);
+                                    m.y = fma(gpc[q].y, a, m.y);
+                                }
+                            } else {
+                                const cplx *lv = (const cplx *)lds_w;
+                                for (int q = 0; q < np; ++q) {
+                                    cplx a = lv[(p - lo) * np + q];
+                                    a.y *= sg;
+                                    cfma(m, gpc[q], a);
+                                }
+                            }
+                            cfma(acc[k], m, X[(size_t)j * nb + bcol[k]]);
                         }
-                        cfma(acc, m, X[(size_t)j * nb + bb]);
                     }
                 }
             }
         }
     }
-    if (!valid || !active) return;
-    const size_t e = (size_t)row * nb + b;
-    cplx out;
-    if (mode == MODE_AX) {
-        out = acc;
-    } else if (mode == MODE_RES) {
-        const cplx bv = B[e];
-        out = cplx{bv.x - acc.x, bv.y - acc.y};
-    } else if (mode == MODE_ADD) {
-        const cplx bv = B[e];
-        out = cplx{bv.x + acc.x, bv.y + acc.y};
-    } else {   // MODE_JAC / MODE_AX_DS / MODE_RES_DS need the diagonal of this column's operator
-        cplx dg = {0.0, 0.0};
-        const double dsg = op.conj_diag ? -1.0 : 1.0;
-        for (int q = 0; q < npl; ++q) { cplx dq = op.diag[(size_t)row * npl + q]; dq.y *= dsg; cfma(dg, mypc[q], dq); }
-        if (mode == MODE_AX_DS) {
-            out = cdiv(acc, dg);
-        } else if (mode == MODE_RES_DS) {
+    if (!valid) return;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        if (!act[k]) continue;
+        const int b = col0 + k * C + c;
+        const cplx *mypc = spc + (k * C + c) * npl;
+        const size_t e = (size_t)row * nb + b;
+        cplx out;
+        if (mode == MODE_AX) {
+            out = acc[k];
+        } else if (mode == MODE_RES) {
             const cplx bv = B[e];
-            out = cdiv(cplx{bv.x - acc.x, bv.y - acc.y}, dg);
-        } else {
-            const cplx bv = B[e], xv = X[e];
-            cplx r = cdiv(cplx{bv.x - acc.x, bv.y - acc.y}, dg);
-            out = cplx{xv.x + jac_w * r.x, xv.y + jac_w * r.y};
+            out = cplx{bv.x - acc[k].x, bv.y - acc[k].y};
+        } else if (mode == MODE_ADD) {
+            const cplx bv = B[e];
+            out = cplx{bv.x + acc[k].x, bv.y + acc[k].y};
+        } else {   // MODE_JAC / MODE_AX_DS / MODE_RES_DS need the diagonal of this column's operator
+            cplx dg = {0.0, 0.0};
+            const double dsg = op.conj_diag ? -1.0 : 1.0;
+            for (int q = 0; q < npl; ++q) { cplx dq = op.diag[(size_t)row * npl + q]; dq.y *= dsg; cfma(dg, mypc[q], dq); }
+            if (mode == MODE_AX_DS) {
+                out = cdiv(acc[k], dg);
+            } else if (mode == MODE_RES_DS) {
+                const cplx bv = B[e];
+                out = cdiv(cplx{bv.x - acc[k].x, bv.y - acc[k].y}, dg);
+            } else {
+                const cplx bv = B[e], xv = X[e];
+                cplx r = cdiv(cplx{bv.x - acc[k].x, bv.y - acc[k].y}, dg);
+                out = cplx{xv.x + jac_w * r.x, xv.y + jac_w * r.y};
+            }
         }
+        Y[e] = out;
     }
-    Y[e] = out;
 }
 
 typedef void (*spmv_fn)(OpDev, const cplx *, int, const cplx *, cplx *, const cplx *, double, int, int);
@@ -329,10 +352,16 @@ void launch_spmv(const OpDev &op, const cplx *pc, int cps, const cplx *X, cplx *
     if (envS > 0) S = envS;
     if (op.n <= 0) return;
     if (C == 8 && S == 1 && env_int("WAE_SPMV_LDS", 1)) {
+        const int nch_env = env_int("WAE_SPMV_NCH", 0);
+        int nchunks = (nb + 7) / 8;
+        int NCH = nch_env > 0 ? nch_env : (nchunks >= 4 ? 4 : (nchunks >= 2 ? 2 : 1));   // 8 halves the occupancy: slower (measured)
         const unsigned nrb = (unsigned)((op.n + 31) / 32);
-        dim3 grid((nrb + 7u) / 8u * 8u, (unsigned)((nb + 7) / 8));
-        size_t shm = (size_t)8 * op.nplanes_total * sizeof(cplx);
-        hipLaunchKernelGGL(spmv_lds_kernel<8>, grid, dim3(256), shm, st, op, pc, cps, X, Y, B, jac_w, nb, mode);
+        dim3 grid((nrb + 7u) / 8u * 8u, (unsigned)((nb + 8 * NCH - 1) / (8 * NCH)));
+        size_t shm = (size_t)8 * NCH * op.nplanes_total * sizeof(cplx);
+        if (NCH == 8) hipLaunchKernelGGL(spmv_lds_kernel<8>, grid, dim3(256), shm, st, op, pc, cps, X, Y, B, jac_w, nb, mode);
+        else if (NCH == 4) hipLaunchKernelGGL(spmv_lds_kernel<4>, grid, dim3(256), shm, st, op, pc, cps, X, Y, B, jac_w, nb, mode);
+        else if (NCH == 2) hipLaunchKernelGGL(spmv_lds_kernel<2>, grid, dim3(256), shm, st, op, pc, cps, X, Y, B, jac_w, nb, mode);
+        else hipLaunchKernelGGL(spmv_lds_kernel<1>, grid, dim3(256), shm, st, op, pc, cps, X, Y, B, jac_w, nb, mode);
         HIP_CHECK(hipGetLastError());
         return;
     }
