@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--tol", type=float, default=1e-10)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--restart", type=int, default=40)
-    ap.add_argument("--sweeps", type=int, default=2)
+    ap.add_argument("--sweeps", type=int, default=1)
     ap.add_argument("--n", type=float, default=1.0)
     ap.add_argument("--tau", type=float, default=2e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -348,6 +348,9 @@ void launch_spmv(const OpDev &op, const cplx *pc, int cps, const cplx *X, cplx *
     int C = nb >= 8 ? 8 : (nb >= 4 ? 4 : (nb >= 2 ? 2 : 1));
     int S = 64 / C >= 8 ? 8 : 64 / C;
     if (C == 8) S = 1;
+    // small (coarse-level / transfer) operators are latency-bound with one lane per row: split each row over S lanes
+    if (C == 8 && op.n < env_int("WAE_SPMV_SMALL8", 4096)) S = 8;
+    else if (C == 8 && op.n < env_int("WAE_SPMV_SMALL4", 65536)) S = 4;
     if (envC > 0 && envC <= nb) C = envC;
     if (envS > 0) S = envS;
     if (op.n <= 0) return;
@@ -609,7 +612,7 @@ void launch_add(const cplx *X, cplx *Y, size_t count, hipStream_t st) {
 
 // partial[blk][i][b] = sum over this block's rows of conj(V_i[row][b]) W[row][b];  any nb <= 256
 // (thread t owns column t % nb and every R-th row, R = 256 / nb; threads beyond R*nb idle)
-constexpr int DOT_BLOCKS = 256;
+constexpr int DOT_BLOCKS = 1024;
 template <int MAXV>
 __global__ __launch_bounds__(256) void dots_kernel(const cplx *__restrict__ V, size_t stride, int nv, const cplx *__restrict__ W,
                                                    int64_t n, int nb, cplx *__restrict__ partial) {

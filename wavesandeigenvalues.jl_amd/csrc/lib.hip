@@ -778,7 +778,7 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
         const size_t vec = (size_t)h->d * NB;
         h->V.alloc(vec * (m + 1));
         h->W.alloc(vec); h->Xs.alloc(vec); h->Bs.alloc(vec); h->U.alloc(vec);
-        h->partial.alloc((size_t)512 * 32 * NB);
+        h->partial.alloc((size_t)1024 * 32 * NB);   // DOT_BLOCKS x 32 vectors x NB columns
         h->hdev.alloc((size_t)2 * (m + 3) * NB);     // second half: scratch for the re-orthogonalisation pass
         h->ydev.alloc((size_t)(m + 1) * NB);
         if (h->h_pinned) { (void)hipHostFree(h->h_pinned); h->h_pinned = nullptr; }
