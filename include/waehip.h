@@ -148,7 +148,8 @@ int wae_arnoldi_shiftinvert(wae_family *h, const double *coeffsA, const double *
  * two-parameter expansion L(m,n) = d^m/dλ^m d^n/dε^n L /(m! n!):
  *   coeff_table[(m*(N+1)+n)*T + k]  = coefficient of term k in L(m,n), m,n = 0..N  (0 where m+n>N)
  *   v0, v0adj   base eigenvectors (un-normalised as the reference receives them)
- *   norm_mode   0: perturb (no `c` normalisation)  1: perturb_disk  2: perturb_norm with Y = sum cY_k A_k
+ *   norm_mode   0: perturb (no `c` normalisation)  1: perturb_disk  2: perturb_norm with Y = sum cY_k A_k;
+ *               +16: eigenvalue series only (skip the solve at order N; what householder/mslp need, Householder.jl:115-116)
  * Outputs lambda_out[N+1] (entry 0 untouched, the wrappers overwrite it: LinOpFam.jl:555), v_out d x (N+1).
  */
 int wae_perturb(wae_family *h, const double *coeff_table, int32_t N, const double *v0, const double *v0adj,

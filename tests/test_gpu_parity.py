@@ -246,3 +246,37 @@ def test_newton_variants_match_oracle():
     sp3, np3, fp3 = lancaster(Lp, 1710 + 9j, maxiter=6, tol=1e-9)
     assert abs(Lp.params["ω"] - Lo.params["ω"]) < 1e-6 * abs(w) or (fo != 0 and fp3 != 0)
     Lp._drop_device()
+
+
+def test_perturb_device_call_all_modes():
+    """wae_perturb (one device call) vs the host-orchestrated recurrence and vs the oracle, for perturb!,
+    perturb_fast! and perturb_norm! (LinOpFam.jl:546-618)."""
+    from wae_amd.nlevp import perturb_, perturb_norm_
+    from wae_amd.nlevp import perturbation as PP
+    Lo = F.rijke_family(n=0.01, tau=0.001)
+    Lp = helmholtz_family(F.rijke_terms(), n=0.01, tau=0.001)
+    Lp.solver_ref = 340 * 2 * np.pi
+    so, _, _ = OS.householder(Lo, 340 * 2 * np.pi, maxiter=20, tol=1e-11)
+    sp_, _, _ = householder(Lp, 340 * 2 * np.pi, maxiter=20, tol=1e-11)
+    N = 6
+    for name, fo, fp in (("perturb", OS.perturb_, perturb_), ("fast", OS.perturb_fast_, perturb_fast_),
+                         ("norm", OS.perturb_norm_, perturb_norm_)):
+        fo(so, Lo, "τ", N)
+        fp(sp_, Lp, "τ", N)
+        lo, lp = so.eigval_pert["τ/Taylor"], sp_.eigval_pert["τ/Taylor"]
+        for k in range(1, N + 1):
+            assert abs(lp[k] - lo[k]) < 1e-7 * abs(lo[k]), (name, k, lp[k], lo[k])
+        # eigenvector coefficients: compare up to the phase/normalisation of the base vectors via |<v_k, v_0>|-free norms
+        vo, vp = so.v_pert["τ/Taylor"], sp_.v_pert["τ/Taylor"]
+        ph = np.vdot(vo[0], vp[0]) / abs(np.vdot(vo[0], vp[0]))
+        for k in range(1, 4):
+            assert np.linalg.norm(vp[k] - ph * vo[k]) < 1e-5 * np.linalg.norm(vo[k]), (name, k)
+    # device call == host-orchestrated recurrence on the same inputs
+    Lp.params = sp_.params; Lp.active = ["ω", "τ"]; Lp.mode = "compact"
+    try:
+        l1, _ = PP._recurrence(Lp, 5, sp_.v, sp_.v_adj, normalize=True)
+        l2, _ = PP._recurrence_host(Lp, 5, sp_.v, sp_.v_adj, normalize=True)
+    finally:
+        Lp.active = ["ω"]; Lp.mode = "all"
+    assert np.allclose(l1[1:], l2[1:], rtol=1e-7)
+    Lp._drop_device()

@@ -795,6 +795,23 @@ void launch_beyn_accum(const cplx *Xi, int nb, int64_t d, int l, int nsys, const
     HIP_CHECK(hipGetLastError());
 }
 
+// X[row][t] = sum_i G[i][t] * V_i[row]   (tall-skinny product of the perturbation regrouping; V_i = V + i*stride)
+__global__ __launch_bounds__(256) void gemv_multi_kernel(const cplx *__restrict__ V, size_t stride, int k, const cplx *__restrict__ G,
+                                                         cplx *__restrict__ X, int64_t d, int T) {
+    const size_t total = (size_t)d * T;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t row = e / T;
+        const int t = (int)(e - row * T);
+        cplx acc = {0.0, 0.0};
+        for (int i = 0; i < k; ++i) cfma(acc, G[(size_t)i * T + t], V[(size_t)i * stride + row]);
+        X[e] = acc;
+    }
+}
+void launch_gemv_multi(const cplx *V, size_t stride, int k, const cplx *G, cplx *X, int64_t d, int T, hipStream_t st) {
+    hipLaunchKernelGGL(gemv_multi_kernel, dim3(grid_for((size_t)d * T)), dim3(256), 0, st, V, stride, k, G, X, d, T);
+    HIP_CHECK(hipGetLastError());
+}
+
 __global__ __launch_bounds__(256) void triad_kernel(double2 *__restrict__ a, const double2 *__restrict__ b, const double2 *__restrict__ c, double s, size_t n2) {
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n2; e += (size_t)gridDim.x * 256) {
         double2 x = b[e], y = c[e];

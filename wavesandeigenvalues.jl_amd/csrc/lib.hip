@@ -546,6 +546,26 @@ static int info_code(wae_solve_info &i) {   // also clears the internal stagnati
 // ----------------------------------------------------------------------------------------------------
 // C ABI
 // ----------------------------------------------------------------------------------------------------
+// Kelleher's accelerated ascending-composition generator (same order as perturbation.jl:2-80)
+template <class F> static void for_each_partition(int n, F &&f) {
+    std::vector<int> a(n + 1, 0);
+    int k = 1, y = n - 1;
+    while (k != 0) {
+        int x = a[k - 1] + 1;
+        k -= 1;
+        while (2 * x <= y) { a[k] = x; y -= x; k += 1; }
+        const int l = k + 1;
+        while (x <= y) {
+            a[k] = x; a[l] = y;
+            f(a.data(), k + 2);
+            x += 1; y -= 1;
+        }
+        a[k] = x + y;
+        y = x + y - 1;
+        f(a.data(), k + 1);
+    }
+}
+
 extern "C" {
 
 const char *wae_last_error(void) { return g_last_error.c_str(); }
@@ -973,12 +993,172 @@ int wae_arnoldi_shiftinvert(wae_family *h, const double *coeffsA, const double *
     });
 }
 
-int wae_perturb(wae_family *h, const double *coeff_table, int32_t N, const double *v0, const double *v0adj, int32_t norm_mode, const double *coeffsY,
+int wae_perturb(wae_family *h, const double *coeff_table, int32_t N, const double *v0, const double *v0adj, int32_t norm_mode_in, const double *coeffsY,
                 double tol, int32_t maxit, double *lambda_out, double *v_out, wae_solve_info *info) {
-    return guarded([&]() -> int {
-        (void)h; (void)coeff_table; (void)N; (void)v0; (void)v0adj; (void)norm_mode; (void)coeffsY; (void)tol; (void)maxit;
-        (void)lambda_out; (void)v_out; (void)info;
-        throw WaeError(WAE_ERR_INVALID, "wae_perturb: not implemented yet");
+    return guarded([&]() {
+        WAE_REQUIRE(h && coeff_table && v0 && v0adj && lambda_out && v_out && N >= 0 && N <= 200, "bad argument");
+        const bool skip_last = (norm_mode_in & 16) != 0;    // eigenvalue series only: no solve at order N
+        const int norm_mode = norm_mode_in & 15;
+        WAE_REQUIRE(norm_mode >= 0 && norm_mode <= 2 && (norm_mode != 2 || coeffsY), "bad norm_mode");
+        require_solver(h);
+        HIP_CHECK(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        wae_solve_info li;
+        memset(&li, 0, sizeof(li));
+        const double t0 = now_s();
+        const int64_t d = h->d;
+        const int T = h->T;
+        auto F = [&](int m, int n, int k) { return zc(coeff_table[((size_t)(m * (N + 1) + n) * T + k) * 2], coeff_table[((size_t)(m * (N + 1) + n) * T + k) * 2 + 1]); };
+        DevBuf<cplx> PV, Ub, rb, rhs, u10, wl, tmp, tmp2, tmp3, sc, Gd, pcd;
+        PV.alloc((size_t)d * (N + 1)); Ub.alloc((size_t)d * T); rb.alloc(d); rhs.alloc(d); u10.alloc(d); wl.alloc(d); tmp.alloc(d); tmp2.alloc(d); tmp3.alloc(d);
+        sc.alloc(8); Gd.alloc((size_t)(N + 1) * T + 4);
+        const OpDev A0 = h->ops[0].dev(WAE_OP_N);
+        cplx hs[4];
+        auto plane_tab = [&](const double *coeffs, int op) {     // level-0 plane table for an spmv
+            std::vector<zc> pc;
+            plane_coeffs(h, coeffs, op, pc);
+            std::vector<cplx> tab(h->nplanes);
+            for (int q = 0; q < h->nplanes; ++q) { const zc c = pc[h->slot_plane[0][q]]; tab[q] = cplx{c.real(), c.imag()}; }
+            pcd.upload(tab.data(), tab.size(), st);
+            HIP_CHECK(hipStreamSynchronize(st));
+        };
+        auto apply = [&](const double *coeffs, int op, const cplx *x, cplx *y) {
+            plane_tab(coeffs, op);
+            launch_spmv(h->ops[0].dev(op), pcd.p, 1 << 30, x, y, nullptr, 0.0, 1, MODE_AX, st);
+            HIP_CHECK(hipStreamSynchronize(st));
+        };
+        auto dot = [&](const cplx *a, const cplx *b) -> zc {      // a^H b
+            launch_dots(a, 0, 1, b, d, 1, h->partial.p, sc.p, st);
+            HIP_CHECK(hipMemcpyAsync(hs, sc.p, sizeof(cplx), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            return zc(hs[0].x, hs[0].y);
+        };
+        auto axpby = [&](zc a, const cplx *x, zc b, const cplx *y, cplx *out) {   // out = a x + b y (out may alias x or y)
+            cplx co[2] = {cplx{a.real(), a.imag()}, cplx{b.real(), b.imag()}};
+            Gd.upload(co, 2, st);
+            launch_lincomb(x, 0, 1, Gd.p, tmp2.p, d, 1, st);            // tmp2 = a x
+            launch_lincomb(y, 0, 1, Gd.p + 1, tmp3.p, d, 1, st);        // tmp3 = b y
+            launch_add(tmp2.p, tmp3.p, (size_t)d, st);
+            launch_copy(tmp3.p, out, (size_t)d, st);
+            HIP_CHECK(hipStreamSynchronize(st));
+        };
+        auto ipY = [&](const cplx *a, const cplx *b) -> zc {      // a^H Y b  (mode 2) or a^H b
+            if (norm_mode != 2) return dot(a, b);
+            apply(coeffsY, WAE_OP_N, b, tmp.p);
+            return dot(a, tmp.p);
+        };
+        std::vector<double> c00(2 * T), c10(2 * T);
+        for (int k = 0; k < T; ++k) {
+            const zc a = F(0, 0, k), b = N >= 1 ? F(1, 0, k) : zc(0);
+            c00[2 * k] = a.real(); c00[2 * k + 1] = a.imag();
+            c10[2 * k] = b.real(); c10[2 * k + 1] = b.imag();
+        }
+        // v[0] = v0 / sqrt(ip(v0,v0))
+        cplx *V0 = PV.p;
+        HIP_CHECK(hipMemcpyAsync(V0, v0, (size_t)d * sizeof(cplx), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(wl.p, v0adj, (size_t)d * sizeof(cplx), hipMemcpyHostToDevice, st));
+        {
+            const zc nn = ipY(V0, V0);
+            axpby(1.0 / std::sqrt(nn), V0, 0.0, V0, V0);
+        }
+        std::vector<zc> lam(N + 1, zc(0));
+        if (N >= 1) {
+            apply(c10.data(), WAE_OP_N, V0, u10.p);                                  // u10 = L(1,0) v0
+            Batch bt;
+            bt.nb = 1; bt.cps = 1; bt.nsys = 1; bt.op = WAE_OP_N;
+            std::vector<std::vector<zc>> pcs(1);
+            if (norm_mode == 2) {                                                    // perturbation.jl:493-494
+                plane_coeffs(h, coeffsY, WAE_OP_N, pcs[0]);
+                solve_chunk(h, bt, pcs, wl.p, tmp.p, tol, maxit, &li);               // v0Adj = Y \ v0Adj
+                apply(coeffsY, WAE_OP_N, u10.p, tmp2.p);
+                const zc sN = dot(tmp.p, tmp2.p);                                    // v0Adj' Y L10 v0
+                launch_copy(tmp.p, rb.p, (size_t)d, st);
+                axpby(1.0 / sN, rb.p, 0.0, rb.p, rb.p);                              // v0Adj /= s
+                apply(coeffsY, WAE_OP_C, rb.p, wl.p);                                // wl = Y' v0Adj
+            } else {
+                const zc sN = dot(wl.p, u10.p);                                      // v0Adj' L10 v0
+                axpby(1.0 / sN, wl.p, 0.0, wl.p, wl.p);
+            }
+            const zc denom = dot(wl.p, u10.p);
+            plane_coeffs(h, c00.data(), WAE_OP_N, pcs[0]);
+            upload_pc(h, pcs);
+            dense_setup(h, bt);
+            // plane passes for the multi-input SpMV (coefficient 1 per term: the weights live in G)
+            std::vector<std::vector<int>> plane_terms(h->nplanes);
+            for (int k = 0; k < T; ++k) plane_terms[h->term_plane[k]].push_back(k);
+            size_t npass = 0;
+            for (auto &v : plane_terms) npass = std::max(npass, v.size());
+            std::vector<zc> G;
+            for (int k = 1; k <= N; ++k) {
+                G.assign((size_t)k * T, zc(0));
+                auto addF = [&](int i, int m, int n, zc coeff) {
+                    for (int t = 0; t < T; ++t) G[(size_t)i * T + t] += coeff * F(m, n, t);
+                };
+                for (int n = 1; n <= k; ++n) addF(k - n, 0, n, 1.0);
+                for (int mw = 1; mw <= k; ++mw)
+                    for_each_partition(mw, [&](const int *p, int len) {
+                        if (len == 1 && p[0] == k) return;
+                        std::vector<int> mu(mw, 0);
+                        for (int i = 0; i < len; ++i) mu[p[i] - 1]++;
+                        double mn = std::tgamma((double)len + 1.0);
+                        zc coeff = 1.0;
+                        for (int g = 0; g < mw; ++g)
+                            if (mu[g]) {
+                                mn /= std::tgamma((double)mu[g] + 1.0);
+                                coeff *= std::pow(lam[g + 1], mu[g]);
+                            }
+                        coeff *= mn;
+                        for (int n = 0; n <= k - mw; ++n) {
+                            if (k == 1 && len == 1) continue;
+                            addF(k - n - mw, len, n, coeff);
+                        }
+                    });
+                std::vector<cplx> Gc((size_t)k * T);
+                for (size_t i = 0; i < Gc.size(); ++i) Gc[i] = cplx{G[i].real(), G[i].imag()};
+                Gd.upload(Gc.data(), Gc.size(), st);
+                launch_gemv_multi(PV.p, (size_t)d, k, Gd.p, Ub.p, d, T, st);
+                HIP_CHECK(hipStreamSynchronize(st));
+                launch_fill_zero(rb.p, (size_t)d, st);
+                std::vector<cplx> tab(h->nplanes);
+                std::vector<int> pcol(h->nplanes);
+                for (size_t ps = 0; ps < npass; ++ps) {
+                    for (int sidx = 0; sidx < h->nplanes; ++sidx) {
+                        const int q = h->slot_plane[0][sidx];
+                        if (ps < plane_terms[q].size()) {
+                            const int kk = plane_terms[q][ps];
+                            const zc c = h->term_scale[kk];
+                            tab[sidx] = cplx{c.real(), c.imag()};
+                            pcol[sidx] = kk;
+                        } else { tab[sidx] = cplx{0.0, 0.0}; pcol[sidx] = 0; }
+                    }
+                    pcd.upload(tab.data(), tab.size(), st);
+                    h->plane_col_dev.upload(pcol.data(), pcol.size(), st);
+                    launch_spmv_multi(A0, pcd.p, h->plane_col_dev.p, Ub.p, tmp.p, T, st);
+                    launch_add(tmp.p, rb.p, (size_t)d, st);
+                    HIP_CHECK(hipStreamSynchronize(st));
+                }
+                lam[k] = -dot(wl.p, rb.p) / denom;
+                if (skip_last && k == N) break;
+                axpby(-1.0, rb.p, -lam[k], u10.p, rhs.p);                             // rhs = -(r + lam_k L10 v0)
+                cplx *vk = PV.p + (size_t)k * d;
+                gmres(h, bt, rhs.p, vk, tol, maxit, &li);
+                const zc pr = ipY(V0, vk);
+                axpby(1.0, vk, -pr, V0, vk);                                          // v_k -= (v0' [Y] v_k) v0
+                if (norm_mode >= 1) {
+                    zc c = 0;
+                    for (int l = 1; l < k; ++l) c -= 0.5 * ipY(PV.p + (size_t)l * d, PV.p + (size_t)(k - l) * d);
+                    axpby(1.0, vk, c, V0, vk);
+                }
+            }
+        }
+        HIP_CHECK(hipMemcpyAsync(v_out, PV.p, (size_t)d * (N + 1) * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        for (int k = 1; k <= N; ++k) { lambda_out[2 * k] = lam[k].real(); lambda_out[2 * k + 1] = lam[k].imag(); }
+        for (auto *bf : {&PV, &Ub, &rb, &rhs, &u10, &wl, &tmp, &tmp2, &tmp3, &sc, &Gd, &pcd}) bf->release();
+        li.seconds = now_s() - t0;
+        const int rc_ = info_code(li);
+        if (info) *info = li;
+        return rc_;
     });
 }
 

@@ -166,5 +166,7 @@ void launch_inter_to_colmajor(const cplx *Xi, int nb, int64_t d, int r, cplx *Xc
 void launch_replicate(const cplx *Vc, int64_t d, int l, cplx *Xi, int nb, hipStream_t s);
 // Beyn accumulation: A[(p*l+c)*d + row] += sum_s w[s] z[s]^p X[row][s*l+c], s < nsys, p < npow
 void launch_beyn_accum(const cplx *Xi, int nb, int64_t d, int l, int nsys, const cplx *w, const cplx *z, int npow, cplx *A, hipStream_t s);
+// X[row][t] = sum_i G[i][t] V_i[row], V_i = V + i*stride (single vectors), X interleaved with leading dimension T
+void launch_gemv_multi(const cplx *V, size_t stride, int k, const cplx *G, cplx *X, int64_t d, int T, hipStream_t s);
 // triad for bandwidth measurement
 void launch_triad(double *a, const double *b, const double *c, double s_, int64_t n, hipStream_t s);

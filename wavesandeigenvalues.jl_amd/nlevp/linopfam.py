@@ -187,6 +187,21 @@ class DeviceFamily:
         self.last_code = code
         return H, V
 
+    def perturb(self, coeff_table, N, v0, v0adj, norm_mode=1, coeffsY=None, tol=1e-12, maxit=400):
+        """wae_perturb: the whole recurrence on the device. coeff_table[(m,n)] = T coefficients of L(m,n)."""
+        ct = np.ascontiguousarray(coeff_table, dtype=np.complex128).reshape((N + 1) * (N + 1), self.T)
+        v0 = np.ascontiguousarray(v0, dtype=np.complex128)
+        va = np.ascontiguousarray(v0adj, dtype=np.complex128)
+        lam = np.zeros(N + 1, dtype=np.complex128)
+        V = np.zeros((self.d, N + 1), dtype=np.complex128, order="F")
+        cy = None if coeffsY is None else np.ascontiguousarray(coeffsY, dtype=np.complex128)
+        info = SolveInfo()
+        code = check(_lib.lib().wae_perturb(self.handle, zptr(ct), N, zptr(v0), zptr(va), norm_mode, None if cy is None else zptr(cy),
+                                            tol, maxit, zptr(lam), zptr(V), C.byref(info)))
+        self.last_info = info.as_dict()
+        self.last_code = code
+        return lam, V
+
     def bench_spmv(self, coeffs, r=1, reps=20):
         c = np.ascontiguousarray(coeffs, dtype=np.complex128)
         ms = C.c_double(0)

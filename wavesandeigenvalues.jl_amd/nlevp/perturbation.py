@@ -78,7 +78,25 @@ def multi_indices_at_order(k):
 
 
 def _recurrence(L, N, v0, v0Adj, normalize, Y=None, skip_last_solve=False):
-    """perturbation.jl:319-367 (normalize=False), :374-444 (normalize=True), :487-560 (Y given)."""
+    """perturbation.jl:319-367 (normalize=False), :374-444 (normalize=True), :487-560 (Y given): ONE device call
+    (``wae_perturb``).  The host only evaluates the (N+1)^2 x T scalar coefficient table f_t^{(m,n)} = L.coefficients(m,n);
+    partitions, the tall-skinny products V_k g_t, the fused multi-input SpMV, the N solves on the fixed hierarchy and
+    all normalisations run inside the library on HBM-resident vectors."""
+    fam = L.ensure_solver()
+    T = len(L.terms)
+    table = np.zeros((N + 1, N + 1, T), dtype=np.complex128)
+    for m in range(N + 1):
+        for n in range(N + 1 - m):
+            table[m, n] = L.coefficients(m, n)
+    mode = (2 if Y is not None else (1 if normalize else 0)) + (16 if skip_last_solve else 0)
+    lam, V = fam.perturb(table, N, v0, v0Adj, norm_mode=mode, coeffsY=None if Y is None else Y.coeffs,
+                         tol=L.solver_tol, maxit=L.solver_maxit)
+    return lam, [V[:, i].copy() for i in range(N + 1)]
+
+
+def _recurrence_host(L, N, v0, v0Adj, normalize, Y=None, skip_last_solve=False):
+    """The same recurrence orchestrated from the host over wae_spmv_sum_multi + wae_solve (kept as a cross-check of
+    the device implementation in the GPU tests; not used by the solvers)."""
     fam = L.ensure_solver()
     T = len(L.terms)
     v0 = np.array(v0, dtype=np.complex128)
