@@ -36,20 +36,21 @@ HBM_PEAK_GBS = 8000.0
 
 
 def residuals(L, Om, P):
-    """backward-error style residual of every eigenpair: ||L(ω)v|| / Σ_k |c_k| ||A_k v||  (device SpMVs)."""
-    out = []
+    """backward-error style residual of every eigenpair: ||L(ω)v|| / Σ_k |c_k| ||A_k v||  -- two device launches:
+    all numerators (one coefficient row per column) and all term products with a non-zero coefficient."""
     fam = L.device()
-    for w, v in zip(Om, P.T):
-        cz = L.coefficients(w)
-        num = np.linalg.norm(fam.spmv(cz, v))
-        den = 0.0
-        for k in range(len(cz)):
-            if cz[k] != 0:
-                e = np.zeros_like(cz)
-                e[k] = cz[k]
-                den += np.linalg.norm(fam.spmv(e, v))
-        out.append(num / max(den, 1e-300))
-    return np.array(out)
+    n, T = len(Om), len(L.terms)
+    C = np.array([L.coefficients(w) for w in Om])                       # n x T
+    num = np.linalg.norm(fam.spmv(C, P), axis=0)
+    ks = [k for k in range(T) if np.any(C[:, k] != 0)]
+    Ck = np.zeros((n * len(ks), T), dtype=np.complex128)
+    X = np.empty((P.shape[0], n * len(ks)), dtype=np.complex128, order="F")
+    for j in range(n):
+        for i, k in enumerate(ks):
+            Ck[j * len(ks) + i, k] = C[j, k]
+            X[:, j * len(ks) + i] = P[:, j]
+    den = np.linalg.norm(fam.spmv(Ck, X), axis=0).reshape(n, len(ks)).sum(axis=1)
+    return num / np.maximum(den, 1e-300)
 
 
 def cpu_baseline(preset, l, N, n_in):
@@ -98,14 +99,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    backend = os.environ.get("WAE_BENCH_BACKEND", "nccl")      # "gloo" only to rehearse N>1 on a one-GPU box
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     import wae_amd  # noqa: F401
     from wae_amd.helmholtz.family import annulus_family
     from wae_amd.nlevp import compute_moment_matrices, gauss_points, initialize_V, moments2eigs, pos_test
-    from wae_amd.nlevp.distributed import allreduce_sum_, shard_points
+    from wae_amd.nlevp.distributed import allreduce_sum_, moments2eigs_device, shard_points
+    from wae_amd.nlevp.beyn import inpoly
 
     t0 = time.time()
     L, pb = annulus_family(args.preset, device=local, n=args.n, tau=args.tau)
@@ -124,17 +131,29 @@ def main():
     K = 1
     buf = torch.zeros(d * args.l * 2 * K * 2, dtype=torch.float64, device=f"cuda:{local}")
 
+    tim = {}
+
     def step():
+        t = [time.time()]
         compute_moment_matrices(L, G, V, K=K, N=args.N, points=(zr, wr), out_dev=buf.data_ptr())
+        t.append(time.time())
         info = dict(fam.last_info)
         allreduce_sum_(buf)                              # sum of the partial moment tensors (RCCL over xGMI)
+        torch.cuda.synchronize()
+        t.append(time.time())
         res = None
         if rank == 0:
-            A = buf.cpu().numpy().view(np.complex128).reshape((d, args.l, 2 * K), order="F")
-            Om, P, S = moments2eigs(A, return_sigma=True)
-            Om, P = pos_test(Om, P, G)
+            t.append(time.time())
+            Om, Pd, S = moments2eigs_device(buf, (d, args.l, 2 * K))       # SVD on the GPU, small eig on the host
+            mask = np.array([inpoly(w, G) for w in Om], dtype=bool)         # pos_test (beyn.jl:104-107)
+            Om = Om[mask]
+            P = np.asfortranarray(Pd[:, torch.from_numpy(mask).to(Pd.device)].cpu().numpy())
+            t.append(time.time())
             r = residuals(L, Om, P) if len(Om) else np.zeros(0)
+            t.append(time.time())
             res = (Om, r, S)
+            for name, a, b in (("moments", 0, 1), ("allreduce", 1, 2), ("d2h", 2, 3), ("svd_eig", 3, 4), ("residuals", 4, 5)):
+                tim[name] = t[b] - t[a]
         return info, res
 
     def sync():
@@ -188,6 +207,7 @@ def main():
             "eig_residual_max": float(r[good].max()) if n_eig else None, "n_inside_before_residual_test": int(len(Om)),
             "singular_values": [float(s) for s in S],
             "solver": {**info, "setup_seconds": t_setup},
+            "step_breakdown_seconds": {k: round(v, 4) for k, v in tim.items()},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

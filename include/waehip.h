@@ -76,6 +76,10 @@ int64_t wae_family_spmv_bytes(const wae_family *h, const uint8_t *mask, int32_t 
  *   X, Y    d x r column-major complex, host memory.
  */
 int wae_spmv_sum(wae_family *h, const double *coeffs, const double *X, double *Y, int32_t r, int32_t op);
+/* one coefficient set per column (ncoef = r): Y[:,j] = sum_k c_jk op(A_k) X[:,j] -- e.g. the residuals L(w_j) v_j of
+ * all Beyn eigenpairs in one launch; ncoef = 1 is wae_spmv_sum. */
+int wae_spmv_sum_cols(wae_family *h, const double *coeffs, int32_t ncoef, const double *X, double *Y, int32_t r,
+                      int32_t op);
 /* per-term inputs: Y = sum_k c_k A_k X_k, X = d x T column-major (regrouped perturbation recurrence,
  * SURVEY appendix C; replaces the sum over (m,n) of `L(m,n)*w` at perturbation.jl:394-415). */
 int wae_spmv_sum_multi(wae_family *h, const double *coeffs, const double *X, double *Y);

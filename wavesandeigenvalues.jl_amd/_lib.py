@@ -35,7 +35,7 @@ _lib = None
 # every symbol include/waehip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "wae_last_error", "wae_device_count", "wae_version", "wae_family_create", "wae_family_destroy",
-    "wae_family_info", "wae_family_spmv_bytes", "wae_spmv_sum", "wae_spmv_sum_multi", "wae_solver_setup",
+    "wae_family_info", "wae_family_spmv_bytes", "wae_spmv_sum", "wae_spmv_sum_cols", "wae_spmv_sum_multi", "wae_solver_setup",
     "wae_solve", "wae_solve_guess", "wae_beyn_moments", "wae_arnoldi_shiftinvert", "wae_perturb", "wae_bench_spmv", "wae_bench_triad",
 ]
 
@@ -61,6 +61,7 @@ def lib():
     L.wae_family_spmv_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32]
     L.wae_family_spmv_bytes.restype = C.c_int64
     L.wae_spmv_sum.argtypes = [C.c_void_p, dp, dp, dp, C.c_int32, C.c_int32]
+    L.wae_spmv_sum_cols.argtypes = [C.c_void_p, dp, C.c_int32, dp, dp, C.c_int32, C.c_int32]
     L.wae_spmv_sum_multi.argtypes = [C.c_void_p, dp, dp, dp]
     L.wae_solver_setup.argtypes = [C.c_void_p, dp, dp, C.c_int32]
     L.wae_solve.argtypes = [C.c_void_p, dp, C.c_int32, dp, dp, C.c_int32, C.c_int32, C.c_double, C.c_int32,

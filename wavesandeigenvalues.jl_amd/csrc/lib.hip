@@ -653,9 +653,10 @@ int64_t wae_family_spmv_bytes(const wae_family *h, const uint8_t *mask, int32_t 
 
 static void ensure(DevBuf<cplx> &b, size_t n) { if (b.n < n) b.alloc(n); }
 
-int wae_spmv_sum(wae_family *h, const double *coeffs, const double *X, double *Y, int32_t r, int32_t op) {
+int wae_spmv_sum_cols(wae_family *h, const double *coeffs, int32_t ncoef, const double *X, double *Y, int32_t r, int32_t op) {
     return guarded([&]() {
         WAE_REQUIRE(h && coeffs && X && Y && r > 0, "bad argument");
+        WAE_REQUIRE(ncoef == 1 || ncoef == r, "ncoef must be 1 or r");
         WAE_REQUIRE(op >= 0 && op <= 2, "bad op");
         HIP_CHECK(hipSetDevice(h->device));
         hipStream_t st = h->stream;
@@ -663,21 +664,27 @@ int wae_spmv_sum(wae_family *h, const double *coeffs, const double *X, double *Y
         ensure(h->io_a, cnt); ensure(h->io_b, cnt);
         DevBuf<cplx> xi, yi;
         xi.alloc(cnt); yi.alloc(cnt);
+        std::vector<cplx> tab((size_t)ncoef * h->nplanes);
         std::vector<zc> pc;
-        plane_coeffs(h, coeffs, op, pc);
-        std::vector<cplx> tab(h->nplanes);
-        for (int q = 0; q < h->nplanes; ++q) { const zc c = pc[h->slot_plane[0][q]]; tab[q] = cplx{c.real(), c.imag()}; }
+        for (int s = 0; s < ncoef; ++s) {
+            plane_coeffs(h, coeffs + (size_t)s * 2 * h->T, op, pc);
+            for (int q = 0; q < h->nplanes; ++q) { const zc c = pc[h->slot_plane[0][q]]; tab[(size_t)s * h->nplanes + q] = cplx{c.real(), c.imag()}; }
+        }
         DevBuf<cplx> pcd;
         pcd.upload(tab.data(), tab.size(), st);
         HIP_CHECK(hipMemcpyAsync(h->io_a.p, X, cnt * sizeof(cplx), hipMemcpyHostToDevice, st));
         launch_colmajor_to_inter(h->io_a.p, h->d, r, xi.p, r, st);
-        launch_spmv(h->ops[0].dev(op), pcd.p, 1 << 30, xi.p, yi.p, nullptr, 0.0, r, MODE_AX, st);
+        launch_spmv(h->ops[0].dev(op), pcd.p, ncoef == 1 ? (1 << 30) : 1, xi.p, yi.p, nullptr, 0.0, r, MODE_AX, st);
         launch_inter_to_colmajor(yi.p, r, h->d, r, h->io_b.p, st);
         HIP_CHECK(hipMemcpyAsync(Y, h->io_b.p, cnt * sizeof(cplx), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         xi.release(); yi.release(); pcd.release();
         return WAE_OK;
     });
+}
+
+int wae_spmv_sum(wae_family *h, const double *coeffs, const double *X, double *Y, int32_t r, int32_t op) {
+    return wae_spmv_sum_cols(h, coeffs, 1, X, Y, r, op);
 }
 
 int wae_spmv_sum_multi(wae_family *h, const double *coeffs, const double *X, double *Y) {

@@ -89,7 +89,14 @@ def moments2eigs(A_list, tol_sigma=0.0, return_sigma=False):
                 c0 = ll * dl + l * j
                 B0[d * i:d * (i + 1), c0:c0 + dl] = A[:, :, i + j]
                 B1[d * i:d * (i + 1), c0:c0 + dl] = A[:, :, i + j + 1]
-    U, S, Wh = np.linalg.svd(B0, full_matrices=False)
+    if B0.shape[0] > 8 * B0.shape[1]:
+        # tall-skinny: thin QR first, SVD of the small triangular factor (same factorisation up to rounding,
+        # a few times cheaper than LAPACK's SVD of the d x l matrix)
+        Q, R = np.linalg.qr(B0)
+        Ur, S, Wh = np.linalg.svd(R)
+        U = Q @ Ur
+    else:
+        U, S, Wh = np.linalg.svd(B0, full_matrices=False)
     W = Wh.conj().T
     if tol_sigma > 0:
         mask = S > tol_sigma

@@ -69,3 +69,23 @@ def beyn_distributed(L, G, l=5, K=1, N=16, V=None, pos_test_=True):
     if pos_test_:
         Om, P = pos_test(Om, P, G)
     return Om, P, S
+
+
+def moments2eigs_device(buf, shape, tol_sigma=0.0):
+    """`moments2eigs` (beyn.jl:289-323) with the tall-skinny part kept on the GPU (torch.linalg.svd on the moment
+    buffer that the all-reduce already left in HBM); only the (lK x lK) eigenproblem runs on the host.
+    buf: flat float64 CUDA tensor holding the column-major d x l x 2K complex moments.  Returns (Ω, P_device, Σ)."""
+    import torch
+    d, l, K2 = shape
+    K = K2 // 2
+    A = torch.view_as_complex(buf.view(-1, 2)).view(K2, l, d).permute(2, 1, 0)       # (d, l, 2K) strided view
+    B0 = torch.cat([torch.cat([A[:, :, i + j] for j in range(K)], dim=1) for i in range(K)], dim=0)
+    B1 = torch.cat([torch.cat([A[:, :, i + j + 1] for j in range(K)], dim=1) for i in range(K)], dim=0)
+    U, S, Wh = torch.linalg.svd(B0, full_matrices=False)
+    if tol_sigma > 0:
+        m = S > tol_sigma
+        U, S, Wh = U[:, m], S[m], Wh[m, :]
+    small = (U.conj().T @ B1 @ Wh.conj().T) / S.to(U.dtype)
+    Om, Pt = np.linalg.eig(small.cpu().numpy())
+    P = U[:d, :] @ torch.from_numpy(Pt).to(U.device)
+    return Om, P, S.cpu().numpy()

@@ -112,7 +112,11 @@ class DeviceFamily:
         one = X.ndim == 1
         Xf = np.asfortranarray(X.reshape(self.d, -1))
         Y = np.empty_like(Xf, order="F")
-        check(_lib.lib().wae_spmv_sum(self.handle, zptr(c), zptr(Xf), zptr(Y), Xf.shape[1], op))
+        if c.ndim == 2:          # one coefficient row per column
+            assert c.shape == (Xf.shape[1], self.T)
+            check(_lib.lib().wae_spmv_sum_cols(self.handle, zptr(c), c.shape[0], zptr(Xf), zptr(Y), Xf.shape[1], op))
+        else:
+            check(_lib.lib().wae_spmv_sum(self.handle, zptr(c), zptr(Xf), zptr(Y), Xf.shape[1], op))
         return Y[:, 0].copy() if one else Y
 
     def spmv_multi(self, coeffs, X):
