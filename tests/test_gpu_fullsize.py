@@ -1,0 +1,94 @@
+"""GPU tests at BASELINE.json's full single-GPU size (configs[1], d = 199 680) through size-independent properties:
+the oracle's direct factorisation needs ~10 minutes and 9 GB per quadrature point there, so parity at this size is
+checked by identities that hold for the exact operator (linearity, adjoint identity, solve round trip, additivity of
+sharded moments, eigenpair residuals and Newton refinement of the Beyn estimates).  Unpinned by any reference output
+(the annulus is synthetic)."""
+import numpy as np
+import pytest
+
+from wae_amd.helmholtz.family import annulus_family
+from wae_amd.nlevp import compute_moment_matrices, gauss_points, householder, moments2eigs, pos_test
+
+pytestmark = pytest.mark.gpu
+RNG = np.random.default_rng(3)
+GAMMA = np.array([150 - 150j, 1000 - 150j, 1000 + 150j, 150 + 150j]) * 2 * np.pi
+
+
+@pytest.fixture(scope="module")
+def c2():
+    L, pb = annulus_family("C2", tau=2e-4)
+    L.solver_tol = 1e-10
+    L.solver_ref = 2 * np.pi * 500.0
+    L.solver_opts = {"batch": 64, "restart": 40, "sweeps": 1}
+    yield L, pb
+    L._drop_device()
+
+
+def _rand(d, r):
+    return RNG.standard_normal((d, r)) + 1j * RNG.standard_normal((d, r))
+
+
+def test_spmv_linearity_and_adjoint_identity(c2):
+    L, pb = c2
+    d = pb["d"]
+    z = 2 * np.pi * (620 + 35j)
+    A = L(z)
+    X, Y = _rand(d, 8), _rand(d, 8)
+    a, b = 0.7 - 0.2j, -1.3 + 0.4j
+    lhs = A @ (a * X + b * Y)
+    rhs = a * (A @ X) + b * (A @ Y)
+    assert np.max(np.abs(lhs - rhs)) <= 1e-12 * np.max(np.abs(rhs))
+    # <y, A x> == <A^H y, x>  column by column
+    AX, AHY = A @ X, A.H @ Y
+    l1 = np.einsum("ij,ij->j", Y.conj(), AX)
+    l2 = np.einsum("ij,ij->j", AHY.conj(), X)
+    assert np.max(np.abs(l1 - l2)) <= 1e-12 * np.max(np.abs(l1))
+    # derivative operator: L(z,1) = 2 z M + Y C - i tau n e^{-i z tau} Q   (finite-difference check, relative 1e-6)
+    h = 1e-3
+    fd = (L(z + h) @ X[:, 0] - L(z - h) @ X[:, 0]) / (2 * h)
+    an = L(z, 1) @ X[:, 0]
+    assert np.linalg.norm(fd - an) <= 1e-6 * np.linalg.norm(an)
+
+
+def test_solve_round_trip_full_batch(c2):
+    """64 systems in lock-step, every column its own z on the contour: A(z_j) x_j = b_j, then check the residual
+    with the independent SpMV path, in the same error-like (Jacobi-scaled) sense the solver uses."""
+    L, pb = c2
+    d = pb["d"]
+    fam = L.ensure_solver()
+    zs, _ = gauss_points(GAMMA, 16)
+    B = _rand(d, 64)
+    ct = np.array([L.coefficients(z) for z in zs])
+    X = fam.solve(ct, B, tol=1e-10, maxit=300)
+    assert fam.last_info["n_unconverged"] == 0 and fam.last_info["relres_max"] <= 1e-10
+    R = B - fam.spmv(ct, X)
+    # scale rows by the operator diagonal magnitude (interior ~ |K_ii|, admittance rows ~ 1e15): error-like measure
+    T = pb["terms"]
+    for j in (0, 17, 40, 63):
+        z = zs[j]
+        dg = z * z * T["M"].diagonal() + T["K"].diagonal() + z * 1e15 * T["C"].diagonal()
+        assert np.linalg.norm(R[:, j] / dg) <= 1e-8 * np.linalg.norm(B[:, j] / dg)
+
+
+def test_moments_are_additive_over_shards_and_eigenpairs_verify(c2):
+    L, pb = c2
+    d = pb["d"]
+    V = np.random.default_rng(7).standard_normal((d, 16)) + 0j
+    zs, ws = gauss_points(GAMMA, 32)
+    A_full = compute_moment_matrices(L, GAMMA, V, K=1, N=32)
+    parts = [compute_moment_matrices(L, GAMMA, V, K=1, N=32, points=(zs[r::4], ws[r::4])) for r in range(4)]
+    assert np.max(np.abs(sum(parts) - A_full)) <= 1e-9 * np.max(np.abs(A_full))
+    Om, P, S = moments2eigs(A_full, return_sigma=True)
+    Om, P = pos_test(Om, P, GAMMA)
+    assert S[7] / S[8] > 1e6                            # 8 eigenvalues inside: clean rank gap after the 8th singular value
+    fam = L.device()
+    C = np.array([L.coefficients(w) for w in Om])
+    num = np.linalg.norm(fam.spmv(C, np.asfortranarray(P)), axis=0)
+    scale = np.linalg.norm(fam.spmv(np.array([L.coefficients(w * 1.05) for w in Om]), np.asfortranarray(P)), axis=0)
+    good = num <= 1e-5 * scale                          # the other l-8 Ritz values are quadrature noise (the reference keeps
+    assert good.sum() == 8                              # them too unless tol>0, beyn.jl:92-95): the residual test removes them
+    Om, P = Om[good], P[:, good]
+    # Newton refinement from the Beyn estimate lands on the same eigenvalue (Beyn accuracy ~1e-8 relative)
+    k = int(np.argmin(np.abs(Om - 2 * np.pi * 737)))
+    sol, n, flag = householder(L, Om[k], maxiter=6, tol=1e-6, v0=P[:, k])
+    assert abs(sol.params["ω"] - Om[k]) <= 1e-6 * abs(Om[k]) and n <= 3

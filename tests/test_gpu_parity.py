@@ -280,3 +280,28 @@ def test_perturb_device_call_all_modes():
         Lp.active = ["ω"]; Lp.mode = "all"
     assert np.allclose(l1[1:], l2[1:], rtol=1e-7)
     Lp._drop_device()
+
+
+def test_beyn_annulus_small_vs_oracle_golden():
+    """The bench configuration at 8 736 DoF (4 terms incl. the non-symmetric flame term, 12 flames, complex probe
+    matrix) against the oracle's direct-solver Beyn result committed in tests/golden/annulus_small_beyn.json."""
+    import json
+    import os
+    g = json.load(open(os.path.join(F.GOLDEN_DIR, "annulus_small_beyn.json")))
+    from wae_amd.helmholtz.family import annulus_family
+    L, pb = annulus_family("small", n=g["n"], tau=g["tau"])
+    assert pb["d"] == g["d"]
+    L.solver_tol = 1e-12
+    L.solver_ref = 2 * np.pi * 500.0
+    Gam = np.array([150 - 150j, 1000 - 150j, 1000 + 150j, 150 + 150j]) * 2 * np.pi
+    rng = np.random.default_rng(g["seed_V"])
+    V = rng.standard_normal((pb["d"], g["l"])) + 1j * rng.standard_normal((pb["d"], g["l"]))
+    A = compute_moment_matrices(L, Gam, V, K=1, N=g["N"])
+    assert L.device().last_info["n_unconverged"] == 0
+    Om, P, S = moments2eigs(A, return_sigma=True)
+    want = np.array([c(e) for e in g["eigs"]])
+    for w in want:
+        assert np.min(np.abs(Om - w)) < 1e-8 * abs(w)
+    ns = len(want)
+    assert np.allclose(S[:ns], g["sigma"][:ns], rtol=1e-7) and S[ns] < 1e-8 * S[0]
+    L._drop_device()
