@@ -187,9 +187,15 @@ def main():
         abytes = fam.spmv_bytes(r=rb, mask=mask)
         ms1 = fam.bench_spmv(cz, r=1, reps=50)
         ms8 = fam.bench_spmv(cz, r=8, reps=50)
-        roof = {"bound": "hbm", "kernel": "spmv_kernel<8,1> (fused multi-term complex CSR SpMV, r columns per launch)",
+        traffic = None       # HBM bytes per launch from the PMC passes committed under profiles/ (not collectable in-run)
+        tfile = os.path.join(ROOT, "profiles", "r01_spmv_traffic.json")
+        if os.path.exists(tfile):
+            tj = json.load(open(tfile))
+            if tj.get("preset") == args.preset and tj.get("r") == rb:
+                traffic = tj["traffic_bytes"]
+        roof = {"bound": "hbm", "kernel": "spmv_lds_kernel<4> (fused multi-term complex CSR SpMV, r columns per launch)",
                 "achieved": abytes / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": abytes / ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                "frac": abytes / ms / 1e6 / HBM_PEAK_GBS, "traffic": traffic,
                 "r": rb, "us_per_launch": ms * 1e3, "algorithmic_bytes": int(abytes),
                 "r1": {"us": ms1 * 1e3, "GB/s": fam.spmv_bytes(r=1, mask=mask) / ms1 / 1e6},
                 "r8": {"us": ms8 * 1e3, "GB/s": fam.spmv_bytes(r=8, mask=mask) / ms8 / 1e6}}
