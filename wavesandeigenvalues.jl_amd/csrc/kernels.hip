@@ -35,7 +35,9 @@ __device__ __forceinline__ cplx cdiv(cplx a, cplx b) {
 template <int C, int S>
 __global__ __launch_bounds__(256) void spmv_kernel(OpDev op, const cplx *__restrict__ pc, int cps,
                                                    const cplx *__restrict__ X, cplx *Y,
-                                                   const cplx *B, double jac_w, int nb, int mode) {
+                                                   const cplx *B, double jac_w, int nb, int mode,
+                                                   const unsigned char *__restrict__ cmask) {
+    if (C == 8 && cmask && !cmask[blockIdx.y]) return;      // whole 8-column chunk converged (uniform per workgroup)
     constexpr int TEAM = C * S;
     constexpr int TPB = 256 / TEAM;
     extern __shared__ cplx spc[];   // [C][nplanes_total]
@@ -175,10 +177,19 @@ constexpr int LDS_NNZ = 1024;     // nonzeros staged per chunk (4 KB of indices)
 template <int NCH>
 __global__ __launch_bounds__(256) void spmv_lds_kernel(OpDev op, const cplx *__restrict__ pc, int cps,
                                                        const cplx *__restrict__ X, cplx *Y, const cplx *B, double jac_w,
-                                                       int nb, int mode) {
+                                                       int nb, int mode, const unsigned char *__restrict__ cmask) {
     constexpr int C = 8;
     constexpr int TPB = 256 / C;            // rows per workgroup
     constexpr int CW = C * NCH;             // columns per workgroup
+    if (cmask) {                            // skip the workgroup if all of its column chunks have converged (uniform)
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = blockIdx.y * NCH + k;
+            if (ch * C < nb && cmask[ch]) any = true;
+        }
+        if (!any) return;
+    }
     extern __shared__ cplx spc[];           // [CW][nplanes_total]
     __shared__ __attribute__((aligned(16))) double lds_w[LDS_WORDS];
     __shared__ int lds_c[LDS_NNZ];
@@ -202,8 +213,8 @@ __global__ __launch_bounds__(256) void spmv_lds_kernel(OpDev op, const cplx *__r
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const int b = col0 + k * C + c;
-        act[k] = b < nb;
-        bcol[k] = act[k] ? b : nb - 1;
+        act[k] = b < nb && (!cmask || cmask[blockIdx.y * NCH + k]);
+        bcol[k] = b < nb ? b : nb - 1;
     }
     cplx acc[NCH];
 #pragma unroll
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(256) void spmv_lds_kernel(OpDev op, const cplx *__r
 #pragma unroll
                         for (int u = 0; u < U; ++u)
 #pragma unroll
-                            for (int k = 0; k < NCH; ++k) x[u][k] = X[(size_t)j[u] * nb + bcol[k]];
+                            for (int k = 0; k < NCH; ++k) x[u][k] = act[k] ? X[(size_t)j[u] * nb + bcol[k]] : cplx{0.0, 0.0};
 #pragma unroll
                         for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(256) void spmv_lds_kernel(OpDev op, const cplx *__r
                                     cfma(m, gpc[q], a);
                                 }
                             }
-                            cfma(acc[k], m, X[(size_t)j * nb + bcol[k]]);
+                            if (act[k]) cfma(acc[k], m, X[(size_t)j * nb + bcol[k]]);
                         }
                     }
                 }
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(256) void spmv_lds_kernel(OpDev op, const cplx *__r
     }
 }
 
-typedef void (*spmv_fn)(OpDev, const cplx *, int, const cplx *, cplx *, const cplx *, double, int, int);
+typedef void (*spmv_fn)(OpDev, const cplx *, int, const cplx *, cplx *, const cplx *, double, int, int, const unsigned char *);
 template <int C, int S> static spmv_fn spmv_ptr() { return spmv_kernel<C, S>; }
 
 static spmv_fn pick_spmv(int C, int S) {
@@ -343,7 +354,7 @@ static int env_int(const char *name, int dflt) {
 }
 
 void launch_spmv(const OpDev &op, const cplx *pc, int cps, const cplx *X, cplx *Y, const cplx *B, double jac_w,
-                 int nb, int mode, hipStream_t st) {
+                 int nb, int mode, hipStream_t st, const unsigned char *cmask) {
     const int envC = env_int("WAE_SPMV_C", 0), envS = env_int("WAE_SPMV_S", 0);   // tuning overrides
     int C = nb >= 8 ? 8 : (nb >= 4 ? 4 : (nb >= 2 ? 2 : 1));
     int S = 64 / C >= 8 ? 8 : 64 / C;
@@ -361,10 +372,10 @@ void launch_spmv(const OpDev &op, const cplx *pc, int cps, const cplx *X, cplx *
         const unsigned nrb = (unsigned)((op.n + 31) / 32);
         dim3 grid((nrb + 7u) / 8u * 8u, (unsigned)((nb + 8 * NCH - 1) / (8 * NCH)));
         size_t shm = (size_t)8 * NCH * op.nplanes_total * sizeof(cplx);
-        if (NCH == 8) hipLaunchKernelGGL(spmv_lds_kernel<8>, grid, dim3(256), shm, st, op, pc, cps, X, Y, B, jac_w, nb, mode);
-        else if (NCH == 4) hipLaunchKernelGGL(spmv_lds_kernel<4>, grid, dim3(256), shm, st, op, pc, cps, X, Y, B, jac_w, nb, mode);
-        else if (NCH == 2) hipLaunchKernelGGL(spmv_lds_kernel<2>, grid, dim3(256), shm, st, op, pc, cps, X, Y, B, jac_w, nb, mode);
-        else hipLaunchKernelGGL(spmv_lds_kernel<1>, grid, dim3(256), shm, st, op, pc, cps, X, Y, B, jac_w, nb, mode);
+        if (NCH == 8) hipLaunchKernelGGL(spmv_lds_kernel<8>, grid, dim3(256), shm, st, op, pc, cps, X, Y, B, jac_w, nb, mode, cmask);
+        else if (NCH == 4) hipLaunchKernelGGL(spmv_lds_kernel<4>, grid, dim3(256), shm, st, op, pc, cps, X, Y, B, jac_w, nb, mode, cmask);
+        else if (NCH == 2) hipLaunchKernelGGL(spmv_lds_kernel<2>, grid, dim3(256), shm, st, op, pc, cps, X, Y, B, jac_w, nb, mode, cmask);
+        else hipLaunchKernelGGL(spmv_lds_kernel<1>, grid, dim3(256), shm, st, op, pc, cps, X, Y, B, jac_w, nb, mode, cmask);
         HIP_CHECK(hipGetLastError());
         return;
     }
@@ -374,17 +385,19 @@ void launch_spmv(const OpDev &op, const cplx *pc, int cps, const cplx *X, cplx *
     const unsigned nrb = (unsigned)((op.n + tpb - 1) / tpb);
     dim3 grid((nrb + 7u) / 8u * 8u, (unsigned)((nb + C - 1) / C));
     size_t shm = (size_t)C * op.nplanes_total * sizeof(cplx);
-    hipLaunchKernelGGL(fn, grid, dim3(256), shm, st, op, pc, cps, X, Y, B, jac_w, nb, mode);
+    hipLaunchKernelGGL(fn, grid, dim3(256), shm, st, op, pc, cps, X, Y, B, jac_w, nb, mode, C == 8 ? cmask : (const unsigned char *)nullptr);
     HIP_CHECK(hipGetLastError());
 }
 
 __global__ __launch_bounds__(256) void jacobi0_kernel(OpDev op, const cplx *__restrict__ pc, int cps,
-                                                      const cplx *__restrict__ B, cplx *__restrict__ X, double w, int nb) {
+                                                      const cplx *__restrict__ B, cplx *__restrict__ X, double w, int nb,
+                                                      const unsigned char *__restrict__ cmask) {
     const size_t total = (size_t)op.n * nb;
     const int npl = op.nplanes_total;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const size_t row = e / nb;
         const int b = (int)(e - row * nb);
+        if (cmask && !cmask[b >> 3]) continue;
         const cplx *mypc = pc + (size_t)(b / cps) * npl;
         cplx dg = {0.0, 0.0};
         const double dsg = op.conj_diag ? -1.0 : 1.0;
@@ -400,9 +413,9 @@ static inline unsigned grid_for(size_t total, unsigned cap = 4096) {
     return (unsigned)(g > cap ? cap : g);
 }
 
-void launch_jacobi0(const OpDev &op, const cplx *pc, int cps, const cplx *B, cplx *X, double w, int nb, hipStream_t st) {
+void launch_jacobi0(const OpDev &op, const cplx *pc, int cps, const cplx *B, cplx *X, double w, int nb, hipStream_t st, const unsigned char *cmask) {
     if (op.n <= 0) return;
-    hipLaunchKernelGGL(jacobi0_kernel, dim3(grid_for((size_t)op.n * nb)), dim3(256), 0, st, op, pc, cps, B, X, w, nb);
+    hipLaunchKernelGGL(jacobi0_kernel, dim3(grid_for((size_t)op.n * nb)), dim3(256), 0, st, op, pc, cps, B, X, w, nb, cmask);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -566,20 +579,21 @@ void launch_dense_invert(cplx *Ainv, int n, int nsys, int *status, hipStream_t s
 }
 
 __global__ __launch_bounds__(256) void dense_apply_kernel(const cplx *__restrict__ Ainv, int n, int cps, const cplx *__restrict__ X,
-                                                          cplx *__restrict__ Y, int nb) {
+                                                          cplx *__restrict__ Y, int nb, const unsigned char *__restrict__ cmask) {
     const size_t total = (size_t)n * nb;
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     const int i = (int)(e / nb), b = (int)(e - (size_t)i * nb);
+    if (cmask && !cmask[b >> 3]) return;
     const cplx *Arow = Ainv + ((size_t)(b / cps) * n + i) * n;
     cplx acc = {0.0, 0.0};
     for (int j = 0; j < n; ++j) cfma(acc, Arow[j], X[(size_t)j * nb + b]);
     Y[e] = acc;
 }
 
-void launch_dense_apply(const cplx *Ainv, int n, int cps, const cplx *X, cplx *Y, int nb, hipStream_t st) {
+void launch_dense_apply(const cplx *Ainv, int n, int cps, const cplx *X, cplx *Y, int nb, hipStream_t st, const unsigned char *cmask) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(dense_apply_kernel, dim3((unsigned)(((size_t)n * nb + 255) / 256)), dim3(256), 0, st, Ainv, n, cps, X, Y, nb);
+    hipLaunchKernelGGL(dense_apply_kernel, dim3((unsigned)(((size_t)n * nb + 255) / 256)), dim3(256), 0, st, Ainv, n, cps, X, Y, nb, cmask);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -615,12 +629,13 @@ void launch_add(const cplx *X, cplx *Y, size_t count, hipStream_t st) {
 constexpr int DOT_BLOCKS = 1024;
 template <int MAXV>
 __global__ __launch_bounds__(256) void dots_kernel(const cplx *__restrict__ V, size_t stride, int nv, const cplx *__restrict__ W,
-                                                   int64_t n, int nb, cplx *__restrict__ partial) {
+                                                   int64_t n, int nb, cplx *__restrict__ partial,
+                                                   const unsigned char *__restrict__ cmask) {
     __shared__ cplx sm[256];
     const int tid = threadIdx.x;
     const int R = 256 / nb;
     const int b = tid % nb, rl = tid / nb;
-    const bool live = rl < R;
+    const bool live = rl < R && (!cmask || cmask[b >> 3]);
     cplx acc[MAXV];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) acc[i] = cplx{0.0, 0.0};
@@ -669,16 +684,17 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const cplx *__rest
     }
 }
 
-static void dots_impl(const cplx *V, size_t stride, int nv, const cplx *W, int64_t n, int nb, cplx *partial, cplx *out, int do_sqrt, hipStream_t st) {
+static void dots_impl(const cplx *V, size_t stride, int nv, const cplx *W, int64_t n, int nb, cplx *partial, cplx *out, int do_sqrt, hipStream_t st,
+                      const unsigned char *cmask) {
     if (nb < 1 || nb > 256) throw WaeError(WAE_ERR_INVALID, "dots: nb must be in 1..256");
     int done = 0;
     while (done < nv) {
         int chunk = nv - done > 32 ? 32 : nv - done;
         const cplx *Vc = V + (size_t)done * stride;
         int nblk = DOT_BLOCKS;
-        if (chunk <= 8) hipLaunchKernelGGL(dots_kernel<8>, dim3(nblk), dim3(256), 0, st, Vc, stride, chunk, W, n, nb, partial);
-        else if (chunk <= 16) hipLaunchKernelGGL(dots_kernel<16>, dim3(nblk), dim3(256), 0, st, Vc, stride, chunk, W, n, nb, partial);
-        else hipLaunchKernelGGL(dots_kernel<32>, dim3(nblk), dim3(256), 0, st, Vc, stride, chunk, W, n, nb, partial);
+        if (chunk <= 8) hipLaunchKernelGGL(dots_kernel<8>, dim3(nblk), dim3(256), 0, st, Vc, stride, chunk, W, n, nb, partial, cmask);
+        else if (chunk <= 16) hipLaunchKernelGGL(dots_kernel<16>, dim3(nblk), dim3(256), 0, st, Vc, stride, chunk, W, n, nb, partial, cmask);
+        else hipLaunchKernelGGL(dots_kernel<32>, dim3(nblk), dim3(256), 0, st, Vc, stride, chunk, W, n, nb, partial, cmask);
         HIP_CHECK(hipGetLastError());
         int count = chunk * nb;
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((count + 31) / 32), dim3(256), 0, st, partial, nblk, count, out + (size_t)done * nb, do_sqrt);
@@ -686,17 +702,20 @@ static void dots_impl(const cplx *V, size_t stride, int nv, const cplx *W, int64
         done += chunk;
     }
 }
-void launch_dots(const cplx *V, size_t stride, int nv, const cplx *W, int64_t n, int nb, cplx *partial, cplx *out, hipStream_t st) {
-    dots_impl(V, stride, nv, W, n, nb, partial, out, 0, st);
+void launch_dots(const cplx *V, size_t stride, int nv, const cplx *W, int64_t n, int nb, cplx *partial, cplx *out, hipStream_t st,
+                 const unsigned char *cmask) {
+    dots_impl(V, stride, nv, W, n, nb, partial, out, 0, st, cmask);
 }
-void launch_norms(const cplx *X, int64_t n, int nb, cplx *partial, cplx *out, hipStream_t st) {
-    dots_impl(X, 0, 1, X, n, nb, partial, out, 1, st);
+void launch_norms(const cplx *X, int64_t n, int nb, cplx *partial, cplx *out, hipStream_t st, const unsigned char *cmask) {
+    dots_impl(X, 0, 1, X, n, nb, partial, out, 1, st, cmask);
 }
 
 __global__ __launch_bounds__(256) void axpy_neg_kernel(const cplx *__restrict__ V, size_t stride, int nv, const cplx *__restrict__ h,
-                                                       cplx *W, size_t total, int nb, double sign, const cplx *base) {
+                                                       cplx *W, size_t total, int nb, double sign, const cplx *base,
+                                                       const unsigned char *__restrict__ cmask) {
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const int b = (int)(e % nb);
+        if (cmask && !cmask[b >> 3]) continue;
         cplx acc = base ? base[e] : cplx{0.0, 0.0};
         for (int i = 0; i < nv; ++i) {
             const cplx c = h[(size_t)i * nb + b];
@@ -707,31 +726,33 @@ __global__ __launch_bounds__(256) void axpy_neg_kernel(const cplx *__restrict__ 
         W[e] = acc;
     }
 }
-void launch_axpy_neg(const cplx *V, size_t stride, int nv, const cplx *h, cplx *W, int64_t n, int nb, hipStream_t st) {
+void launch_axpy_neg(const cplx *V, size_t stride, int nv, const cplx *h, cplx *W, int64_t n, int nb, hipStream_t st, const unsigned char *cmask) {
     size_t total = (size_t)n * nb;
     if (!total) return;
-    hipLaunchKernelGGL(axpy_neg_kernel, dim3(grid_for(total)), dim3(256), 0, st, V, stride, nv, h, W, total, nb, -1.0, (const cplx *)W);
+    hipLaunchKernelGGL(axpy_neg_kernel, dim3(grid_for(total)), dim3(256), 0, st, V, stride, nv, h, W, total, nb, -1.0, (const cplx *)W, cmask);
     HIP_CHECK(hipGetLastError());
 }
 void launch_lincomb(const cplx *V, size_t stride, int nv, const cplx *y, cplx *Y, int64_t n, int nb, hipStream_t st) {
     size_t total = (size_t)n * nb;
     if (!total) return;
-    hipLaunchKernelGGL(axpy_neg_kernel, dim3(grid_for(total)), dim3(256), 0, st, V, stride, nv, y, Y, total, nb, 1.0, (const cplx *)nullptr);
+    hipLaunchKernelGGL(axpy_neg_kernel, dim3(grid_for(total)), dim3(256), 0, st, V, stride, nv, y, Y, total, nb, 1.0, (const cplx *)nullptr, (const unsigned char *)nullptr);
     HIP_CHECK(hipGetLastError());
 }
 
-__global__ __launch_bounds__(256) void scale_inv_kernel(const cplx *__restrict__ X, const cplx *__restrict__ alpha, cplx *__restrict__ Y, size_t total, int nb) {
+__global__ __launch_bounds__(256) void scale_inv_kernel(const cplx *__restrict__ X, const cplx *__restrict__ alpha, cplx *__restrict__ Y, size_t total, int nb,
+                                                        const unsigned char *__restrict__ cmask) {
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        if (cmask && !cmask[(e % nb) >> 3]) continue;
         const double a = alpha[e % nb].x;
         const double s = (a > 1e-300) ? 1.0 / a : 0.0;
         const cplx x = X[e];
         Y[e] = cplx{x.x * s, x.y * s};
     }
 }
-void launch_scale_inv(const cplx *X, const cplx *alpha, cplx *Y, int64_t n, int nb, hipStream_t st) {
+void launch_scale_inv(const cplx *X, const cplx *alpha, cplx *Y, int64_t n, int nb, hipStream_t st, const unsigned char *cmask) {
     size_t total = (size_t)n * nb;
     if (!total) return;
-    hipLaunchKernelGGL(scale_inv_kernel, dim3(grid_for(total)), dim3(256), 0, st, X, alpha, Y, total, nb);
+    hipLaunchKernelGGL(scale_inv_kernel, dim3(grid_for(total)), dim3(256), 0, st, X, alpha, Y, total, nb, cmask);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -77,12 +77,14 @@ struct wae_family {
     std::vector<DevBuf<cplx>> lx, lb, lt;
     DevBuf<cplx> V, W, Z, Xs, Bs, U, partial, hdev, ydev, pcdev, one_dev, io_a, io_b, zw_dev;
     DevBuf<int> plane_col_dev;
+    DevBuf<unsigned char> cmask;     // one byte per 8-column chunk of the current batch (0 = converged)
     cplx *h_pinned = nullptr;        // (restart+2)*NB
     size_t pc_stride_level = 0;      // elements per level in pcdev
     ~wae_family() {
         for (auto *b : {&dense_planes, &Ainv, &V, &W, &Z, &Xs, &Bs, &U, &partial, &hdev, &ydev, &pcdev, &one_dev, &io_a, &io_b, &zw_dev}) b->release();
         dstatus.release();
         plane_col_dev.release();
+        cmask.release();
         for (auto &b : lx) b.release();
         for (auto &b : lb) b.release();
         for (auto &b : lt) b.release();
@@ -288,29 +290,29 @@ static void dense_setup(wae_family *h, const Batch &bt) {
 }
 
 // x = Minv b on level l;  returns pointer to the result (either lx[l] or lt[l])
-static cplx *vcycle(wae_family *h, const Batch &bt, int l, const cplx *b) {
+static cplx *vcycle(wae_family *h, const Batch &bt, int l, const cplx *b, const unsigned char *cm = nullptr) {
     const int L = (int)h->ops.size() - 1;
     hipStream_t st = h->stream;
     if (l == L) {
-        launch_dense_apply(h->Ainv.p, (int)h->nc, bt.cps, b, h->lx[l].p, bt.nb, st);
+        launch_dense_apply(h->Ainv.p, (int)h->nc, bt.cps, b, h->lx[l].p, bt.nb, st, cm);
         return h->lx[l].p;
     }
     const OpDev A = h->ops[l].dev(bt.op);
     const cplx *pc = pc_level(h, l);
     cplx *x = h->lx[l].p, *t = h->lt[l].p;
-    launch_jacobi0(A, pc, bt.cps, b, x, h->jac_w, bt.nb, st);
+    launch_jacobi0(A, pc, bt.cps, b, x, h->jac_w, bt.nb, st, cm);
     for (int s = 1; s < h->nsweeps; ++s) {
-        launch_spmv(A, pc, bt.cps, x, t, b, h->jac_w, bt.nb, MODE_JAC, st);
+        launch_spmv(A, pc, bt.cps, x, t, b, h->jac_w, bt.nb, MODE_JAC, st, cm);
         std::swap(x, t);
     }
     // residual -> t, restrict -> lb[l+1]
-    launch_spmv(A, pc, bt.cps, x, t, b, 0.0, bt.nb, MODE_RES, st);
+    launch_spmv(A, pc, bt.cps, x, t, b, 0.0, bt.nb, MODE_RES, st, cm);
     // for op = T/C the transfer operators are unchanged (real): (R A P)^H = R A^H P
-    launch_spmv(h->xfer[l].devR(), h->one_dev.p, 1 << 30, t, h->lb[l + 1].p, nullptr, 0.0, bt.nb, MODE_AX, st);
-    const cplx *xc = vcycle(h, bt, l + 1, h->lb[l + 1].p);
-    launch_spmv(h->xfer[l].devP(), h->one_dev.p, 1 << 30, xc, x, x, 0.0, bt.nb, MODE_ADD, st);
+    launch_spmv(h->xfer[l].devR(), h->one_dev.p, 1 << 30, t, h->lb[l + 1].p, nullptr, 0.0, bt.nb, MODE_AX, st, cm);
+    const cplx *xc = vcycle(h, bt, l + 1, h->lb[l + 1].p, cm);
+    launch_spmv(h->xfer[l].devP(), h->one_dev.p, 1 << 30, xc, x, x, 0.0, bt.nb, MODE_ADD, st, cm);
     for (int s = 0; s < h->nsweeps; ++s) {
-        launch_spmv(A, pc, bt.cps, x, t, b, h->jac_w, bt.nb, MODE_JAC, st);
+        launch_spmv(A, pc, bt.cps, x, t, b, h->jac_w, bt.nb, MODE_JAC, st, cm);
         std::swap(x, t);
     }
     return x;
@@ -363,6 +365,21 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
     int total_it = 0;
     bool first = true;
     bool nan_seen = false;
+    // converged-chunk mask: columns are skipped in groups of 8 (one 128-B segment of every interleaved row) as soon as
+    // all 8 have converged -- the columns of one shifted system converge together, so this removes most of the work the
+    // lock-step batch would otherwise spend on finished systems
+    const int nch = (nb + 7) / 8;
+    static const bool use_mask = !(getenv("WAE_NO_MASK") && atoi(getenv("WAE_NO_MASK")));
+    std::vector<unsigned char> cm(nch, 1), cm_prev(nch, 2);
+    if (h->cmask.n < (size_t)nch) h->cmask.alloc(nch);
+    auto push_mask = [&]() {
+        if (cm != cm_prev) {
+            HIP_CHECK(hipMemcpyAsync(h->cmask.p, cm.data(), nch, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            cm_prev = cm;
+        }
+    };
+    const unsigned char *mk = nullptr;
     if (guess_dir) {
         // initial guess x0 = alpha * g, alpha = (M^-1 A g)^H (M^-1 b) / ||M^-1 A g||^2 per column: when the solution is
         // dominated by a known direction (inverse iteration close to an eigenvalue) the Krylov solve only has to
@@ -407,6 +424,12 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
         }
         if (all_done || total_it >= maxit || nan_seen) break;
         launch_scale_inv(z0, h->hdev.p, h->V.p, n, nb, st);     // V0 = M^-1 r / beta
+        if (use_mask && nb >= 8) {
+            for (int k = 0; k < nch; ++k) cm[k] = 0;
+            for (int b = 0; b < nb; ++b) if (!done[b]) cm[b >> 3] = 1;
+            push_mask();
+            mk = h->cmask.p;
+        }
         for (int b = 0; b < nb; ++b) {
             ColState &c = cs[b];
             c.H.assign((size_t)(m + 1) * m, zc(0));
@@ -420,18 +443,18 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
         int j = 0;
         for (; j < m && total_it < maxit; ++j) {
             const cplx *vj = h->V.p + (size_t)j * vec;
-            launch_spmv(A, pc, bt.cps, vj, h->W.p, nullptr, 0.0, nb, MODE_AX, st);
-            cplx *w = vcycle(h, bt, 0, h->W.p);                  // w = M^-1 A v_j  (lives in a V-cycle buffer)
-            launch_dots(h->V.p, vec, j + 1, w, n, nb, h->partial.p, h->hdev.p, st);
-            launch_axpy_neg(h->V.p, vec, j + 1, h->hdev.p, w, n, nb, st);
+            launch_spmv(A, pc, bt.cps, vj, h->W.p, nullptr, 0.0, nb, MODE_AX, st, mk);
+            cplx *w = vcycle(h, bt, 0, h->W.p, mk);              // w = M^-1 A v_j  (lives in a V-cycle buffer)
+            launch_dots(h->V.p, vec, j + 1, w, n, nb, h->partial.p, h->hdev.p, st, mk);
+            launch_axpy_neg(h->V.p, vec, j + 1, h->hdev.p, w, n, nb, st, mk);
             if (reorth) {   // CGS2: h += V^H w', w' -= V (V^H w')
                 cplx *h2 = h->hdev.p + (size_t)(m + 2) * nb;
-                launch_dots(h->V.p, vec, j + 1, w, n, nb, h->partial.p, h2, st);
-                launch_axpy_neg(h->V.p, vec, j + 1, h2, w, n, nb, st);
+                launch_dots(h->V.p, vec, j + 1, w, n, nb, h->partial.p, h2, st, mk);
+                launch_axpy_neg(h->V.p, vec, j + 1, h2, w, n, nb, st, mk);
                 launch_add(h2, h->hdev.p, (size_t)(j + 1) * nb, st);
             }
-            launch_norms(w, n, nb, h->partial.p, h->hdev.p + (size_t)(j + 1) * nb, st);
-            launch_scale_inv(w, h->hdev.p + (size_t)(j + 1) * nb, h->V.p + (size_t)(j + 1) * vec, n, nb, st);
+            launch_norms(w, n, nb, h->partial.p, h->hdev.p + (size_t)(j + 1) * nb, st, mk);
+            launch_scale_inv(w, h->hdev.p + (size_t)(j + 1) * nb, h->V.p + (size_t)(j + 1) * vec, n, nb, st, mk);
             HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, (size_t)(j + 2) * nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
             ++total_it;
@@ -467,7 +490,13 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
                 else all_conv = false;
             }
             if (all_conv || nan_seen) { ++j; break; }
+            if (mk) {
+                for (int k = 0; k < nch; ++k) cm[k] = 0;
+                for (int b = 0; b < nb; ++b) if (!cs[b].conv) cm[b >> 3] = 1;
+                push_mask();
+            }
         }
+        mk = nullptr;
         // y = R^{-1} g per column, zero-padded to j steps;  x += V y
         const int ju = std::min(j, m);
         std::vector<cplx> y((size_t)std::max(ju, 1) * nb, cplx{0.0, 0.0});
@@ -805,6 +834,17 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
         const size_t vec = (size_t)h->d * NB;
         h->V.alloc(vec * (m + 1));
         h->W.alloc(vec); h->Xs.alloc(vec); h->Bs.alloc(vec); h->U.alloc(vec);
+        // masked (converged) columns keep stale data: make sure "stale" is never an uninitialised NaN pattern
+        HIP_CHECK(hipMemsetAsync(h->V.p, 0, vec * (m + 1) * sizeof(cplx), st));
+        HIP_CHECK(hipMemsetAsync(h->W.p, 0, vec * sizeof(cplx), st));
+        HIP_CHECK(hipMemsetAsync(h->U.p, 0, vec * sizeof(cplx), st));
+        for (int l = 0; l < nl; ++l) {
+            const size_t cnt = (size_t)h->ops[l].n * NB;
+            HIP_CHECK(hipMemsetAsync(h->lx[l].p, 0, cnt * sizeof(cplx), st));
+            HIP_CHECK(hipMemsetAsync(h->lb[l].p, 0, cnt * sizeof(cplx), st));
+            HIP_CHECK(hipMemsetAsync(h->lt[l].p, 0, cnt * sizeof(cplx), st));
+        }
+        HIP_CHECK(hipStreamSynchronize(st));
         h->partial.alloc((size_t)1024 * 32 * NB);   // DOT_BLOCKS x 32 vectors x NB columns
         h->hdev.alloc((size_t)2 * (m + 3) * NB);     // second half: scratch for the re-orthogonalisation pass
         h->ydev.alloc((size_t)(m + 1) * NB);

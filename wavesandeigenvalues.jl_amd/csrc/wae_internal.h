@@ -131,10 +131,12 @@ enum { MODE_AX = 0, MODE_RES = 1, MODE_JAC = 2, MODE_ADD = 3, MODE_AX_DS = 4, MO
 //   MODE_AX : Y = A X            MODE_RES: Y = B - A X
 //   MODE_JAC: Y = X + w/diag (B - A X)   (diag from op.diag and pc)      MODE_ADD: Y = B + A X
 //   MODE_AX_DS: Y = (A X)/diag          MODE_RES_DS: Y = (B - A X)/diag   (row-scaled operator / residual)
+// cmask (optional): one byte per 8-column chunk, 0 = chunk converged -> its columns are skipped (outputs untouched)
 void launch_spmv(const OpDev &op, const cplx *pc, int cps, const cplx *X, cplx *Y, const cplx *B, double jac_w,
-                 int nb, int mode, hipStream_t s);
+                 int nb, int mode, hipStream_t s, const unsigned char *cmask = nullptr);
 // X = w/diag * B  (first Jacobi sweep from a zero initial guess)
-void launch_jacobi0(const OpDev &op, const cplx *pc, int cps, const cplx *B, cplx *X, double jac_w, int nb, hipStream_t s);
+void launch_jacobi0(const OpDev &op, const cplx *pc, int cps, const cplx *B, cplx *X, double jac_w, int nb, hipStream_t s,
+                    const unsigned char *cmask = nullptr);
 // multi-input variant: Y[:,0] = sum_q pc[q] plane_q X[:, term_of_plane(q)]  (X interleaved with leading dim nb)
 void launch_spmv_multi(const OpDev &op, const cplx *pc, const int *plane_col, const cplx *X, cplx *Y, int nb, hipStream_t s);
 
@@ -142,21 +144,23 @@ void launch_spmv_multi(const OpDev &op, const cplx *pc, const int *plane_col, co
 void launch_dense_assemble(const cplx *planes, int nplanes, int n, const cplx *pc, int nsys, int op,
                            cplx *Ainv, hipStream_t s);
 void launch_dense_invert(cplx *Ainv, int n, int nsys, int *status, hipStream_t s);
-void launch_dense_apply(const cplx *Ainv, int n, int cps, const cplx *X, cplx *Y, int nb, hipStream_t s);
+void launch_dense_apply(const cplx *Ainv, int n, int cps, const cplx *X, cplx *Y, int nb, hipStream_t s, const unsigned char *cmask = nullptr);
 
 // vector kernels on interleaved multivectors [n][nb]
 void launch_fill_zero(cplx *X, size_t count, hipStream_t s);
 void launch_copy(const cplx *X, cplx *Y, size_t count, hipStream_t s);
 // partial dots: out[i][b] = sum_rows conj(V_i[row][b]) * W[row][b], i = 0..nv-1; V_i = V + i*stride
-void launch_dots(const cplx *V, size_t stride, int nv, const cplx *W, int64_t n, int nb, cplx *partial, cplx *out, hipStream_t s);
+void launch_dots(const cplx *V, size_t stride, int nv, const cplx *W, int64_t n, int nb, cplx *partial, cplx *out, hipStream_t s,
+                 const unsigned char *cmask = nullptr);
 // W -= sum_i h[i][b] V_i
-void launch_axpy_neg(const cplx *V, size_t stride, int nv, const cplx *h, cplx *W, int64_t n, int nb, hipStream_t s);
+void launch_axpy_neg(const cplx *V, size_t stride, int nv, const cplx *h, cplx *W, int64_t n, int nb, hipStream_t s,
+                     const unsigned char *cmask = nullptr);
 // Y = sum_i y[i][b] V_i
 void launch_lincomb(const cplx *V, size_t stride, int nv, const cplx *y, cplx *Y, int64_t n, int nb, hipStream_t s);
 // norms: out[b] = ||X[:,b]||_2  (real part of out[b], imag 0)
-void launch_norms(const cplx *X, int64_t n, int nb, cplx *partial, cplx *out, hipStream_t s);
+void launch_norms(const cplx *X, int64_t n, int nb, cplx *partial, cplx *out, hipStream_t s, const unsigned char *cmask = nullptr);
 // Y[:,b] = X[:,b] * (1/alpha[b].x)  (0 if alpha tiny)
-void launch_scale_inv(const cplx *X, const cplx *alpha, cplx *Y, int64_t n, int nb, hipStream_t s);
+void launch_scale_inv(const cplx *X, const cplx *alpha, cplx *Y, int64_t n, int nb, hipStream_t s, const unsigned char *cmask = nullptr);
 // Y += X
 void launch_add(const cplx *X, cplx *Y, size_t count, hipStream_t s);
 // layout changes: column-major d x r  <->  interleaved [d][nb] (columns >= r zero-filled / ignored)
