@@ -305,3 +305,43 @@ def test_beyn_annulus_small_vs_oracle_golden():
     ns = len(want)
     assert np.allclose(S[:ns], g["sigma"][:ns], rtol=1e-7) and S[ns] < 1e-8 * S[0]
     L._drop_device()
+
+
+def _qep1():
+    g = G["G8"]
+    T = LinearOperatorFamily()
+    T.push(Term(np.array(g["A2"], dtype=complex), (pow2,), (("λ",),), "λ^2", "A2"))
+    T.push(Term(np.array(g["A1"], dtype=complex), (pow1,), (("λ",),), "λ", "A1"))
+    T.push(Term(np.array(g["A0"], dtype=complex), (), (), "", "A0"))
+    return T
+
+
+def test_G8_small_dense_solvers():
+    """qep1 (tutorial_00): mslp from 0 -> 1/3, pole/zero count = 5, trace iteration, all on the device path
+    (d = 3: the 'multigrid' degenerates to the dense coarse solve)."""
+    from wae_amd.nlevp import count_poles_and_zeros, traceiter
+    g = G["G8"]
+    T = _qep1()
+    Gam = [2 + 2j, -2 + 2j, -2 - 2j, 2 - 2j]
+    n = count_poles_and_zeros(T, Gam)
+    assert abs(n - g["count_poles_and_zeros"]) < 1e-2
+    sol, it, flag = mslp(T, 0, tol=1e-10)
+    assert abs(sol.params["λ"] - c(g["mslp_from_0_tol1e-10"]["omega"])) < 1e-9 and flag == 0
+    assert abs(it - g["mslp_from_0_tol1e-10"]["iterations"]) <= 2
+    T2 = _qep1()
+    sol, it, flag = traceiter(T2, 0.4 + 0.1j, maxiter=30, tol=1e-10)
+    assert flag == 0 and min(abs(sol.params["λ"] - c(e)) for e in g["eigs_inside"]) < 1e-8
+    T._drop_device(); T2._drop_device()
+
+
+def test_solve_driver_rijke():
+    """solve(L, Γ): incremental Beyn + deflation + local refinement (solver.jl:36-184 intent) finds the two passive
+    Rijke modes (272.06 Hz, 694.97 Hz) with machine-precise local refinement."""
+    from wae_amd.nlevp import solve
+    Lp = helmholtz_family(F.rijke_terms(), n=0.0)
+    Lp.solver_ref = 2 * np.pi * 500
+    Gam = np.array([150 + 50j, 150 - 50j, 1000 - 50j, 1000 + 50j]) * 2 * np.pi
+    eig = solve(Lp, Gam, dl=3, N=32, tol=1e-9, maxcycles=2)
+    inside = sorted(w.real / 2 / np.pi for w, v in eig.items() if v[1])
+    assert len(inside) == 2 and abs(inside[0] - 272.0643) < 1e-3 and abs(inside[1] - 694.9677) < 1e-3
+    Lp._drop_device()

@@ -1128,8 +1128,8 @@ int wae_perturb(wae_family *h, const double *coeff_table, int32_t N, const doubl
             }
             const zc denom = dot(wl.p, u10.p);
             plane_coeffs(h, c00.data(), WAE_OP_N, pcs[0]);
-            upload_pc(h, pcs);
-            dense_setup(h, bt);
+            bool l00_ready = false;      // set up lazily: order-1 Newton steps (skip_last) never solve with L(0,0), which is
+                                         // exactly singular for small dense families (the reference would throw there)
             // plane passes for the multi-input SpMV (coefficient 1 per term: the weights live in G)
             std::vector<std::vector<int>> plane_terms(h->nplanes);
             for (int k = 0; k < T; ++k) plane_terms[h->term_plane[k]].push_back(k);
@@ -1188,6 +1188,7 @@ int wae_perturb(wae_family *h, const double *coeff_table, int32_t N, const doubl
                 if (skip_last && k == N) break;
                 axpby(-1.0, rb.p, -lam[k], u10.p, rhs.p);                             // rhs = -(r + lam_k L10 v0)
                 cplx *vk = PV.p + (size_t)k * d;
+                if (!l00_ready) { upload_pc(h, pcs); dense_setup(h, bt); l00_ready = true; }
                 gmres(h, bt, rhs.p, vk, tol, maxit, &li);
                 const zc pr = ipY(V0, vk);
                 axpby(1.0, vk, -pr, V0, vk);                                          // v_k -= (v0' [Y] v_k) v0
