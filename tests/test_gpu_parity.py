@@ -345,3 +345,51 @@ def test_solve_driver_rijke():
     inside = sorted(w.real / 2 / np.pi for w, v in eig.items() if v[1])
     assert len(inside) == 2 and abs(inside[0] - 272.0643) < 1e-3 and abs(inside[1] - 694.9677) < 1e-3
     Lp._drop_device()
+
+
+def test_many_terms_mixed_patterns_bloch_like():
+    """A Bloch-like family (Helmholtz.jl:507-512 pushes 3-6 sub-operators per matrix with phase factors
+    exp(+-i b 2pi/N)): 11 terms, several sparsity patterns, complex-valued planes, non-symmetric parts; SpMV (N/T/C),
+    batched solve and Beyn moments against the oracle's assembled matrices."""
+    from oracle import nlevp as ON
+    from wae_amd.nlevp import exp_pm
+    t = F.rijke_terms()
+    d = t["M"].shape[0]
+    rows = np.arange(d)
+    def part(A, k, m):          # rows with index % m == k
+        D = sp.diags((rows % m == k).astype(float))
+        return sp.csr_matrix(D @ A)
+    pieces = [("M", part(t["M"], 0, 3), 1.0), ("M", part(t["M"], 1, 3), 1.0), ("M", part(t["M"], 2, 3), 1.0),
+              ("K", part(t["K"], 0, 2) * (0.6 + 0.8j), 0.6 - 0.8j), ("K", part(t["K"], 1, 2), 1.0)]
+    fplus, fminus = exp_pm(+1), exp_pm(-1)
+    oplus, ominus = ON.exp_pm(+1), ON.exp_pm(-1)
+    Lp = LinearOperatorFamily(["ω", "λ"], [0.0, complex(np.inf, 0)])
+    Lo = ON.LinearOperatorFamily(["ω", "λ"], [0.0, complex(np.inf, 0)])
+    for L, p2, p1, T_, fp, fm in ((Lp, pow2, pow1, Term, fplus, fminus), (Lo, ON.pow2, ON.pow1, ON.Term, oplus, ominus)):
+        L.params["φ"] = 2 * np.pi / 12; L.params["Y"] = 1e15
+        conv = (lambda A: sp.csc_matrix(A)) if L is Lo else (lambda A: A)
+        for i, (nm, A, sc) in enumerate(pieces):    # push! merges equal (func, params) signatures: one symbol per term
+            if nm == "M":   # ω² · e^{±i b φ} · M_i
+                L.params[f"b{i}"] = 2.0
+                L.push(T_(conv(A * sc), (p2, fp if i % 2 == 0 else fm), (("ω",), (f"b{i}", "φ")), f"ω^2*ph{i}", f"M{i}"))
+            else:           # complex-scaled stiffness pieces with a constant coefficient
+                L.params[f"s{i}"] = 1.0
+                L.push(T_(conv(A * sc), (p1,), ((f"s{i}",),), f"s{i}", f"K{i}"))
+        L.push(T_(conv(t["C"]), (p1, p1), (("ω",), ("Y",)), "ω*Y", "C"))
+        L.params["sq"] = 1.0; L.params["st"] = 1.0
+        L.push(T_(conv(t["Q"]), (p1,), (("sq",),), "sq", "Q"))
+        L.push(T_(conv(t["Q"].T.tocsr() * 0.5j), (p1,), (("st",),), "st", "Qt"))
+        L.push(T_(conv(-t["M"]), (p1,), (("λ",),), "-λ", "__aux__"))
+    assert len(Lp.terms) == len(Lo.terms) >= 9
+    x = RNG.standard_normal((d, 9)) + 1j * RNG.standard_normal((d, 9))
+    z = 2 * np.pi * (300 + 30j)
+    Ao, Ap = Lo(z), Lp(z)
+    assert relerr(Ap @ x, Ao @ x) < 1e-13
+    assert relerr(Ap.H @ x, Ao.conj().T @ x) < 1e-13
+    assert relerr(Lp(z, 1) @ x, Lo(z, 1) @ x) < 1e-13
+    Lp.solver_ref = 2 * np.pi * 400
+    X = Ap.solve(x, tol=1e-12)
+    assert relerr(X, OS._solve(Ao, x)) < 1e-7
+    Xh = Ap.H.solve(x, tol=1e-12)
+    assert relerr(Xh, OS._solve(sp.csc_matrix(Ao.conj().T), x)) < 1e-7
+    Lp._drop_device()

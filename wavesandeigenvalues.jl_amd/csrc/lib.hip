@@ -117,8 +117,8 @@ static std::vector<int> build_levelop(LevelOp &L, const std::vector<CsrZ> &plane
             if (g.real == re && csr_same_pattern(planes[g.members[0]], planes[q])) { g.members.push_back(q); placed = true; break; }
         if (!placed) grps.push_back(Grp{{q}, re});
     }
-    if ((int)grps.size() > WAE_MAXG) throw WaeError(WAE_ERR_INVALID, "too many distinct sparsity patterns (max 8)");
-    if ((int)planes.size() > WAE_MAXP) throw WaeError(WAE_ERR_INVALID, "too many distinct term matrices (max 32)");
+    if ((int)grps.size() > WAE_MAXG) throw WaeError(WAE_ERR_INVALID, "too many distinct sparsity patterns (max 24)");
+    if ((int)planes.size() > WAE_MAXP) throw WaeError(WAE_ERR_INVALID, "too many distinct term matrices (max 64)");
     std::vector<int> slot_plane;
     L.groups.clear();
     L.groups.resize(grps.size());

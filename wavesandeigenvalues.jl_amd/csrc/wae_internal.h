@@ -55,8 +55,8 @@ CsrZ galerkin(const CsrD &R, const CsrZ &A, const CsrD &P);   // R*A*P
 // ---------------------------------------------------------------------------------------------------
 // device-side operator description
 // ---------------------------------------------------------------------------------------------------
-constexpr int WAE_MAXG = 8;         // pattern groups per level operator
-constexpr int WAE_MAXP = 32;        // value planes in total per level operator
+constexpr int WAE_MAXG = 24;        // pattern groups per level operator
+constexpr int WAE_MAXP = 64;       // value planes in total per level operator
 
 struct GroupDev {                   // one sparsity pattern shared by `nplanes` value planes
     const int *rowptr;              // n+1
