@@ -202,7 +202,7 @@ def main():
         out = {
             "metric": "eigenpairs/sec", "value": n_eig * args.steps / dt, "unit": "eigenpairs/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "complex128 (f64)",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"annular combustor Helmholtz NLEVP (P1), preset {args.preset}: d={d}, "
                                    f"L(w)=w^2 M+K+w Y C+n exp(-i w tau) Q, Beyn l={args.l} K=1 N={args.N}/edge "

@@ -369,7 +369,9 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
     // all 8 have converged -- the columns of one shifted system converge together, so this removes most of the work the
     // lock-step batch would otherwise spend on finished systems
     const int nch = (nb + 7) / 8;
-    static const bool use_mask = !(getenv("WAE_NO_MASK") && atoi(getenv("WAE_NO_MASK")));
+    // opt-in (WAE_MASK=1): on the annulus all systems of a batch converge within a few iterations of each other and the
+    // predicates cost ~2 %; batches mixing easy and hard shifts gain from it
+    static const bool use_mask = getenv("WAE_MASK") && atoi(getenv("WAE_MASK"));
     std::vector<unsigned char> cm(nch, 1), cm_prev(nch, 2);
     if (h->cmask.n < (size_t)nch) h->cmask.alloc(nch);
     auto push_mask = [&]() {
