@@ -307,6 +307,32 @@ def pade(w, L, M):
     return a, b
 
 
+def pade_vector(sol, param, L, M):
+    """pade!(..., vector=true)  LinOpFam.jl:653-678"""
+    tkey = f"{param}/Taylor"
+    V = np.array(sol.v_pert[tkey][:L + M + 1])
+    d = V.shape[1]
+    A = np.zeros((L + 1, d), dtype=complex)
+    B = np.zeros((M + 1, d), dtype=complex)
+    for i in range(d):
+        A[:, i], B[:, i] = pade(V[:, i], L, M)
+    return A, B
+
+
+def estimate_pol(w):
+    """LinOpFam.jl:736-747"""
+    w = np.asarray(w, dtype=complex)
+    N = len(w)
+    de = np.zeros(N - 2, dtype=complex)
+    k = np.zeros(N - 2, dtype=complex)
+    for j in range(2, N):                 # Julia j = 2..N-1 (1-based)
+        i = j - 1
+        denom = (i + 1) * w[j] * w[j - 2] - i * w[j - 1] ** 2
+        de[i - 1] = w[j - 1] * w[j - 2] / denom
+        k[i - 1] = (i ** 2 - 1) * w[j] * w[j - 2] - (i * w[j - 1]) ** 2
+    return de, k
+
+
 def conv_radius(a):
     """LinOpFam.jl:754-761"""
     a = np.asarray(a)

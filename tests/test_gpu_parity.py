@@ -222,6 +222,13 @@ def test_G5_mslp_active_flame():
     assert flag in (0, 1, 2) and n <= 14
     first = next(i for i, zk in enumerate(sol.history) if abs(zk - w) < 1e-9 * abs(w))
     assert first <= G["G5"]["iterations"] - 1
+    # padesolve = the same iteration with householder's flags; order 2 exercises the in-loop perturbation solve
+    from wae_amd.nlevp import padesolve
+    Lp.params["τ"] = 0.001
+    sol3, n3, flag3 = padesolve(Lp, 340 * 2 * np.pi, maxiter=20, tol=1e-9, order=2, num_order=1)
+    assert flag3 in (0, 1) and abs(sol3.params["ω"] - w) < 1e-8 * abs(w) and n3 <= 8
+    sol4, n4, flag4 = householder(Lp, 340 * 2 * np.pi, maxiter=20, tol=1e-9, order=3)
+    assert flag4 in (0, 1) and abs(sol4.params["ω"] - w) < 1e-8 * abs(w) and n4 <= 6
     Lp._drop_device()
 
 

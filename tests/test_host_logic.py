@@ -78,3 +78,29 @@ def test_beyn_host_tail_and_contour():
     Om, P, S = moments2eigs(A, return_sigma=True)
     Oo, Po, So = OS.moments2eigs(A, return_sigma=True)
     assert np.allclose(np.sort_complex(Om), np.sort_complex(Oo)) and np.allclose(S, So)
+
+
+def test_pade_estimate_pol_and_vector_pade_match_oracle():
+    from wae_amd.nlevp import Solution, conv_radius, estimate_pol, pade, pade_
+    rng = np.random.default_rng(5)
+    w = rng.standard_normal(9) + 1j * rng.standard_normal(9)
+    for Lp, Mp in ((4, 4), (3, 2), (8, 0), (0, 3)):
+        a, b = pade(w, Lp, Mp)
+        ao, bo = ON.pade(w, Lp, Mp)
+        assert np.allclose(a, ao) and np.allclose(b, bo)
+    de, k = estimate_pol(w)
+    deo, ko = ON.estimate_pol(w)
+    assert np.allclose(de, deo) and np.allclose(k, ko)
+    assert np.allclose(conv_radius(w), ON.conv_radius(w))
+    # series of f(e) = 1/(1-2e) * v:  Pade [1/1] reproduces it exactly, component-wise
+    v = rng.standard_normal(5) + 0j
+    sol = Solution({"ω": 1.0 + 0j, "τ": 0.5 + 0j}, v, v, "ω")
+    sol.eigval_pert["τ/Taylor"] = np.array([2.0 ** n for n in range(5)], dtype=complex)
+    sol.v_pert["τ/Taylor"] = [v * 2.0 ** n for n in range(5)]
+    val, vec = sol("τ", 0.5 + 0.1, 1, 1, vector=True)
+    assert abs(val - 1 / (1 - 0.2)) < 1e-12 and np.allclose(vec, v / (1 - 0.2))
+    so = ON.Solution({"ω": 1.0 + 0j, "τ": 0.5 + 0j}, v, v, "ω")
+    so.v_pert["τ/Taylor"] = sol.v_pert["τ/Taylor"]
+    A, B = ON.pade_vector(so, "τ", 1, 1)
+    Ap, Bp = sol.v_pert["τ/[1/1]"]
+    assert np.allclose(A, Ap) and np.allclose(B, Bp)

@@ -60,13 +60,17 @@ class Solution:
         self.v_pert = {}
         self.auxval = auxval
 
-    def __call__(self, param, eps, L=0, M=0):
+    def __call__(self, param, eps, L=0, M=0, vector=False):
         key = f"{param}/[{L}/{M}]"
-        if key not in self.eigval_pert:
-            self.eigval_pert[key] = pade(self.eigval_pert[f"{param}/Taylor"], L, M)
+        if key not in self.eigval_pert or (vector and key not in self.v_pert):
+            pade_(self, param, L, M, vector=vector)
         a, b = self.eigval_pert[key]
         de = eps - self.params[param]
-        return polyval(a, de) / polyval(b, de)
+        eigval = polyval(a, de) / polyval(b, de)
+        if not vector:
+            return eigval
+        A, B = self.v_pert[key]                       # (L+1, d) and (M+1, d) coefficient arrays
+        return eigval, polyval(list(A), de) / polyval(list(B), de)
 
 
 class DeviceFamily:
@@ -406,6 +410,35 @@ def pade(w, L, M):
         for m in range(min(l, M) + 1):
             a[l] += w[l - m] * b[m]
     return a, b
+
+
+def pade_(sol, param, L, M, vector=False):
+    """pade!(sol, param, L, M; vector)  (LinOpFam.jl:646-680): Padé coefficients of the eigenvalue series and,
+    component-wise, of the eigenvector series."""
+    key, tkey = f"{param}/[{L}/{M}]", f"{param}/Taylor"
+    sol.eigval_pert[key] = pade(sol.eigval_pert[tkey], L, M)
+    if vector:
+        V = np.array(sol.v_pert[tkey][:L + M + 1])    # (L+M+1, d)
+        d = V.shape[1]
+        A = np.zeros((L + 1, d), dtype=complex)
+        B = np.zeros((M + 1, d), dtype=complex)
+        for i in range(d):
+            A[:, i], B[:, i] = pade(V[:, i], L, M)
+        sol.v_pert[key] = (A, B)
+
+
+def estimate_pol(w):
+    """estimate_pol (LinOpFam.jl:736-747): pole position / order estimates from consecutive Taylor coefficients."""
+    w = np.asarray(w, dtype=complex)
+    N = len(w)
+    de = np.zeros(N - 2, dtype=complex)
+    k = np.zeros(N - 2, dtype=complex)
+    for j in range(1, N - 1):
+        i = j                                           # 1-based j-1 in the reference
+        denom = (i + 1) * w[j + 1] * w[j - 1] - i * w[j] ** 2
+        de[i - 1] = w[j] * w[j - 1] / denom
+        k[i - 1] = (i * i - 1) * w[j + 1] * w[j - 1] - (i * w[j]) ** 2
+    return de, k
 
 
 def conv_radius(a):

@@ -290,6 +290,19 @@ def mslp(L, z, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, nev=1, v
     return sol, n, flag
 
 
+def padesolve(L, z, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, nev=1, v0=None, v0_adj=None, output=False,
+              num_order=1):
+    """sol, n, flag = padesolve(L, z; ...)   (Householder.jl:205-355): the MSLP/Padé iteration with `householder`'s
+    flag conventions (1 converged, 0 slow, -1 maxiter, ...), without the automatic aux term and without `scale`."""
+    if L.terms[-1].operator != "__aux__":
+        raise ValueError("padesolve needs a family whose last term is the __aux__ term (Householder.jl:225)")
+    sol, n, flag = mslp(L, z, maxiter=maxiter, tol=tol, relax=relax, lam_tol=lam_tol, order=order, nev=nev, v0=v0,
+                        v0_adj=v0_adj, num_order=num_order, scale=1.0, output=output)
+    return sol, n, {itsol_converged: 1, itsol_slow_convergence: 0, itsol_maxiter: -1, itsol_isnan: -5, itsol_impossible: -3,
+                    itsol_arpack_exception: -4, itsol_singular_exception: -6, itsol_unknown: -2,
+                    itsol_arpack_9999: -9999}.get(flag, -2)
+
+
 def _finish(n, maxiter, z, z0, tol, flag):
     """iterative_solvers.jl:326-342"""
     if flag != itsol_converged:
