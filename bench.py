@@ -187,6 +187,10 @@ def main():
         abytes = fam.spmv_bytes(r=rb, mask=mask)
         ms1 = fam.bench_spmv(cz, r=1, reps=50)
         ms8 = fam.bench_spmv(cz, r=8, reps=50)
+        import ctypes as _C
+        from wae_amd import _lib as _wl
+        tri = _C.c_double(0.0)                 # device triad a = b + s*c over 2^27 doubles: the streaming rate this GPU attains
+        _wl.check(_wl.lib().wae_bench_triad(int(os.environ.get("LOCAL_RANK", 0)), 1 << 27, 20, _C.byref(tri)))
         traffic = None       # HBM bytes per launch from the PMC passes committed under profiles/ (not collectable in-run)
         tfile = os.path.join(ROOT, "profiles", "r01_spmv_traffic.json")
         if os.path.exists(tfile):
@@ -197,6 +201,7 @@ def main():
                 "achieved": abytes / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": abytes / ms / 1e6 / HBM_PEAK_GBS, "traffic": traffic,
                 "r": rb, "us_per_launch": ms * 1e3, "algorithmic_bytes": int(abytes),
+                "triad_GBps": tri.value, "frac_of_triad": abytes / ms / 1e6 / tri.value if tri.value else None,
                 "r1": {"us": ms1 * 1e3, "GB/s": fam.spmv_bytes(r=1, mask=mask) / ms1 / 1e6},
                 "r8": {"us": ms8 * 1e3, "GB/s": fam.spmv_bytes(r=8, mask=mask) / ms8 / 1e6}}
         out = {

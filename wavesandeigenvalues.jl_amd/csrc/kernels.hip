@@ -691,7 +691,9 @@ static void dots_impl(const cplx *V, size_t stride, int nv, const cplx *W, int64
     while (done < nv) {
         int chunk = nv - done > 32 ? 32 : nv - done;
         const cplx *Vc = V + (size_t)done * stride;
-        int nblk = DOT_BLOCKS;
+        // one resident round only: dots_kernel<32> holds 3 waves/SIMD (768 workgroups on 256 CUs); a 1024-block grid ran a
+        // second, one-third-full round
+        const int nblk = chunk <= 16 ? DOT_BLOCKS : 768;
         if (chunk <= 8) hipLaunchKernelGGL(dots_kernel<8>, dim3(nblk), dim3(256), 0, st, Vc, stride, chunk, W, n, nb, partial, cmask);
         else if (chunk <= 16) hipLaunchKernelGGL(dots_kernel<16>, dim3(nblk), dim3(256), 0, st, Vc, stride, chunk, W, n, nb, partial, cmask);
         else hipLaunchKernelGGL(dots_kernel<32>, dim3(nblk), dim3(256), 0, st, Vc, stride, chunk, W, n, nb, partial, cmask);
@@ -710,33 +712,71 @@ void launch_norms(const cplx *X, int64_t n, int nb, cplx *partial, cplx *out, hi
     dots_impl(X, 0, 1, X, n, nb, partial, out, 1, st, cmask);
 }
 
+// W[row][b] = base[row][b] + sign * sum_i c[i][b] V_i[row][b].  The nv x nb coefficients are staged in LDS once per
+// workgroup (reading them per element through the vector cache doubled the L1 traffic of this streaming kernel), and
+// the basis vectors are fetched AXU at a time so that AXU 16-B loads are in flight per lane.
+// Thread t owns column t % nb and every R-th row, R = 256 / nb (as in dots_kernel).
+constexpr int AXU = 8;
+constexpr int AX_MAXC = 4096;      // coefficients per launch (64 KB of LDS)
 __global__ __launch_bounds__(256) void axpy_neg_kernel(const cplx *__restrict__ V, size_t stride, int nv, const cplx *__restrict__ h,
-                                                       cplx *W, size_t total, int nb, double sign, const cplx *base,
+                                                       cplx *W, int64_t n, int nb, double sign, const cplx *base,
                                                        const unsigned char *__restrict__ cmask) {
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const int b = (int)(e % nb);
-        if (cmask && !cmask[b >> 3]) continue;
+    extern __shared__ cplx hs[];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < nv * nb; k += 256) {
+        const cplx c = h[k];
+        hs[k] = cplx{sign * c.x, sign * c.y};
+    }
+    __syncthreads();
+    const int R = 256 / nb;
+    const int b = tid % nb, rl = tid / nb;
+    if (rl >= R || (cmask && !cmask[b >> 3])) return;
+    for (int64_t row = (int64_t)blockIdx.x * R + rl; row < n; row += (int64_t)gridDim.x * R) {
+        const size_t e = (size_t)row * nb + b;
         cplx acc = base ? base[e] : cplx{0.0, 0.0};
-        for (int i = 0; i < nv; ++i) {
-            const cplx c = h[(size_t)i * nb + b];
+        int i = 0;
+        for (; i + AXU <= nv; i += AXU) {
+            cplx v[AXU];
+#pragma unroll
+            for (int u = 0; u < AXU; ++u) v[u] = V[(size_t)(i + u) * stride + e];
+#pragma unroll
+            for (int u = 0; u < AXU; ++u) {
+                const cplx c = hs[(i + u) * nb + b];
+                acc.x += c.x * v[u].x - c.y * v[u].y;
+                acc.y += c.x * v[u].y + c.y * v[u].x;
+            }
+        }
+        for (; i < nv; ++i) {
+            const cplx c = hs[i * nb + b];
             const cplx v = V[(size_t)i * stride + e];
-            acc.x += sign * (c.x * v.x - c.y * v.y);
-            acc.y += sign * (c.x * v.y + c.y * v.x);
+            acc.x += c.x * v.x - c.y * v.y;
+            acc.y += c.x * v.y + c.y * v.x;
         }
         W[e] = acc;
     }
 }
+static void axpy_impl(const cplx *V, size_t stride, int nv, const cplx *c, cplx *W, int64_t n, int nb, double sign, const cplx *base,
+                      hipStream_t st, const unsigned char *cmask) {
+    if (!n || nb < 1) return;
+    if (nb > 256) throw WaeError(WAE_ERR_INVALID, "axpy: nb must be in 1..256");
+    const int R = 256 / nb;
+    const int64_t steps = (n + R - 1) / R;
+    const unsigned grid = (unsigned)std::min<int64_t>(steps, 2048);
+    const int maxv = std::max(1, AX_MAXC / nb);
+    int done = 0;
+    do {                                              // nv == 0 still writes W = base (or 0)
+        const int chunk = std::min(nv - done, maxv);
+        hipLaunchKernelGGL(axpy_neg_kernel, dim3(grid), dim3(256), (size_t)std::max(chunk, 1) * nb * sizeof(cplx), st,
+                           V + (size_t)done * stride, stride, chunk, c + (size_t)done * nb, W, n, nb, sign, done ? (const cplx *)W : base, cmask);
+        HIP_CHECK(hipGetLastError());
+        done += chunk;
+    } while (done < nv);
+}
 void launch_axpy_neg(const cplx *V, size_t stride, int nv, const cplx *h, cplx *W, int64_t n, int nb, hipStream_t st, const unsigned char *cmask) {
-    size_t total = (size_t)n * nb;
-    if (!total) return;
-    hipLaunchKernelGGL(axpy_neg_kernel, dim3(grid_for(total)), dim3(256), 0, st, V, stride, nv, h, W, total, nb, -1.0, (const cplx *)W, cmask);
-    HIP_CHECK(hipGetLastError());
+    axpy_impl(V, stride, nv, h, W, n, nb, -1.0, W, st, cmask);
 }
 void launch_lincomb(const cplx *V, size_t stride, int nv, const cplx *y, cplx *Y, int64_t n, int nb, hipStream_t st) {
-    size_t total = (size_t)n * nb;
-    if (!total) return;
-    hipLaunchKernelGGL(axpy_neg_kernel, dim3(grid_for(total)), dim3(256), 0, st, V, stride, nv, y, Y, total, nb, 1.0, (const cplx *)nullptr, (const unsigned char *)nullptr);
-    HIP_CHECK(hipGetLastError());
+    axpy_impl(V, stride, nv, y, Y, n, nb, 1.0, nullptr, st, nullptr);
 }
 
 __global__ __launch_bounds__(256) void scale_inv_kernel(const cplx *__restrict__ X, const cplx *__restrict__ alpha, cplx *__restrict__ Y, size_t total, int nb,
