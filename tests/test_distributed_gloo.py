@@ -80,3 +80,64 @@ def test_shard_covers_all_points_once():
     for world in (1, 2, 3, 8, 16):
         got = np.concatenate([shard_points(z, z, r, world)[0] for r in range(world)])
         assert sorted(got.real.astype(int).tolist()) == list(range(13))
+
+
+# ------------------------------------------------------------------------------------------------------
+# independent units: Bloch wave numbers / start values dealt to the ranks, one gather at the end
+# ------------------------------------------------------------------------------------------------------
+def _sweep_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import wae_amd  # noqa: F401
+    from oracle import bloch as OB
+    from oracle import fixtures as F
+    from oracle import solvers as OS
+    from wae_amd.helmholtz import annulus
+    from wae_amd.nlevp.distributed import bloch_sweep_distributed, refine_distributed
+
+    # (1) one start value per rank: Rijke tube, the CPU oracle's householder injected as the method
+    L = F.rijke_family(n=0.0)
+    starts = [2 * np.pi * 250.0, 2 * np.pi * 650.0, 2 * np.pi * 300.0]          # ragged: 2 + 1 over two ranks
+    tab, sols = refine_distributed(L, starts, method=OS.householder, maxiter=12, tol=1e-10)
+    assert sorted(sols) == list(range(rank, 3, world))
+    # (2) Bloch sweep on a small unit cell, mslp from shared start values
+    cell = annulus.build_unit_cell(grid=(4, 12, 4), DOS=12, tau=2e-4)
+    Lb = OB.bloch_family(cell["terms_ext"], cell["nsector"], 12, tau=2e-4, n=0.0)
+    bs = [0, 1, 2]
+    tab2, keep = bloch_sweep_distributed(Lb, bs, [2 * np.pi * 200.0], method=OS.mslp, maxiter=15, tol=1e-9)
+    if rank == 0:
+        q.put((tab, tab2))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sweeps_gather_results_of_all_ranks():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sweep_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    tab, tab2 = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # Rijke passive modes (tests/golden: the n=0 spectrum has its first two modes near 272 and 695 Hz)
+    f = tab[:, 0].real / 2 / np.pi
+    assert abs(f[0] - f[2]) < 1e-6 and 200 < f[0] < 350 and 600 < f[1] < 800
+    assert np.all(tab[:, 2].real == 1)                       # flag: converged
+    # single-process reference of the Bloch sweep
+    sys.path.insert(0, ROOT)
+    import wae_amd  # noqa: F401
+    from oracle import bloch as OB
+    from oracle import solvers as OS
+    from wae_amd.helmholtz import annulus
+    cell = annulus.build_unit_cell(grid=(4, 12, 4), DOS=12, tau=2e-4)
+    Lb = OB.bloch_family(cell["terms_ext"], cell["nsector"], 12, tau=2e-4, n=0.0)
+    for k, b in enumerate([0, 1, 2]):
+        Lb.params["b"] = complex(b)
+        sol, n, flag = OS.mslp(Lb, 2 * np.pi * 200.0, maxiter=15, tol=1e-9)
+        assert abs(tab2[k, 0] - sol.params["ω"]) <= 1e-9 * abs(tab2[k, 0]) and tab2[k, 2].real == flag
+    assert abs(tab2[1, 0] - tab2[0, 0]) > 1.0               # different wave numbers, different eigenvalues

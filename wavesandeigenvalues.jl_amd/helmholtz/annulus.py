@@ -31,6 +31,7 @@ PRESETS = {
     "C2": (160, 78, 16),        # 199 680 DoF (BASELINE.json configs[1])
     "C5": (224, 106, 21),       # 498 624 DoF (configs[4])
     "C3": (288, 128, 27),       # 995 328 DoF (configs[2])
+    "C4": (20, 200, 50),        # 200 000 DoF: ONE sector (unit cell) of a 32-fold symmetric ring (configs[3])
 }
 
 # the 6 Kuhn tetrahedra of the unit cube, as corner indices (bit0=θ, bit1=z, bit2=r)
@@ -45,17 +46,24 @@ for perm in ((0, 1, 2), (0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0)):
 _KUHN = np.array(_KUHN)
 
 
-def _mesh(nth, nz, nr):
-    th = np.arange(nth) * (2 * np.pi / nth)
+def _mesh(nth, nz, nr, sector_of=None):
+    """Full ring (θ periodic, nth planes) or, with sector_of=DOS, ONE sector of a DOS-fold symmetric ring: nth cells,
+    nth+1 planes, the last plane being the rotated image of the first (the unit cell of a Bloch computation)."""
+    if sector_of is None:
+        th = np.arange(nth) * (2 * np.pi / nth)
+        nplanes, ncells = nth, nth
+    else:
+        th = np.arange(nth + 1) * (2 * np.pi / sector_of / nth)
+        nplanes, ncells = nth + 1, nth
     z = np.linspace(0.0, HEIGHT, nz)
     r = np.linspace(R_IN, R_OUT, nr)
     TH, Z, RR = np.meshgrid(th, z, r, indexing="ij")
     pts = np.stack([RR * np.cos(TH), RR * np.sin(TH), Z], axis=-1).reshape(-1, 3)
 
     def nid(i, j, k):
-        return ((i % nth) * nz + j) * nr + k
+        return ((i % nplanes) * nz + j) * nr + k
 
-    I, J, K = np.meshgrid(np.arange(nth), np.arange(nz - 1), np.arange(nr - 1), indexing="ij")
+    I, J, K = np.meshgrid(np.arange(ncells), np.arange(nz - 1), np.arange(nr - 1), indexing="ij")
     I, J, K = I.ravel(), J.ravel(), K.ravel()
     corners = np.stack([nid(I + (c & 1), J + ((c >> 1) & 1), K + ((c >> 2) & 1)) for c in range(8)], axis=1)
     tets = corners[:, _KUHN].reshape(-1, 4)
@@ -69,10 +77,27 @@ def _coo_to_csr(I, J, V, d):
     return A
 
 
-def build(preset="C2", Y=1e15, n=1.0, tau=1e-3, grid=None):
-    """Return dict(d, terms={M,K,C,Q} scipy CSR complex128, params, points, info)."""
+def build(preset="C2", Y=1e15, n=1.0, tau=1e-3, grid=None, n_sector=N_SECTOR, ref_offset="cartesian"):
+    """Return dict(d, terms={M,K,C,Q} scipy CSR complex128, params, points, info).
+
+    ref_offset: how the flame reference points are nudged off the grid planes -- "cartesian" (+1e-7 in x, y, z; the
+    historical C2/C3 inputs) or "polar" (+1e-7 in θ, r, z: identical in every sector, which makes a grid with
+    nθ divisible by n_sector exactly n_sector-fold symmetric -- the comparator for the Bloch unit cell)."""
     nth, nz, nr = grid if grid is not None else PRESETS[preset]
-    pts, tets, (th, zc, rc) = _mesh(nth, nz, nr)
+    pts, tets, _ = _mesh(nth, nz, nr)
+    terms, info = _assemble(pts, tets, nz, n_sector, range(n_sector), ref_offset)
+    info["grid"] = (nth, nz, nr)
+    return {
+        "d": pts.shape[0],
+        "terms": terms,
+        "params": {"Y": complex(Y), "n": complex(n), "τ": complex(tau)},
+        "points": pts,
+        "info": info,
+    }
+
+
+def _assemble(pts, tets, nz, n_sector, flame_sectors, ref_offset):
+    """Element loops of discretize (src/Helmholtz.jl:405-525) for the fixed annulus description, vectorised."""
     d = pts.shape[0]
     X = pts[tets]                                            # (nt,4,3)
     Jm = np.transpose(X[:, :3, :] - X[:, 3:4, :], (0, 2, 1))  # columns x_a - x_4  (FEM.jl:9-20)
@@ -106,16 +131,16 @@ def build(preset="C2", Y=1e15, n=1.0, tau=1e-3, grid=None):
 
     # flames: Q = Σ_f S_f ⊗ g_f   (Helmholtz.jl:292-344,464-487; FEM.jl:2429-2448)
     gamma, rho, Tu, Tb, P0 = 1.4, 1.225, 300.0, 1200.0, 101325.0
-    A_f = np.pi * (R_OUT ** 2 - R_IN ** 2) / N_SECTOR
+    A_f = np.pi * (R_OUT ** 2 - R_IN ** 2) / n_sector
     Q02U0 = P0 * (Tb / Tu - 1) * A_f * gamma / (gamma - 1)
     ang = np.mod(np.arctan2(ctr[:, 1], ctr[:, 0]), 2 * np.pi)
-    sector = np.floor(ang / (2 * np.pi / N_SECTOR)).astype(int)
-    frac = ang / (2 * np.pi / N_SECTOR) - sector
+    sector = np.floor(ang / (2 * np.pi / n_sector)).astype(int)
+    frac = ang / (2 * np.pi / n_sector) - sector
     in_flame = (ctr[:, 2] > FLAME_Z0) & (ctr[:, 2] < FLAME_Z1) & (frac > 0.25) & (frac < 0.75)
     QI, QJ, QV = [], [], []
     n_ref = np.array([0.0, 0.0, 1.0])
     r_mid = 0.5 * (R_IN + R_OUT)
-    for f in range(N_SECTOR):
+    for f in flame_sectors:
         sel = np.nonzero(in_flame & (sector == f))[0]
         if len(sel) == 0:
             continue
@@ -123,8 +148,11 @@ def build(preset="C2", Y=1e15, n=1.0, tau=1e-3, grid=None):
         nlocal = (gamma - 1) / rho * Q02U0 / vol               # Helmholtz.jl:325
         S_nodes = tets[sel].ravel()
         S_vals = np.repeat(adet[sel] / 24.0, 4)                # FEM.jl:2429-2431
-        a0 = (f + 0.5) * 2 * np.pi / N_SECTOR
-        x_ref = np.array([r_mid * np.cos(a0), r_mid * np.sin(a0), REF_Z]) + 1e-7
+        a0 = (f + 0.5) * 2 * np.pi / n_sector
+        if ref_offset == "polar":
+            x_ref = np.array([(r_mid + 1e-7) * np.cos(a0 + 1e-7), (r_mid + 1e-7) * np.sin(a0 + 1e-7), REF_Z + 1e-7])
+        else:
+            x_ref = np.array([r_mid * np.cos(a0), r_mid * np.sin(a0), REF_Z]) + 1e-7
         # first tet (list order) containing x_ref (Meshutils.jl:800-816), searched among nearby tets only
         near = np.nonzero(np.linalg.norm(ctr - x_ref, axis=1) < 4 * HEIGHT / nz)[0]
         ref = -1
@@ -140,10 +168,23 @@ def build(preset="C2", Y=1e15, n=1.0, tau=1e-3, grid=None):
         QV.append(np.outer(S_vals, g).ravel())
     Q = _coo_to_csr(np.concatenate(QI), np.concatenate(QJ), np.concatenate(QV).astype(complex), d)
 
+    return ({"M": M, "K": K, "C": C, "Q": Q},
+            {"ntets": len(tets), "ntri_outlet": len(tri), "nflame_tets": int(in_flame.sum())})
+
+
+def build_unit_cell(grid=(8, 26, 7), DOS=N_SECTOR, Y=1e15, n=1.0, tau=1e-3):
+    """One sector of the DOS-fold symmetric annulus, discretised on its own mesh (nθc cells, nθc+1 planes).  The
+    matrices are returned on the EXTENDED numbering (image plane included, d_ext = (nθc+1)·nz·nr, image nodes last,
+    reference-plane nodes first -- the layout src/Bloch.jl:4-8 assumes with naxis = 0); helmholtz/bloch.py folds them
+    into the Bloch terms.  Same element formulas and flame model as build()."""
+    nthc, nz, nr = grid
+    pts, tets, _ = _mesh(nthc, nz, nr, sector_of=DOS)
+    terms, info = _assemble(pts, tets, nz, DOS, [0], "polar")
+    info["grid"] = grid
     return {
-        "d": d,
-        "terms": {"M": M, "K": K, "C": C, "Q": Q},
+        "d_ext": pts.shape[0], "nsector": nthc * nz * nr, "nxbloch": nz * nr, "DOS": DOS,
+        "terms_ext": terms,
         "params": {"Y": complex(Y), "n": complex(n), "τ": complex(tau)},
         "points": pts,
-        "info": {"grid": (nth, nz, nr), "ntets": len(tets), "ntri_outlet": len(tri), "nflame_tets": int(in_flame.sum())},
+        "info": info,
     }

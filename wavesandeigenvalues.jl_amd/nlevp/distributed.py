@@ -89,3 +89,77 @@ def moments2eigs_device(buf, shape, tol_sigma=0.0):
     Om, Pt = np.linalg.eig(small.cpu().numpy())
     P = U[:d, :] @ torch.from_numpy(Pt).to(U.device)
     return Om, P, S.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------------
+# independent units: Bloch wave numbers, start values of the local solvers -- no data-path collective,
+# one gather of the results at the end
+# ------------------------------------------------------------------------------------------------------
+def shard_items(n_items, rank, world):
+    """indices of the units this rank owns (round-robin)"""
+    return list(range(rank, n_items, world))
+
+
+def gather_rows(local_rows, n_items, width):
+    """Every rank contributes the rows it owns of an (n_items x width) complex table; returns the complete table on
+    every rank.  One collective (sum all-reduce of a table that is zero outside the owned rows -- the shards may be
+    ragged, which all_gather would not take); NaN marks a failed unit and survives the sum."""
+    import torch
+    tab = np.zeros((n_items, width), dtype=np.complex128)
+    for k, row in local_rows.items():
+        tab[k, :] = np.asarray(row, dtype=np.complex128)
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return tab
+    t = torch.from_numpy(tab.view(np.float64))
+    if d.get_backend() == "nccl":
+        t = t.cuda()
+    d.all_reduce(t)
+    return t.cpu().numpy().view(np.complex128).reshape(n_items, width)
+
+
+def sweep_distributed(items, unit_fn, width):
+    """Run ``unit_fn(item) -> sequence of `width` complex numbers`` for the items this rank owns; gather the table.
+    Returns (table (len(items) x width), {index: whatever unit_fn returned as second value}) -- the second values
+    (Solutions, eigenvectors) stay on the rank that computed them."""
+    rank, world = rank_world()
+    rows, keep = {}, {}
+    for k in shard_items(len(items), rank, world):
+        res = unit_fn(items[k])
+        if isinstance(res, tuple):
+            rows[k], keep[k] = res
+        else:
+            rows[k] = res
+    return gather_rows(rows, len(items), width), keep
+
+
+def refine_distributed(L, starts, method=None, **kw):
+    """One start value per rank (Householder/mslp from e.g. the Beyn estimates): returns the table
+    [ω, iterations, flag] per start on every rank and the owned Solutions."""
+    from .local_solvers import householder
+    method = method or householder
+
+    def unit(z0):
+        sol, n, flag = method(L, z0, **kw)
+        return [sol.params[L.eigval], n, flag], sol
+    return sweep_distributed(list(starts), unit, 3)
+
+
+def bloch_sweep_distributed(L, bs, starts, method=None, b_symbol="b", **kw):
+    """Bloch sweep (config C4): one Bloch wave number per rank at a time, no communication until the final gather.
+    starts: start values shared by all b, or a dict b -> start values (e.g. the Beyn estimates of that b).
+    Returns (table (len(bs) x 3·nstart): [ω, iterations, flag] per start, {index of b: [Solution, ...]})."""
+    from .local_solvers import mslp
+    method = method or mslp
+    nstart = max(len(starts[b]) for b in bs) if isinstance(starts, dict) else len(starts)
+
+    def unit(b):
+        L.params[b_symbol] = complex(b)
+        row = np.full(3 * nstart, complex(np.nan, np.nan))
+        sols = []
+        for q, z0 in enumerate(starts[b] if isinstance(starts, dict) else starts):
+            sol, n, flag = method(L, z0, **kw)
+            row[3 * q:3 * q + 3] = [sol.params[L.eigval], n, flag]
+            sols.append(sol)
+        return row, sols
+    return sweep_distributed(list(bs), unit, 3 * nstart)

@@ -80,9 +80,17 @@ def eigs(A, M, nev=1, v0=None, ncv=None, tol=1e-12, maxiter=300, sigma=0.0, retu
     last = None
     gap = np.inf
     total = 0
+    failed_runs = 0
     while total < maxiter:
         H, V = fam.arnoldi(cA, cM, step, v, op=A.op, tol=stol, maxit=smax)
         total += step
+        # inner solves that did not even reach 1e-4 (far outside the range the multigrid hierarchy was built for, or
+        # beyond what the mesh resolves) cannot produce Ritz pairs: give up like ARPACK does instead of restarting
+        # up to `maxiter` steps of failing solves
+        if fam.last_info["n_unconverged"] > 0 and fam.last_info["relres_max"] > 1e-4:
+            failed_runs += 1
+            if failed_runs >= 2:
+                raise EigsError(f"inner solves stalled at relative residual {fam.last_info['relres_max']:.1e}")
         m = step
         for j in range(step):                # invariant subspace: H[j+1,j] == 0
             if H[j + 1, j] == 0:
