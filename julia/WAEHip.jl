@@ -171,4 +171,47 @@ function arnoldi_shiftinvert(A::Operator, M::Operator, m::Integer, v0::Vector{Co
     return H, V
 end
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# operator interchange: the WAEFAM1 container read by wae_amd.nlevp.save.load_family (Python harness).  The text format
+# of `save(fname, L)` (LinOpFam.jl:236-294) also loads there, but a 1M-DoF family is ~1 GB of text; this writes the
+# CSC arrays as they lie in memory.  Coefficient functions are stored by name: `names` maps closures (e.g. the
+# `exp_plus` made in Helmholtz.jl:90) to a constructor expression such as "generate_exp_az(0.0+0.19634954084936207im)".
+# ---------------------------------------------------------------------------------------------------------------
+_jsonstr(s::AbstractString) = "\"" * replace(replace(String(s), "\\" => "\\\\"), "\"" => "\\\"") * "\""
+_jsonnum(x::Real) = isnan(x) ? "NaN" : (isinf(x) ? (x > 0 ? "Infinity" : "-Infinity") : string(Float64(x)))
+
+function save_family_bin(fname::AbstractString, L::LinearOperatorFamily; names=Dict{Any,String}())
+    io = IOBuffer()
+    print(io, "{\"version\": 1, \"eigval\": ", _jsonstr(string(L.eigval)), ", \"auxval\": ", _jsonstr(string(L.auxval)),
+          ", \"active\": [", join((_jsonstr(string(a)) for a in L.active), ", "), "], \"mode\": ", _jsonstr(string(L.mode)),
+          ", \"params\": {")
+    print(io, join((_jsonstr(string(k)) * ": [" * _jsonnum(real(v)) * ", " * _jsonnum(imag(v)) * "]" for (k, v) in L.params), ", "))
+    print(io, "}, \"terms\": [")
+    for (i, t) in enumerate(L.terms)
+        i > 1 && print(io, ", ")
+        fn = [haskey(names, f) ? names[f] : string(nameof(f)) for f in t.func]
+        m, n = size(t.coeff)
+        print(io, "{\"symbol\": ", _jsonstr(t.symbol), ", \"operator\": ", _jsonstr(t.operator), ", \"functions\": [",
+              join((_jsonstr(f) for f in fn), ", "), "], \"params\": [",
+              join(("[" * join((_jsonstr(string(q)) for q in p), ", ") * "]" for p in t.params), ", "),
+              "], \"m\": ", m, ", \"n\": ", n, ", \"nnz\": ", nnz(t.coeff), ", \"base\": 1}")
+    end
+    print(io, "]}")
+    head = take!(io)
+    open(fname, "w") do f
+        write(f, "WAEFAM1\n")
+        write(f, UInt64(length(head)))
+        write(f, head)
+        pad() = write(f, zeros(UInt8, mod(-position(f), 8)))
+        for t in L.terms
+            A = t.coeff
+            pad(); write(f, Vector{Int64}(A.colptr))
+            pad(); write(f, Vector{Int64}(A.rowval))
+            pad(); write(f, Vector{ComplexF64}(A.nzval))
+        end
+    end
+    return fname
+end
+
 end # module

@@ -22,7 +22,8 @@ from __future__ import annotations
 import numpy as np
 import scipy.sparse as sp
 
-from ..nlevp.algebra import (exp_az, exp_delay, generate_1_gz, generate_gz_hz, generate_Sigma_y_exp_ikx, pow1, pow2)
+from ..nlevp.algebra import (exp_delay, generate_1_gz, generate_exp_az, generate_gz_hz, generate_Sigma_y_exp_ikx, pow1,
+                             pow2)
 from ..nlevp.linopfam import LinearOperatorFamily, Term
 
 SUFFIXES = ("", "+", "-", "δ", "δ+", "δ-")
@@ -57,12 +58,8 @@ def phase_functions(DOS):
     """exp_plus, exp_minus, bloch_filt, anti_bloch_filt, bloch_exp_plus, bloch_exp_minus -- src/Helmholtz.jl:89-98."""
     dphi = 2 * np.pi / DOS
 
-    def exp_plus(z, k=0):
-        return exp_az(z, 1j * dphi, k)
-
-    def exp_minus(z, k=0):
-        return exp_az(z, -1j * dphi, k)
-
+    exp_plus = generate_exp_az(1j * dphi)        # = exp_az(z, Δϕ·i, k), written so that operator files can name it
+    exp_minus = generate_exp_az(-1j * dphi)
     y = np.zeros(DOS, dtype=complex)
     y[0] = 1.0 / DOS
     bloch_filt = generate_Sigma_y_exp_ikx(np.fft.fft(y))

@@ -10,4 +10,5 @@ from .local_solvers import (count_poles_and_zeros, decode_error_flag, eigs, hous
                             mslp, padesolve, rf2s, traceiter)
 from .perturbation import (multi_indices_at_order, multinomcoeff, part2mult, partitions, perturb, perturb_,  # noqa: F401
                            perturb_disk, perturb_fast_, perturb_norm, perturb_norm_, weigh)
+from .save import load_family, read_sol, save  # noqa: F401
 from .solver import solve  # noqa: F401

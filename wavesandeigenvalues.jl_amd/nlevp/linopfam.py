@@ -258,6 +258,10 @@ class LinearOperatorFamily:
     """LinOpFam.jl:131-186 (type + constructors), :305-346 (push!), :482-529 (functor)."""
 
     def __init__(self, params=("λ",), values=None, device=0):
+        if isinstance(params, str):                     # LinearOperatorFamily(fname)  LinOpFam.jl:196-225
+            from .save import load_family
+            self.__dict__.update(load_family(params, device=device).__dict__)
+            return
         params = list(params)
         if values is None:
             values = [NaN for _ in params]
