@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--sweeps", type=int, default=1)
     ap.add_argument("--n", type=float, default=1.0)
     ap.add_argument("--tau", type=float, default=2e-4)
+    ap.add_argument("--rb", type=int, default=32,
+                    help="snapshot points for projected initial guesses (wae_beyn_moments_rb); 0 = every system from a zero guess")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-preset", default="20k")
     args = ap.parse_args()
@@ -111,7 +113,7 @@ def main():
     import wae_amd  # noqa: F401
     from wae_amd.helmholtz.family import annulus_family
     from wae_amd.nlevp import compute_moment_matrices, gauss_points, initialize_V, moments2eigs, pos_test
-    from wae_amd.nlevp.distributed import allreduce_sum_, moments2eigs_device, shard_points
+    from wae_amd.nlevp.distributed import allreduce_sum_, beyn_moments_distributed_rb, moments2eigs_device, shard_points
     from wae_amd.nlevp.beyn import inpoly
 
     t0 = time.time()
@@ -134,13 +136,23 @@ def main():
     tim = {}
 
     def step():
+        nonlocal buf
         t = [time.time()]
-        compute_moment_matrices(L, G, V, K=K, N=args.N, points=(zr, wr), out_dev=buf.data_ptr())
-        t.append(time.time())
-        info = dict(fam.last_info)
-        allreduce_sum_(buf)                              # sum of the partial moment tensors (RCCL over xGMI)
-        torch.cuda.synchronize()
-        t.append(time.time())
+        if args.rb > 0:
+            # snapshot points -> all-gather of the snapshot store -> projected initial guesses -> all-reduce of the moments
+            ph = {}
+            buf, info = beyn_moments_distributed_rb(L, G, V, K, args.N, args.rb, timings=ph)
+            t.append(t[0] + ph["snapshots"] + ph["allgather"] + ph["projected"])
+            t.append(time.time())
+            if rank == 0:
+                tim.update({"snapshot_solves": ph["snapshots"], "allgather": ph["allgather"], "projected_solves": ph["projected"]})
+        else:
+            compute_moment_matrices(L, G, V, K=K, N=args.N, points=(zr, wr), out_dev=buf.data_ptr(), rb=0)
+            t.append(time.time())
+            info = dict(fam.last_info)
+            allreduce_sum_(buf)                              # sum of the partial moment tensors (RCCL over xGMI)
+            torch.cuda.synchronize()
+            t.append(time.time())
         res = None
         if rank == 0:
             t.append(time.time())

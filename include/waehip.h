@@ -132,6 +132,31 @@ int wae_beyn_moments(wae_family *h, int32_t npts, const double *z, const double 
                      const double *V, int32_t l, int32_t K, double tol, int32_t maxit, double *A_out,
                      uint64_t out_dev, wae_solve_info *info);
 
+/* -- Beyn moments with snapshot-projection initial guesses -----------------------------------------------------
+ * The solutions X(z) = L(z)^{-1} V along a contour form a low-dimensional manifold (a handful of poles near the
+ * contour plus a smooth part) -- the observation behind the reference's `generate_subspace`/`project`
+ * (src/NLEVP/beyn.jl:429-560).  Here it accelerates the integrand evaluation of `beyn`/`compute_moment_matrices`
+ * (src/NLEVP/beyn.jl:62-71,253-259) itself, without changing its result: a few quadrature points are solved from a
+ * zero guess and kept as snapshots (mode 0); for all other points (mode 1) every system starts from the Galerkin
+ * projection of its solution on the per-column span of the snapshots and multigrid-GMRES only has to supply the rest,
+ * to the same tolerance relative to the same right-hand side.
+ *   nbasis: capacity of the snapshot store in snapshots (each d x l complex, interleaved [row][column]).
+ *   mode 0: solve the npts points, accumulate their moment contributions and append their solutions to the store
+ *           (slot0 = number of snapshots already there; 0 starts a new basis).  Progressive: a chunk of points starts
+ *           from the projection on the snapshots taken before it, so pass the points in a spread-out order.
+ *   mode 1: the store holds slot0 raw snapshots (e.g. all-gathered from several GPUs): orthonormalise them per
+ *           column (in place), project every term, then process the npts points with projected initial guesses.
+ *   mode 2: as mode 1 with the basis as mode 0 calls left it (no rebuild).
+ *   (Environment WAE_RB_ENRICH=<n>: in modes 1/2 append a chunk of points that still needed more than n iterations to
+ *   the basis while the store has room.  Off by default: it did not pay on the benchmark contour.)
+ *   Q_dev : device pointer of the snapshot store, or 0 for a store owned by the handle; a caller-owned store is
+ *           what a multi-GPU driver all-gathers between modes 0 and 1.
+ *   accumulate != 0: add to the moments already in out_dev instead of zeroing them first (requires out_dev).
+ * Everything else as wae_beyn_moments. */
+int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const double *w, const double *coeff_table, const double *V,
+                        int32_t l, int32_t K, double tol, int32_t maxit, int32_t mode, int32_t nbasis, int32_t slot0, uint64_t Q_dev,
+                        double *A_out, uint64_t out_dev, int32_t accumulate, wae_solve_info *info);
+
 /* -- shift-invert Arnoldi factorisation for (A, M), A = sum cA_k A_k, M = sum cM_k A_k -----------------
  * The device half of `Arpack.eigs(A,M,nev=nev,sigma=0,v0=v0)` and of the adjoint call on (A',M')
  * (Householder.jl:100-101, iterative_solvers.jl:132-133):  m steps of Arnoldi on  op(A)^{-1} op(M)

@@ -139,3 +139,22 @@ def test_c4_bloch_unit_cell_full_size():
     # the plane-wave-like mode (b = 0) and the first azimuthal mode (b = 1) of this geometry
     assert 150 < found[0].real / 2 / np.pi < 250 and 380 < found[1].real / 2 / np.pi < 480
     L._drop_device()
+
+
+def test_projected_guesses_full_size(c2):
+    """At C2 the snapshot-projection path (32 snapshot points of 128) returns the moments of the plain path to the inner
+    tolerance with less than a third of the Krylov iterations."""
+    L, pb = c2
+    d = pb["d"]
+    V = np.random.default_rng(7).standard_normal((d, 16)) + 0j
+    A0 = compute_moment_matrices(L, GAMMA, V, K=1, N=32, rb=0)
+    fam = L.device()
+    its0 = fam.last_info["iters_total"]
+    A1 = compute_moment_matrices(L, GAMMA, V, K=1, N=32, rb=32)
+    info = fam.last_info
+    assert info["n_unconverged"] == 0
+    assert np.max(np.abs(A1 - A0)) <= 1e-8 * np.max(np.abs(A0))
+    assert info["iters_total"] < its0 / 3
+    S0 = moments2eigs(A0, return_sigma=True)[2]
+    S1 = moments2eigs(A1, return_sigma=True)[2]
+    assert np.allclose(S0[:8], S1[:8], rtol=1e-8) and S1[8] < 1e-8 * S1[0]

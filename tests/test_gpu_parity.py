@@ -400,3 +400,48 @@ def test_many_terms_mixed_patterns_bloch_like():
     Xh = Ap.H.solve(x, tol=1e-12)
     assert relerr(Xh, OS._solve(sp.csc_matrix(Ao.conj().T), x)) < 1e-7
     Lp._drop_device()
+
+
+def test_beyn_moments_with_projected_guesses_match_plain_and_oracle():
+    """wae_beyn_moments_rb: snapshot points solved from a zero guess, every other point from the Galerkin projection on
+    the snapshots.  The stopping test is unchanged (relative to the same right-hand side), so the moments agree with
+    the plain path to the inner tolerance, and the eigenvalues with the oracle's golden values."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(F.GOLDEN_DIR, "annulus_small_beyn.json")))
+    from wae_amd.helmholtz.family import annulus_family
+    Lp, pb = annulus_family("small", n=gold["n"], tau=gold["tau"])
+    Lp.solver_tol = 1e-11
+    Lp.solver_ref = 2 * np.pi * 500.0
+    Gam = np.array([150 - 150j, 1000 - 150j, 1000 + 150j, 150 + 150j]) * 2 * np.pi
+    d = pb["d"]
+    rng = np.random.default_rng(gold["seed_V"])
+    V = rng.standard_normal((d, gold["l"])) + 1j * rng.standard_normal((d, gold["l"]))
+    A0 = compute_moment_matrices(Lp, Gam, V, K=1, N=gold["N"], rb=0)
+    fam = Lp.device()
+    its0 = fam.last_info["iters_total"]
+    A1 = compute_moment_matrices(Lp, Gam, V, K=1, N=gold["N"], rb=24)
+    info = fam.last_info
+    assert info["n_unconverged"] == 0 and info["snapshots"] == 24
+    assert relerr(A1, A0) < 1e-8
+    assert info["iters_total"] < 0.6 * its0                      # the projection does most of the work
+    Om, P = moments2eigs(A1)
+    for w in np.array([c(e) for e in gold["eigs"]]):
+        assert np.min(np.abs(Om - w)) < 1e-8 * abs(w)
+    # a caller-owned store and the "rebuild from raw snapshots" mode (what the multi-GPU driver uses after its all-gather)
+    import torch
+    from wae_amd.nlevp.beyn import coefficient_table, gauss_points, snapshot_split
+    zs, ws = gauss_points(Gam, gold["N"])
+    ct = coefficient_table(Lp, zs)
+    idx, rest = snapshot_split(len(zs), 24)
+    l = V.shape[1]
+    store = torch.empty(24 * d * l * 2, dtype=torch.float64, device="cuda:0")
+    buf = torch.zeros(d * l * 2 * 2, dtype=torch.float64, device="cuda:0")
+    kw = dict(K=1, tol=Lp.solver_tol, maxit=Lp.solver_maxit, out_dev=buf.data_ptr())
+    fam.beyn_moments_rb(zs[idx[:12]], ws[idx[:12]], ct[idx[:12]], V, 0, 12, Q_dev=store.data_ptr(), **kw)           # "rank 0"
+    fam.beyn_moments_rb(zs[idx[12:]], ws[idx[12:]], ct[idx[12:]], V, 0, 12, Q_dev=store[12 * d * l * 2:].data_ptr(),
+                        accumulate=True, **kw)                                                                     # "rank 1"
+    fam.beyn_moments_rb(zs[rest], ws[rest], ct[rest], V, 1, 24, slot0=24, Q_dev=store.data_ptr(), accumulate=True, **kw)
+    A2 = buf.cpu().numpy().view(np.complex128).reshape((d, l, 2), order="F")
+    assert relerr(A2, A0) < 1e-8
+    Lp._drop_device()

@@ -257,7 +257,8 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
     return P;
 }
 
-void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, const AmgOptions &opt, std::vector<AmgLevel> &levels) {
+void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, const AmgOptions &opt, std::vector<AmgLevel> &levels,
+               std::vector<char> *penalty_rows) {
     levels.clear();
     CsrZ Aref = csr_lincomb(planes, pc_ref);
     const int64_t n0 = Aref.n;
@@ -301,6 +302,7 @@ void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, c
         const double med = tmp[n0 / 2];
         for (int64_t i = 0; i < n0; ++i) skip[i] = dabs[i] > opt.penalty_ratio * med;
     }
+    if (penalty_rows) *penalty_rows = skip;
     std::vector<CsrZ> cur(planes);
     int64_t n = n0;
     while (n > opt.max_coarse && (int)levels.size() < opt.max_levels) {

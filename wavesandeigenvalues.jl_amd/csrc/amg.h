@@ -15,4 +15,6 @@ struct AmgLevel {
 CsrZ csr_lincomb(const std::vector<CsrZ> &planes, const std::vector<zc> &coef);
 CsrD galerkin_real(const CsrD &R, const CsrD &A, const CsrD &P);
 CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double theta, bool smooth);
-void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, const AmgOptions &opt, std::vector<AmgLevel> &levels);
+// penalty_rows (optional): receives the fine-level flags of the rows detected as penalty (Dirichlet-like) rows
+void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, const AmgOptions &opt, std::vector<AmgLevel> &levels,
+               std::vector<char> *penalty_rows = nullptr);

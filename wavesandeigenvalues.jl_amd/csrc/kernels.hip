@@ -407,12 +407,42 @@ __global__ __launch_bounds__(256) void jacobi0_kernel(OpDev op, const cplx *__re
     }
 }
 
+// compact <-> full row sets (penalty-block polish, lib.hip): out[i][b] = X[rows[i]][b];  X[rows[i]][b] += D[i][b]
+__global__ __launch_bounds__(256) void gather_rows_kernel(const cplx *__restrict__ X, const int *__restrict__ rows, size_t total, int nb,
+                                                          cplx *__restrict__ out) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t i = e / nb;
+        out[e] = X[(size_t)rows[i] * nb + (e - i * nb)];
+    }
+}
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const cplx *__restrict__ D, const int *__restrict__ rows, size_t total, int nb,
+                                                               cplx *__restrict__ X) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t i = e / nb;
+        const size_t t = (size_t)rows[i] * nb + (e - i * nb);
+        const cplx x = X[t], dlt = D[e];
+        X[t] = cplx{x.x + dlt.x, x.y + dlt.y};
+    }
+}
+
 static inline unsigned grid_for(size_t total, unsigned cap = 4096) {
     size_t g = (total + 255) / 256;
     if (g < 1) g = 1;
     return (unsigned)(g > cap ? cap : g);
 }
 
+void launch_gather_rows(const cplx *X, const int *rows, int64_t nrows, int nb, cplx *out, hipStream_t st) {
+    const size_t total = (size_t)nrows * nb;
+    if (!total) return;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(total)), dim3(256), 0, st, X, rows, total, nb, out);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_scatter_add_rows(const cplx *D, const int *rows, int64_t nrows, int nb, cplx *X, hipStream_t st) {
+    const size_t total = (size_t)nrows * nb;
+    if (!total) return;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for(total)), dim3(256), 0, st, D, rows, total, nb, X);
+    HIP_CHECK(hipGetLastError());
+}
 void launch_jacobi0(const OpDev &op, const cplx *pc, int cps, const cplx *B, cplx *X, double w, int nb, hipStream_t st, const unsigned char *cmask) {
     if (op.n <= 0) return;
     hipLaunchKernelGGL(jacobi0_kernel, dim3(grid_for((size_t)op.n * nb)), dim3(256), 0, st, op, pc, cps, B, X, w, nb, cmask);
@@ -777,6 +807,87 @@ void launch_axpy_neg(const cplx *V, size_t stride, int nv, const cplx *h, cplx *
 }
 void launch_lincomb(const cplx *V, size_t stride, int nv, const cplx *y, cplx *Y, int64_t n, int nb, hipStream_t st) {
     axpy_impl(V, stride, nv, y, Y, n, nb, 1.0, nullptr, st, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// snapshot-basis helpers (Galerkin initial guesses for the shifted systems of a contour, lib.hip: beyn_moments_rb)
+// ---------------------------------------------------------------------------------------------------
+// out[row][c] = X[row][off + c], c < l   (one system's l columns out of a lock-step batch of nb columns)
+__global__ __launch_bounds__(256) void extract_cols_kernel(const cplx *__restrict__ X, int nb, int off, int l, cplx *__restrict__ out, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t row = e / l;
+        const int c = (int)(e - row * l);
+        out[e] = X[row * nb + off + c];
+    }
+}
+void launch_extract_cols(const cplx *X, int nb, int off, int l, cplx *out, int64_t n, hipStream_t st) {
+    const size_t total = (size_t)n * l;
+    if (!total) return;
+    hipLaunchKernelGGL(extract_cols_kernel, dim3(grid_for(total)), dim3(256), 0, st, X, nb, off, l, out, total);
+    HIP_CHECK(hipGetLastError());
+}
+// X[row][b] = sum_i y[i][b] Q_i[row][b % l]: the basis multivectors have l columns (one per probe column), the batch
+// has nb = nsys*l columns (every system re-uses the same l bases with its own coefficients).  Coefficients in LDS.
+__global__ __launch_bounds__(256) void lincomb_rep_kernel(const cplx *__restrict__ Q, size_t stride, int nv, const cplx *__restrict__ y,
+                                                          cplx *__restrict__ X, int64_t n, int nb, int l, int accumulate) {
+    extern __shared__ cplx hs[];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < nv * nb; k += 256) hs[k] = y[k];
+    __syncthreads();
+    const int R = 256 / nb;
+    const int b = tid % nb, rl = tid / nb;
+    if (rl >= R) return;
+    const int c = b % l;
+    for (int64_t row = (int64_t)blockIdx.x * R + rl; row < n; row += (int64_t)gridDim.x * R) {
+        const size_t eq = (size_t)row * l + c;
+        cplx acc = accumulate ? X[(size_t)row * nb + b] : cplx{0.0, 0.0};
+        int i = 0;
+        for (; i + AXU <= nv; i += AXU) {
+            cplx v[AXU];
+#pragma unroll
+            for (int u = 0; u < AXU; ++u) v[u] = Q[(size_t)(i + u) * stride + eq];
+#pragma unroll
+            for (int u = 0; u < AXU; ++u) {
+                const cplx cf = hs[(i + u) * nb + b];
+                acc.x += cf.x * v[u].x - cf.y * v[u].y;
+                acc.y += cf.x * v[u].y + cf.y * v[u].x;
+            }
+        }
+        for (; i < nv; ++i) {
+            const cplx cf = hs[i * nb + b];
+            const cplx v = Q[(size_t)i * stride + eq];
+            acc.x += cf.x * v.x - cf.y * v.y;
+            acc.y += cf.x * v.y + cf.y * v.x;
+        }
+        X[(size_t)row * nb + b] = acc;
+    }
+}
+void launch_lincomb_rep(const cplx *Q, size_t stride, int nv, const cplx *y, cplx *X, int64_t n, int nb, int l, hipStream_t st) {
+    if (!n || nb < 1) return;
+    if (nb > 256) throw WaeError(WAE_ERR_INVALID, "lincomb_rep: nb must be in 1..256");
+    const int R = 256 / nb;
+    const unsigned grid = (unsigned)std::min<int64_t>((n + R - 1) / R, 2048);
+    const int maxv = std::max(1, AX_MAXC / nb);
+    int done = 0;
+    do {
+        const int chunk = std::min(nv - done, maxv);
+        hipLaunchKernelGGL(lincomb_rep_kernel, dim3(grid), dim3(256), (size_t)std::max(chunk, 1) * nb * sizeof(cplx), st,
+                           Q + (size_t)done * stride, stride, chunk, y + (size_t)done * nb, X, n, nb, l, done ? 1 : 0);
+        HIP_CHECK(hipGetLastError());
+        done += chunk;
+    } while (done < nv);
+}
+// X[row][b] *= keep[b] (keep = 0 or 1, real part of a complex table): drop the guesses of selected columns
+__global__ __launch_bounds__(256) void mask_cols_kernel(cplx *__restrict__ X, const cplx *__restrict__ keep, size_t total, int nb) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        if (keep[e % nb].x == 0.0) X[e] = cplx{0.0, 0.0};
+    }
+}
+void launch_mask_cols(cplx *X, const cplx *keep, int64_t n, int nb, hipStream_t st) {
+    const size_t total = (size_t)n * nb;
+    if (!total) return;
+    hipLaunchKernelGGL(mask_cols_kernel, dim3(grid_for(total)), dim3(256), 0, st, X, keep, total, nb);
+    HIP_CHECK(hipGetLastError());
 }
 
 __global__ __launch_bounds__(256) void scale_inv_kernel(const cplx *__restrict__ X, const cplx *__restrict__ alpha, cplx *__restrict__ Y, size_t total, int nb,

@@ -53,6 +53,15 @@ static OpDev transfer_dev(const DevBuf<int> &ptr, const DevBuf<int> &col, const 
 OpDev Transfer::devP() const { return transfer_dev(p_ptr, p_col, p_val, nf); }
 OpDev Transfer::devR() const { return transfer_dev(r_ptr, r_col, r_val, nc); }
 
+struct RbState {                     // snapshot basis of wae_beyn_moments_rb (one per handle)
+    cplx *Q = nullptr;               // store: cap snapshots of d x l (interleaved [row][column]); slots < S are orthonormal per column
+    int cap = 0, l = 0, S = 0;
+    std::vector<int> kact;           // terms that take part in the projection
+    std::vector<zc> Hk;              // Hk[ki][(s*cap + i)*l + c] = q_i^H A_k q_s   (column c's basis)
+    std::vector<zc> g;               // g[i*l + c] = q_i^H v_c
+    DevBuf<cplx> W, Vi, hb, alpha, ycoef;   // W_k = A_k Q (resident), probe columns interleaved, small scratch
+};
+
 struct wae_family {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -76,15 +85,26 @@ struct wae_family {
     // workspaces
     std::vector<DevBuf<cplx>> lx, lb, lt;
     DevBuf<cplx> V, W, Z, Xs, Bs, U, partial, hdev, ydev, pcdev, one_dev, io_a, io_b, zw_dev;
+    DevBuf<cplx> rbQ;                // library-owned snapshot store of wae_beyn_moments_rb
+    RbState rb;                      // the snapshot basis and its projected terms
     DevBuf<int> plane_col_dev;
     DevBuf<unsigned char> cmask;     // one byte per 8-column chunk of the current batch (0 = converged)
+    // penalty (Dirichlet-like) rows found at set-up: their sub-block as a small operator of its own (see penalty_polish)
+    int64_t n_penalty = 0;
+    LevelOp pen_op;
+    std::vector<int> pen_slot;
+    DevBuf<int> pen_rows;
+    DevBuf<cplx> pen_b, pen_x, pen_t;
     cplx *h_pinned = nullptr;        // (restart+2)*NB
     size_t pc_stride_level = 0;      // elements per level in pcdev
     ~wae_family() {
-        for (auto *b : {&dense_planes, &Ainv, &V, &W, &Z, &Xs, &Bs, &U, &partial, &hdev, &ydev, &pcdev, &one_dev, &io_a, &io_b, &zw_dev}) b->release();
+        for (auto *b : {&dense_planes, &Ainv, &V, &W, &Z, &Xs, &Bs, &U, &partial, &hdev, &ydev, &pcdev, &one_dev, &io_a, &io_b, &zw_dev, &rbQ, &rb.W, &rb.Vi, &rb.hb, &rb.alpha, &rb.ycoef}) b->release();
         dstatus.release();
         plane_col_dev.release();
         cmask.release();
+        pen_rows.release(); pen_b.release(); pen_x.release(); pen_t.release();
+        pen_op.diag.release();
+        for (auto &G : pen_op.groups) { G.rowptr.release(); G.col.release(); G.rowptr_t.release(); G.col_t.release(); G.vals.release(); G.vals_t.release(); }
         for (auto &b : lx) b.release();
         for (auto &b : lb) b.release();
         for (auto &b : lt) b.release();
@@ -254,13 +274,16 @@ static void upload_pc(wae_family *h, const std::vector<std::vector<zc>> &pcs) {
     const int nsys = (int)pcs.size();
     const int nl = (int)h->ops.size();
     const size_t per_level = (size_t)nsys * h->nplanes;
-    std::vector<cplx> tab(per_level * nl);
-    for (int l = 0; l < nl; ++l)
+    std::vector<cplx> tab(per_level * (nl + 1));
+    for (int l = 0; l <= nl; ++l) {                      // block nl: the penalty-row operator (own slot order)
+        if (l == nl && h->n_penalty == 0) break;
+        const std::vector<int> &sp = l < nl ? h->slot_plane[l] : h->pen_slot;
         for (int s = 0; s < nsys; ++s)
             for (int q = 0; q < h->nplanes; ++q) {
-                const zc c = pcs[s][h->slot_plane[l][q]];
+                const zc c = pcs[s][sp[q]];
                 tab[l * per_level + (size_t)s * h->nplanes + q] = cplx{c.real(), c.imag()};
             }
+    }
     h->pc_stride_level = per_level;
     h->pcdev.upload(tab.data(), tab.size(), h->stream);
     HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -330,8 +353,46 @@ struct ColState {
     bool conv = false;
 };
 
-static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double tol, int maxit, wae_solve_info *info,
-                  const cplx *guess_dir = nullptr) {
+// A solution that starts from a guess assembled out of other solutions (wae_beyn_moments_rb) is accurate in the norm of
+// the stopping test but not componentwise on the penalty rows: their unknowns are ~1e-11 of the rest and are multiplied by
+// 1e15 in the operator, so eigenvectors built from such solutions show a large residual exactly there.  (From a zero guess
+// the ~30 V-cycle applications of the Krylov process resolve them as a by-product.)  This solves the penalty rows' own
+// equations  A_bb d = (b - A x)_b  for the given interior values: the block is an admittance-scaled boundary mass matrix,
+// for which point relaxation with weight 0.8 contracts by 0.6 per sweep (spectrum of D^-1 M_P1,2D in [1/2, 2]); the sweeps
+// run on the compact n_b x n_b operator and cost microseconds.  Best effort: a block of another kind on which the
+// relaxation does not contract is left as it was.
+static void penalty_polish(wae_family *h, const Batch &bt, const cplx *B, cplx *X) {
+    if (h->n_penalty <= 0) return;
+    static const int sweeps = getenv("WAE_PEN_SWEEPS") ? atoi(getenv("WAE_PEN_SWEEPS")) : 40;
+    if (sweeps <= 0) return;
+    hipStream_t st = h->stream;
+    const int nb = bt.nb;
+    const int64_t nbk = h->n_penalty;
+    const OpDev A = h->ops[0].dev(bt.op);
+    const OpDev Ab = h->pen_op.dev(bt.op);
+    const cplx *pcb = pc_level(h, (int)h->ops.size());
+    launch_spmv(A, pc_level(h, 0), bt.cps, X, h->W.p, B, 0.0, nb, MODE_RES, st);
+    launch_gather_rows(h->W.p, h->pen_rows.p, nbk, nb, h->pen_b.p, st);
+    launch_norms(h->pen_b.p, nbk, nb, h->partial.p, h->hdev.p, st);
+    cplx *x = h->pen_x.p, *t = h->pen_t.p;
+    launch_jacobi0(Ab, pcb, bt.cps, h->pen_b.p, x, 0.8, nb, st);
+    for (int s = 1; s < sweeps; ++s) {
+        launch_spmv(Ab, pcb, bt.cps, x, t, h->pen_b.p, 0.8, nb, MODE_JAC, st);
+        std::swap(x, t);
+    }
+    launch_spmv(Ab, pcb, bt.cps, x, t, h->pen_b.p, 0.0, nb, MODE_RES, st);
+    launch_norms(t, nbk, nb, h->partial.p, h->hdev.p + nb, st);
+    cplx *hp = h->h_pinned;
+    HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, (size_t)2 * nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    for (int b = 0; b < nb; ++b)
+        if (!(hp[nb + b].x <= 1e-3 * hp[b].x)) return;          // not contracting (or NaN): leave X alone
+    launch_scatter_add_rows(x, h->pen_rows.p, nbk, nb, X, st);
+}
+
+// returns the number of lock-step iterations
+static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double tol, int maxit, wae_solve_info *info,
+                 const cplx *guess_dir = nullptr, bool have_x0 = false) {
     // LEFT-preconditioned GMRES(m) on  M^-1 A x = M^-1 b  (M^-1 = one multigrid V-cycle), all columns in lock-step.
     // Every norm is therefore a norm of the preconditioned residual M^-1 r ~ the error itself.  This matters here:
     // the admittance rows carry 1e15-sized entries (Helmholtz.jl:151-156), so the plain residual norm is dominated
@@ -349,7 +410,9 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
     const OpDev A = h->ops[0].dev(bt.op);
     const cplx *pc = pc_level(h, 0);
     cplx *hp = h->h_pinned;
-    launch_fill_zero(X, vec, st);
+    // have_x0: X already holds an initial guess (the Galerkin projection on earlier solutions, beyn_moments_rb); the
+    // stopping test stays relative to ||M^-1 b||, so the answer is the same as from a zero guess, only cheaper
+    if (!have_x0) launch_fill_zero(X, vec, st);
     {
         const cplx *zb = vcycle(h, bt, 0, B);
         launch_norms(zb, n, nb, h->partial.p, h->hdev.p, st);
@@ -363,15 +426,18 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
     for (int b = 0; b < nb; ++b) { bnorm[b] = hp[b].x; if (!(bnorm[b] > 0.0)) done[b] = 1; }
     std::vector<ColState> cs(nb);
     int total_it = 0;
-    bool first = true;
+    bool first = !have_x0;
+    bool x0_unchecked = have_x0;
     bool nan_seen = false;
     // converged-chunk mask: columns are skipped in groups of 8 (one 128-B segment of every interleaved row) as soon as
     // all 8 have converged -- the columns of one shifted system converge together, so this removes most of the work the
     // lock-step batch would otherwise spend on finished systems
     const int nch = (nb + 7) / 8;
-    // opt-in (WAE_MASK=1): on the annulus all systems of a batch converge within a few iterations of each other and the
-    // predicates cost ~2 %; batches mixing easy and hard shifts gain from it
-    static const bool use_mask = getenv("WAE_MASK") && atoi(getenv("WAE_MASK"));
+    // from a zero guess all systems of a batch converge within a few iterations of each other and the predicates cost
+    // ~2 %: off unless WAE_MASK=1.  With projected initial guesses the columns start 0..8 digits from the answer and
+    // finish at very different times: on (measured -15 % on the C2 Beyn pass), WAE_MASK=0 disables.
+    static const char *env_mask = getenv("WAE_MASK");
+    const bool use_mask = env_mask ? atoi(env_mask) != 0 : have_x0;
     std::vector<unsigned char> cm(nch, 1), cm_prev(nch, 2);
     if (h->cmask.n < (size_t)nch) h->cmask.alloc(nch);
     auto push_mask = [&]() {
@@ -415,6 +481,20 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
         launch_norms(z0, n, nb, h->partial.p, h->hdev.p, st);
         HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
+        if (x0_unchecked) {
+            // a guess that is worse than no guess (an ill-conditioned projected system) is dropped, column by column
+            x0_unchecked = false;
+            std::vector<cplx> keep(nb, cplx{1.0, 0.0});
+            bool any_bad = false;
+            for (int b = 0; b < nb; ++b)
+                if (bnorm[b] > 0.0 && !(hp[b].x / bnorm[b] <= 1.0)) { keep[b] = cplx{0.0, 0.0}; any_bad = true; }
+            if (any_bad) {
+                h->ydev.upload(keep.data(), nb, st);
+                launch_mask_cols(X, h->ydev.p, n, nb, st);
+                HIP_CHECK(hipStreamSynchronize(st));
+                continue;
+            }
+        }
         bool all_done = true;
         for (int b = 0; b < nb; ++b) {
             if (bnorm[b] > 0.0) {
@@ -522,6 +602,13 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
         }
         if (nan_seen) break;
     }
+    if (have_x0 && !nan_seen) penalty_polish(h, bt, B, X);
+    static const bool dbg = getenv("WAE_GMRES_DEBUG") && atoi(getenv("WAE_GMRES_DEBUG"));
+    if (dbg) {
+        double r0max = 0.0;
+        for (int b = 0; b < nb; ++b) if (!hist[b].empty()) r0max = std::max(r0max, hist[b][0]);
+        fprintf(stderr, "[gmres] nb=%d x0=%d lockstep_its=%d first-step relres max=%.2e\n", nb, (int)have_x0, total_it, r0max);
+    }
     if (info) {
         int imax = 0, itot = 0, nun = 0;
         double rmax = 0.0;
@@ -541,6 +628,7 @@ static void gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double
         info->levels = (info->levels & (1 << 16)) | (int)h->ops.size();
     }
     if (nan_seen) throw WaeError(WAE_ERR_NAN, "NaN in GMRES");
+    return total_it;
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -576,6 +664,156 @@ static int info_code(wae_solve_info &i) {   // also clears the internal stagnati
 
 // ----------------------------------------------------------------------------------------------------
 // C ABI
+// ----------------------------------------------------------------------------------------------------
+// snapshot basis for projected initial guesses (wae_beyn_moments_rb)
+// ----------------------------------------------------------------------------------------------------
+// Gaussian elimination with partial pivoting on a small dense complex system (column-major n x n), in place.
+// Unknowns whose pivot vanishes are set to zero (a deficient direction of the snapshot basis).
+static void small_solve(std::vector<zc> &A, std::vector<zc> &b, int n) {
+    std::vector<char> dead(n, 0);
+    double amax = 0.0;
+    for (const zc &a : A) amax = std::max(amax, std::abs(a));
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        double best = 0.0;
+        for (int i = k; i < n; ++i) { const double v = std::abs(A[(size_t)k * n + i]); if (v > best) { best = v; p = i; } }
+        if (!(best > 1e-14 * amax)) { dead[k] = 1; continue; }
+        if (p != k) {
+            for (int j = 0; j < n; ++j) std::swap(A[(size_t)j * n + k], A[(size_t)j * n + p]);
+            std::swap(b[k], b[p]);
+        }
+        const zc inv = 1.0 / A[(size_t)k * n + k];
+        for (int i = k + 1; i < n; ++i) {
+            const zc f = A[(size_t)k * n + i] * inv;
+            if (f == zc(0)) continue;
+            for (int j = k + 1; j < n; ++j) A[(size_t)j * n + i] -= f * A[(size_t)j * n + k];
+            b[i] -= f * b[k];
+        }
+    }
+    for (int k = n - 1; k >= 0; --k) {
+        if (dead[k]) { b[k] = 0; continue; }
+        zc sres = b[k];
+        for (int j = k + 1; j < n; ++j) sres -= A[(size_t)j * n + k] * b[j];
+        b[k] = sres / A[(size_t)k * n + k];
+    }
+}
+
+static void rb_d2h(wae_family *h, const cplx *src, cplx *dst, size_t cnt) {
+    HIP_CHECK(hipMemcpyAsync(dst, src, cnt * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+}
+
+// start an empty basis on the store Q (cap snapshots of d x l); kact = terms with a non-zero coefficient in `table`
+static void rb_reset(wae_family *h, cplx *Q, int cap, int l, const double *table, int npts, const cplx *Vinter) {
+    RbState &R = h->rb;
+    const int T = h->T;
+    R.Q = Q; R.cap = cap; R.l = l; R.S = 0;
+    R.kact.clear();
+    for (int k = 0; k < T; ++k) {
+        bool used = false;
+        for (int p = 0; p < npts && !used; ++p) used = table[((size_t)p * T + k) * 2] != 0.0 || table[((size_t)p * T + k) * 2 + 1] != 0.0;
+        if (used) R.kact.push_back(k);
+    }
+    const size_t vecl = (size_t)h->d * l;
+    if (R.W.n < R.kact.size() * (size_t)cap * vecl) R.W.alloc(R.kact.size() * (size_t)cap * vecl);
+    R.Hk.assign(R.kact.size() * (size_t)cap * cap * l, zc(0));
+    R.g.assign((size_t)cap * l, zc(0));
+    if (R.Vi.n < vecl) R.Vi.alloc(vecl);
+    HIP_CHECK(hipMemcpyAsync(R.Vi.p, Vinter, vecl * sizeof(cplx), hipMemcpyDeviceToDevice, h->stream));
+    if (R.hb.n < (size_t)2 * cap * l) R.hb.alloc((size_t)2 * cap * l);
+    if (R.alpha.n < (size_t)l) R.alpha.alloc(l);
+}
+
+// the store slots S .. S+count-1 hold new raw vectors: orthonormalise them per column against the basis (classical
+// Gram-Schmidt, two passes), then extend  g = Q^H V  and every projected term  H_k = Q^H A_k Q  by the new rows/columns.
+// W_k = A_k Q stays resident (HBM is plentiful: C2 6.5 GB, C3 16 GB), so a new row costs dot products only.
+static void rb_append(wae_family *h, int count) {
+    RbState &R = h->rb;
+    hipStream_t st = h->stream;
+    const int64_t d = h->d;
+    const int l = R.l, cap = R.cap;
+    const size_t vecl = (size_t)d * l;
+    WAE_REQUIRE(R.S + count <= cap, "snapshot store is full");
+    std::vector<cplx> hh((size_t)cap * l), n0(l), n1(l);
+    const OpDev A0 = h->ops[0].dev(WAE_OP_N);
+    std::vector<std::vector<std::vector<zc>>> pck(R.kact.size());
+    for (size_t ki = 0; ki < R.kact.size(); ++ki) {
+        std::vector<double> ek((size_t)2 * h->T, 0.0);
+        ek[(size_t)2 * R.kact[ki]] = 1.0;
+        pck[ki].resize(1);
+        plane_coeffs(h, ek.data(), WAE_OP_N, pck[ki][0]);
+    }
+    for (int s = R.S; s < R.S + count; ++s) {
+        cplx *q = R.Q + (size_t)s * vecl;
+        launch_norms(q, d, l, h->partial.p, R.hb.p, st);
+        rb_d2h(h, R.hb.p, n0.data(), l);
+        for (int pass = 0; pass < 2 && s > 0; ++pass) {
+            launch_dots(R.Q, vecl, s, q, d, l, h->partial.p, R.hb.p, st);
+            launch_axpy_neg(R.Q, vecl, s, R.hb.p, q, d, l, st);
+        }
+        launch_norms(q, d, l, h->partial.p, R.hb.p, st);
+        rb_d2h(h, R.hb.p, n1.data(), l);
+        for (int c = 0; c < l; ++c)             // a snapshot that adds nothing to a column's span is zeroed there
+            n1[c] = (n1[c].x > 1e-9 * n0[c].x && n0[c].x > 0.0) ? cplx{n1[c].x, 0.0} : cplx{0.0, 0.0};
+        R.alpha.upload(n1.data(), l, st);
+        launch_scale_inv(q, R.alpha.p, q, d, l, st);
+        launch_dots(q, 0, 1, R.Vi.p, d, l, h->partial.p, R.hb.p, st);
+        rb_d2h(h, R.hb.p, hh.data(), l);
+        for (int c = 0; c < l; ++c) R.g[(size_t)s * l + c] = zc(hh[c].x, hh[c].y);
+        for (size_t ki = 0; ki < R.kact.size(); ++ki) {
+            cplx *Wk = R.W.p + ki * (size_t)cap * vecl;
+            cplx *w = Wk + (size_t)s * vecl;
+            upload_pc(h, pck[ki]);
+            launch_spmv(A0, pc_level(h, 0), l, q, w, nullptr, 0.0, l, MODE_AX, st);
+            launch_dots(R.Q, vecl, s + 1, w, d, l, h->partial.p, R.hb.p, st);          // column s: q_i^H A_k q_s, i <= s
+            rb_d2h(h, R.hb.p, hh.data(), (size_t)(s + 1) * l);
+            zc *H = &R.Hk[ki * (size_t)cap * cap * l];
+            for (int i = 0; i <= s; ++i)
+                for (int c = 0; c < l; ++c) H[((size_t)s * cap + i) * l + c] = zc(hh[(size_t)i * l + c].x, hh[(size_t)i * l + c].y);
+            if (s > 0) {
+                launch_dots(Wk, vecl, s, q, d, l, h->partial.p, R.hb.p, st);           // (A_k q_i)^H q_s = conj(row s), i < s
+                rb_d2h(h, R.hb.p, hh.data(), (size_t)s * l);
+                for (int i = 0; i < s; ++i)
+                    for (int c = 0; c < l; ++c) H[((size_t)i * cap + s) * l + c] = zc(hh[(size_t)i * l + c].x, -hh[(size_t)i * l + c].y);
+            }
+        }
+    }
+    R.S += count;
+}
+
+// Xs[row][sy*l + c] = Q_c (sum_k c_k(z_sy) Q_c^H A_k Q_c)^{-1} Q_c^H v_c : Galerkin guesses of one chunk
+static void rb_guess(wae_family *h, const double *ct_chunk, int ns, cplx *X) {
+    RbState &R = h->rb;
+    const int S = R.S, l = R.l, cap = R.cap, T = h->T, nb = ns * l;
+    std::vector<cplx> Y((size_t)S * nb);
+    std::vector<zc> Hs((size_t)S * S), rhs(S);
+    for (int sy = 0; sy < ns; ++sy) {
+        const double *ct = ct_chunk + (size_t)sy * 2 * T;
+        for (int k = 0; k < T; ++k)
+            if ((ct[2 * k] != 0.0 || ct[2 * k + 1] != 0.0) && std::find(R.kact.begin(), R.kact.end(), k) == R.kact.end())
+                throw WaeError(WAE_ERR_INVALID, "a term outside the projected set has a non-zero coefficient: rebuild the basis (mode 1)");
+        for (int c = 0; c < l; ++c) {
+            std::fill(Hs.begin(), Hs.end(), zc(0));
+            for (size_t ki = 0; ki < R.kact.size(); ++ki) {
+                const zc ck(ct[2 * R.kact[ki]], ct[2 * R.kact[ki] + 1]);
+                if (ck == zc(0)) continue;
+                const zc *H = &R.Hk[ki * (size_t)cap * cap * l];
+                for (int sc = 0; sc < S; ++sc)
+                    for (int i = 0; i < S; ++i) Hs[(size_t)sc * S + i] += ck * H[((size_t)sc * cap + i) * l + c];
+            }
+            for (int i = 0; i < S; ++i) rhs[i] = R.g[(size_t)i * l + c];
+            small_solve(Hs, rhs, S);
+            for (int i = 0; i < S; ++i) {
+                const zc yv = std::isfinite(rhs[i].real()) && std::isfinite(rhs[i].imag()) ? rhs[i] : zc(0);
+                Y[(size_t)i * nb + (size_t)sy * l + c] = cplx{yv.real(), yv.imag()};
+            }
+        }
+    }
+    R.ycoef.upload(Y.data(), Y.size(), h->stream);
+    launch_lincomb_rep(R.Q, (size_t)h->d * l, S, R.ycoef.p, X, h->d, nb, l, h->stream);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+}
+
 // ----------------------------------------------------------------------------------------------------
 // Kelleher's accelerated ascending-composition generator (same order as perturbation.jl:2-80)
 template <class F> static void for_each_partition(int n, F &&f) {
@@ -790,8 +1028,34 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
         std::vector<zc> pc;
         plane_coeffs(h, coeffs_ref, WAE_OP_N, pc);
         std::vector<AmgLevel> lv;
-        amg_setup(h->planes0, pc, ao, lv);
+        std::vector<char> pen;
+        amg_setup(h->planes0, pc, ao, lv, &pen);
         hipStream_t st = h->stream;
+        {   // the penalty rows' own sub-block, plane by plane (compact numbering)
+            std::vector<int> rows, loc(pen.size(), -1);
+            for (size_t i = 0; i < pen.size(); ++i)
+                if (pen[i]) { loc[i] = (int)rows.size(); rows.push_back((int)i); }
+            h->n_penalty = (int64_t)rows.size();
+            if (!rows.empty()) {
+                std::vector<CsrZ> sub(h->planes0.size());
+                for (size_t q = 0; q < h->planes0.size(); ++q) {
+                    const CsrZ &A = h->planes0[q];
+                    CsrZ &B = sub[q];
+                    B.n = B.m = (int64_t)rows.size();
+                    B.ptr.assign(rows.size() + 1, 0);
+                    for (size_t i = 0; i < rows.size(); ++i) {
+                        for (int pp = A.ptr[rows[i]]; pp < A.ptr[rows[i] + 1]; ++pp)
+                            if (loc[A.col[pp]] >= 0) { B.col.push_back(loc[A.col[pp]]); B.val.push_back(A.val[pp]); }
+                        B.ptr[i + 1] = (int)B.col.size();
+                    }
+                }
+                h->pen_slot = build_levelop(h->pen_op, sub, st);
+                h->pen_rows.upload(rows.data(), rows.size(), st);
+                const size_t cnt = rows.size() * (size_t)h->NB;
+                h->pen_b.alloc(cnt); h->pen_x.alloc(cnt); h->pen_t.alloc(cnt);
+                HIP_CHECK(hipStreamSynchronize(st));
+            }
+        }
         h->ops.resize(lv.size() + 1);
         h->slot_plane.resize(lv.size() + 1);
         h->xfer.resize(lv.size());
@@ -858,11 +1122,11 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
 }
 
 // solve a chunk of nb columns already on device in interleaved layout
-static void solve_chunk(wae_family *h, const Batch &bt, const std::vector<std::vector<zc>> &pcs, const cplx *B, cplx *X, double tol, int maxit,
-                        wae_solve_info *info, const cplx *guess_dir = nullptr) {
+static int solve_chunk(wae_family *h, const Batch &bt, const std::vector<std::vector<zc>> &pcs, const cplx *B, cplx *X, double tol, int maxit,
+                       wae_solve_info *info, const cplx *guess_dir = nullptr, bool have_x0 = false) {
     upload_pc(h, pcs);
     dense_setup(h, bt);
-    gmres(h, bt, B, X, tol, maxit, info, guess_dir);
+    return gmres(h, bt, B, X, tol, maxit, info, guess_dir, have_x0);
 }
 
 int wae_solve_guess(wae_family *h, const double *coeffs, int32_t ncoef, const double *B, const double *Gd, double *X, int32_t r, int32_t op,
@@ -961,6 +1225,104 @@ int wae_beyn_moments(wae_family *h, int32_t npts, const double *z, const double 
             solve_chunk(h, bt, pcs, h->Bs.p, h->Xs.p, tol, maxit, &li);
             launch_beyn_accum(h->Xs.p, bt.nb, d, l, ns, h->zw_dev.p, h->zw_dev.p + ns, npow, Ad, st);
         }
+        if (A_out) HIP_CHECK(hipMemcpyAsync(A_out, Ad, acnt * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        Aown.release();
+        li.seconds = now_s() - t0;
+        const int rc_ = info_code(li);
+        if (info) *info = li;
+        return rc_;
+    });
+}
+
+int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const double *w, const double *coeff_table, const double *V, int32_t l, int32_t K,
+                        double tol, int32_t maxit, int32_t mode, int32_t nbasis, int32_t slot0, uint64_t Q_dev, double *A_out, uint64_t out_dev,
+                        int32_t accumulate, wae_solve_info *info) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && npts >= 0 && (npts == 0 || (z && w && coeff_table)) && V && l > 0 && K > 0, "bad argument");
+        WAE_REQUIRE(A_out || out_dev, "no output buffer");
+        WAE_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (take snapshots), 1 (rebuild the basis from the store, use it) or 2 (use it)");
+        WAE_REQUIRE(nbasis >= 0 && slot0 >= 0 && (mode == 2 || slot0 + (mode == 0 ? npts : 0) <= nbasis), "snapshot slots out of range");
+        WAE_REQUIRE(!accumulate || out_dev, "accumulate needs a device-resident moment buffer");
+        require_solver(h);
+        WAE_REQUIRE(l <= h->NB, "l exceeds the solver batch width");
+        HIP_CHECK(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        wae_solve_info li;
+        memset(&li, 0, sizeof(li));
+        const double t0 = now_s();
+        const int64_t d = h->d;
+        const int npow = 2 * K;
+        const size_t acnt = (size_t)d * l * npow;
+        const size_t vecl = (size_t)d * l;
+        const int T = h->T;
+        RbState &R = h->rb;
+        DevBuf<cplx> Aown;
+        cplx *Ad = (cplx *)(uintptr_t)out_dev;
+        if (!Ad) { Aown.alloc(acnt); Ad = Aown.p; }
+        if (!accumulate) launch_fill_zero(Ad, acnt, st);
+        cplx *Q = (cplx *)(uintptr_t)Q_dev;
+        if (!Q) {                                    // library-owned snapshot store (single-process use)
+            if (mode == 0 && slot0 == 0 && h->rbQ.n < vecl * (size_t)nbasis) h->rbQ.alloc(vecl * (size_t)nbasis);
+            WAE_REQUIRE(h->rbQ.n >= vecl * (size_t)nbasis, "no snapshots stored in the handle: run mode 0 first");
+            Q = h->rbQ.p;
+        }
+        ensure(h->io_a, vecl);
+        HIP_CHECK(hipMemcpyAsync(h->io_a.p, V, vecl * sizeof(cplx), hipMemcpyHostToDevice, st));
+        const int spc = std::max(1, h->NB / l);   // systems per chunk
+        ensure(h->zw_dev, (size_t)2 * spc);
+        if (R.ycoef.n < (size_t)std::max(nbasis, 1) * h->NB) R.ycoef.alloc((size_t)std::max(nbasis, 1) * h->NB);
+
+        static const bool rbdbg = getenv("WAE_GMRES_DEBUG") && atoi(getenv("WAE_GMRES_DEBUG"));
+        // adaptive enrichment is off by default: on the C2 contour the orthogonalisation and projection of the extra
+        // vectors cost more than the iterations they saved (measured with thresholds 3, 6, 9); WAE_RB_ENRICH=<its> enables
+        static const int enrich_its = getenv("WAE_RB_ENRICH") ? atoi(getenv("WAE_RB_ENRICH")) : (1 << 30);
+        double t_guess = 0.0, t_solve = 0.0, t_append = 0.0;
+        if ((mode == 0 && slot0 == 0) || mode == 1) {
+            launch_colmajor_to_inter(h->io_a.p, d, l, h->W.p, l, st);
+            rb_reset(h, Q, nbasis, l, coeff_table, npts, h->W.p);
+            if (mode == 1) rb_append(h, slot0);    // the store holds slot0 raw snapshots (e.g. all-gathered)
+        } else {
+            WAE_REQUIRE(R.Q == Q && R.l == l && R.cap == nbasis, "the basis in the handle belongs to another store / shape");
+            WAE_REQUIRE(mode != 0 || slot0 == R.S, "mode 0 appends: slot0 must equal the number of snapshots taken so far");
+            WAE_REQUIRE(mode != 2 || R.S > 0, "mode 2 needs a basis: run mode 0 (or 1) first");
+        }
+
+        for (int p0 = 0; p0 < npts; p0 += spc) {
+            const int ns = std::min(spc, npts - p0);
+            Batch bt;
+            bt.nb = ns * l; bt.cps = l; bt.nsys = ns; bt.op = WAE_OP_N;
+            std::vector<std::vector<zc>> pcs(ns);
+            std::vector<cplx> zw(2 * ns);
+            for (int s = 0; s < ns; ++s) {
+                plane_coeffs(h, coeff_table + (size_t)(p0 + s) * 2 * T, WAE_OP_N, pcs[s]);
+                zw[s] = cplx{w[2 * (p0 + s)], w[2 * (p0 + s) + 1]};
+                zw[ns + s] = cplx{z[2 * (p0 + s)], z[2 * (p0 + s) + 1]};
+            }
+            h->zw_dev.upload(zw.data(), zw.size(), st);
+            HIP_CHECK(hipStreamSynchronize(st));
+            launch_replicate(h->io_a.p, d, l, h->Bs.p, bt.nb, st);
+            const bool guess = R.S > 0;            // mode 0 is progressive: later snapshot chunks start from the earlier ones
+            const double ta = now_s();
+            if (guess) rb_guess(h, coeff_table + (size_t)p0 * 2 * T, ns, h->Xs.p);
+            const double tb = now_s();
+            const int its = solve_chunk(h, bt, pcs, h->Bs.p, h->Xs.p, tol, maxit, &li, nullptr, guess);
+            launch_beyn_accum(h->Xs.p, bt.nb, d, l, ns, h->zw_dev.p, h->zw_dev.p + ns, npow, Ad, st);
+            if (rbdbg) HIP_CHECK(hipStreamSynchronize(st));
+            const double tc = now_s();
+            // mode 0 keeps every solution; modes 1/2 enrich the basis where the guesses were poor (a region of the
+            // contour close to poles outside it), as long as the store has room
+            if (mode == 0 || (its > enrich_its && R.S + ns <= R.cap)) {
+                for (int s = 0; s < ns; ++s)
+                    launch_extract_cols(h->Xs.p, bt.nb, s * l, l, Q + (size_t)(R.S + s) * vecl, d, st);
+                rb_append(h, ns);
+            }
+            if (rbdbg) {
+                HIP_CHECK(hipStreamSynchronize(st));
+                t_guess += tb - ta; t_solve += tc - tb; t_append += now_s() - tc;
+            }
+        }
+        if (rbdbg) fprintf(stderr, "[rb] mode=%d S=%d guess %.3f s  solve %.3f s  append %.3f s\n", mode, R.S, t_guess, t_solve, t_append);
         if (A_out) HIP_CHECK(hipMemcpyAsync(A_out, Ad, acnt * sizeof(cplx), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         Aown.release();

@@ -168,6 +168,12 @@ void launch_colmajor_to_inter(const cplx *Xc, int64_t d, int r, cplx *Xi, int nb
 void launch_inter_to_colmajor(const cplx *Xi, int nb, int64_t d, int r, cplx *Xc, hipStream_t s);
 // replicate V (col-major d x l) into an interleaved block: column b -> V[:, b % l]
 void launch_replicate(const cplx *Vc, int64_t d, int l, cplx *Xi, int nb, hipStream_t s);
+// snapshot-basis helpers: one system's l columns out of a batch; X = sum_i y[i][b] Q_i[row][b % l]; zero selected columns
+void launch_gather_rows(const cplx *X, const int *rows, int64_t nrows, int nb, cplx *out, hipStream_t s);
+void launch_scatter_add_rows(const cplx *D, const int *rows, int64_t nrows, int nb, cplx *X, hipStream_t s);
+void launch_extract_cols(const cplx *X, int nb, int off, int l, cplx *out, int64_t n, hipStream_t s);
+void launch_lincomb_rep(const cplx *Q, size_t stride, int nv, const cplx *y, cplx *X, int64_t n, int nb, int l, hipStream_t s);
+void launch_mask_cols(cplx *X, const cplx *keep, int64_t n, int nb, hipStream_t s);
 // Beyn accumulation: A[(p*l+c)*d + row] += sum_s w[s] z[s]^p X[row][s*l+c], s < nsys, p < npow
 void launch_beyn_accum(const cplx *Xi, int nb, int64_t d, int l, int nsys, const cplx *w, const cplx *z, int npow, cplx *A, hipStream_t s);
 // X[row][t] = sum_i G[i][t] V_i[row], V_i = V + i*stride (single vectors), X interleaved with leading dimension T

@@ -63,15 +63,55 @@ def coefficient_table(L, zs):
         L.active, L.mode = saved_active, saved_mode
 
 
-def compute_moment_matrices(L, G, V=None, l=5, K=1, N=16, points=None, out_dev=0):
-    """beyn.jl:233-268.  ``points=(z, w)`` overrides the contour (used to shard the quadrature over GPUs)."""
+def snapshot_split(n, S):
+    """indices of S snapshot points spread evenly through a list of n quadrature points, and the remaining indices"""
+    S = int(min(S, n))
+    idx = np.unique(((np.arange(S) + 0.5) * n / max(S, 1)).astype(int)) if S > 0 else np.zeros(0, dtype=int)
+    rest = np.setdiff1d(np.arange(n), idx)
+    return idx, rest
+
+
+def spread_order(idx):
+    """bit-reversal-like order: every prefix of the list covers the whole contour (the snapshot solves are progressive:
+    each chunk starts from the projection on the chunks before it)"""
+    idx = list(idx)
+    n = len(idx)
+    if n < 3:
+        return np.asarray(idx, dtype=int)
+    bits = max(1, int(np.ceil(np.log2(n))))
+    key = [int(format(i, f"0{bits}b")[::-1], 2) for i in range(n)]
+    return np.asarray([idx[i] for i in np.argsort(key, kind="stable")], dtype=int)
+
+
+def compute_moment_matrices(L, G, V=None, l=5, K=1, N=16, points=None, out_dev=0, rb=None):
+    """beyn.jl:233-268.  ``points=(z, w)`` overrides the contour (used to shard the quadrature over GPUs).
+
+    ``rb`` = number of snapshot points (default ``L.rb_snapshots``; 0 = every system from a zero guess): the solutions
+    at ``rb`` points spread along the contour are kept in HBM, all other points start from their Galerkin projection on
+    those (wae_beyn_moments_rb); same moments to the inner tolerance, several times fewer Krylov iterations."""
     d = L.size()
     if V is None:
         V = initialize_V(d, l)
     zs, ws = gauss_points(G, N) if points is None else points
+    zs, ws = np.asarray(zs), np.asarray(ws)
     fam = L.ensure_solver()
     ct = coefficient_table(L, zs) if len(zs) else np.zeros((0, len(L.terms)), dtype=np.complex128)
-    return fam.beyn_moments(zs, ws, ct, V, K=K, tol=L.solver_tol, maxit=L.solver_maxit, out_dev=out_dev)
+    rb = getattr(L, "rb_snapshots", 0) if rb is None else rb
+    if not rb or len(zs) < 2 * rb:
+        return fam.beyn_moments(zs, ws, ct, V, K=K, tol=L.solver_tol, maxit=L.solver_maxit, out_dev=out_dev)
+    idx, rest = snapshot_split(len(zs), rb)
+    idx = spread_order(idx)
+    kw = dict(K=K, tol=L.solver_tol, maxit=L.solver_maxit, out_dev=out_dev)
+    cap = len(idx) + getattr(L, "rb_extra", 0)              # room for adaptive enrichment (WAE_RB_ENRICH)
+    A0 = fam.beyn_moments_rb(zs[idx], ws[idx], ct[idx], V, 0, cap, **kw)
+    i0 = dict(fam.last_info)
+    A1 = fam.beyn_moments_rb(zs[rest], ws[rest], ct[rest], V, 2, cap, accumulate=bool(out_dev), **kw)
+    i1 = fam.last_info
+    fam.last_info = {"iters_max": max(i0["iters_max"], i1["iters_max"]), "iters_total": i0["iters_total"] + i1["iters_total"],
+                     "n_unconverged": i0["n_unconverged"] + i1["n_unconverged"], "levels": i1["levels"],
+                     "relres_max": max(i0["relres_max"], i1["relres_max"]), "seconds": i0["seconds"] + i1["seconds"],
+                     "snapshot_iters": i0["iters_total"], "projected_iters": i1["iters_total"], "snapshots": len(idx)}
+    return None if out_dev else A0 + A1
 
 
 def moments2eigs(A_list, tol_sigma=0.0, return_sigma=False):

@@ -59,6 +59,72 @@ def beyn_moments_distributed(G, N, shape, moment_fn):
     return buf.cpu().numpy().view(np.complex128).reshape(shape, order="F")
 
 
+def beyn_moments_distributed_rb(L, G, V, K, N, S, timings=None, extra=None):
+    """Sharded moments with snapshot-projection initial guesses (wae_beyn_moments_rb).  Two exchange steps:
+    (1) the S snapshot points are dealt round-robin, every rank solves its share from a zero guess, and the raw
+    solutions (S x d x l) are all-gathered so that every rank holds the same snapshot store; (2) the remaining points
+    are dealt round-robin and start from the projection on that store; the partial moments are summed with one
+    all-reduce.  Returns the flat float64 CUDA tensor of the column-major d x l x 2K moments (on every rank) and the
+    solver statistics of this rank."""
+    import time
+
+    import torch
+    rank, world = rank_world()
+    d, l = V.shape
+    dev = torch.device("cuda", L.device_id)
+    zs, ws = gauss_points(G, N)
+    S = min(int(S), len(zs))
+    S = max(world, (S // world) * world)                      # equal snapshot shares (all_gather wants equal sizes)
+    from .beyn import coefficient_table, snapshot_split, spread_order
+    idx, rest = snapshot_split(len(zs), S)
+    idx = spread_order(idx)
+    S = len(idx)
+    fam = L.ensure_solver()
+    ct = coefficient_table(L, zs)
+    mine = idx[rank::world]
+    per = len(mine)
+    buf = torch.zeros(d * l * 2 * K * 2, dtype=torch.float64, device=dev)
+    cap = S + (0 if extra is None else int(extra))            # optional room for adaptive enrichment (WAE_RB_ENRICH)
+    store = torch.empty(cap * d * l * 2, dtype=torch.float64, device=dev)
+    local = store if world == 1 else torch.empty(per * d * l * 2, dtype=torch.float64, device=dev)
+    kw = dict(K=K, tol=L.solver_tol, maxit=L.solver_maxit, out_dev=buf.data_ptr())
+    t0 = time.perf_counter()
+    fam.beyn_moments_rb(zs[mine], ws[mine], ct[mine], V, 0, cap if world == 1 else per, Q_dev=local.data_ptr(), **kw)
+    i0 = dict(fam.last_info)
+    t1 = time.perf_counter()
+    dd = _dist()
+    if world > 1:
+        torch.cuda.synchronize(dev)
+        if dd.get_backend() == "nccl":
+            dd.all_gather_into_tensor(store[:S * d * l * 2], local)          # RCCL over xGMI, device to device
+        else:                                                # gloo rehearsal on one box: through the host
+            parts = [torch.empty(local.numel(), dtype=torch.float64) for _ in range(world)]
+            dd.all_gather(parts, local.cpu())
+            store[:S * d * l * 2].copy_(torch.cat(parts))
+        torch.cuda.synchronize(dev)
+    t2 = time.perf_counter()
+    mine2 = rest[rank::world]
+    # one rank: the progressive basis built while taking the snapshots is complete (mode 2); several ranks: rebuild it
+    # from the gathered store (mode 1)
+    fam.beyn_moments_rb(zs[mine2], ws[mine2], ct[mine2], V, 2 if world == 1 else 1, cap, slot0=0 if world == 1 else S,
+                        Q_dev=store.data_ptr(), accumulate=True, **kw)
+    i1 = dict(fam.last_info)
+    t3 = time.perf_counter()
+    allreduce_sum_(buf)
+    if world > 1:
+        torch.cuda.synchronize(dev)
+    t4 = time.perf_counter()
+    if timings is not None:
+        for k, v in (("snapshots", t1 - t0), ("allgather", t2 - t1), ("projected", t3 - t2), ("allreduce", t4 - t3)):
+            timings[k] = timings.get(k, 0.0) + v
+    info = {"iters_max": max(i0["iters_max"], i1["iters_max"]), "iters_total": i0["iters_total"] + i1["iters_total"],
+            "n_unconverged": i0["n_unconverged"] + i1["n_unconverged"], "levels": i1["levels"],
+            "relres_max": max(i0["relres_max"], i1["relres_max"]), "seconds": i0["seconds"] + i1["seconds"],
+            "snapshot_iters": i0["iters_total"], "projected_iters": i1["iters_total"], "snapshots": S,
+            "snapshot_columns": per * l, "projected_columns": len(mine2) * l}
+    return buf, info
+
+
 def beyn_distributed(L, G, l=5, K=1, N=16, V=None, pos_test_=True):
     """Ω, P, Σ of `beyn` (beyn.jl:34-110) with the quadrature sharded over the process group."""
     d = L.size()

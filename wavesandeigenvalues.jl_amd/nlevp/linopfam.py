@@ -182,6 +182,27 @@ class DeviceFamily:
         self.last_code = code
         return A
 
+    def beyn_moments_rb(self, z, w, coeff_table, V, mode, nbasis, slot0=0, Q_dev=0, K=1, tol=1e-10, maxit=300, out_dev=0,
+                        accumulate=False):
+        """wae_beyn_moments_rb: mode 0 solves the points and stores their solutions as snapshots, mode 1 starts every
+        system from the Galerkin projection on the snapshot basis (include/waehip.h)."""
+        z = np.ascontiguousarray(z, dtype=np.complex128)
+        w = np.ascontiguousarray(w, dtype=np.complex128)
+        ct = np.ascontiguousarray(coeff_table, dtype=np.complex128).reshape(len(z), self.T)
+        Vf = np.asfortranarray(np.asarray(V, dtype=np.complex128))
+        l = Vf.shape[1]
+        info = SolveInfo()
+        A, aptr = None, None
+        if not out_dev:
+            A = np.zeros((self.d, l, 2 * K), dtype=np.complex128, order="F")
+            aptr = zptr(A)
+        code = check(_lib.lib().wae_beyn_moments_rb(self.handle, len(z), zptr(z), zptr(w), zptr(ct), zptr(Vf), l, K, tol, maxit,
+                                                    int(mode), int(nbasis), int(slot0), int(Q_dev), aptr, int(out_dev),
+                                                    1 if accumulate else 0, C.byref(info)))
+        self.last_info = info.as_dict()
+        self.last_code = code
+        return A
+
     def arnoldi(self, coeffsA, coeffsM, m, v0, op=OP_N, tol=1e-12, maxit=300):
         cA = np.ascontiguousarray(coeffsA, dtype=np.complex128)
         cM = np.ascontiguousarray(coeffsM, dtype=np.complex128)
@@ -279,6 +300,7 @@ class LinearOperatorFamily:
         self.solver_opts = {}
         self.solver_ref = None          # reference value of the eigenvalue parameter for the multigrid set-up
         self.solver_ref_coeffs = None   # or: explicit reference coefficients (one per term) for the set-up
+        self.rb_snapshots = 0           # Beyn: number of snapshot points for projected initial guesses (0 = off)
 
     # -- term management -------------------------------------------------------------------------------
     def push(self, T):
