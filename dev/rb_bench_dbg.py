@@ -28,7 +28,7 @@ for rb in (0, 32):
     print("rb", rb, "Om/2pi", np.round(Om / 2 / np.pi, 3))
     Om = Om[mask]
     P = np.asfortranarray(Pd[:, torch.from_numpy(mask).to(Pd.device)].cpu().numpy())
-    r = bench.residuals(L, Om, P)
+    r = fam.eig_residuals(np.array([L.coefficients(w) for w in Om]), P=P)
     print("rb", rb, "inside", np.round(Om / 2 / np.pi, 3), "res", r, flush=True)
     # host cross-check of the first eigenpair's residual, and of the moments themselves
     T = pb["terms"]

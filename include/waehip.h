@@ -132,6 +132,13 @@ int wae_beyn_moments(wae_family *h, int32_t npts, const double *z, const double 
                      const double *V, int32_t l, int32_t K, double tol, int32_t maxit, double *A_out,
                      uint64_t out_dev, wae_solve_info *info);
 
+/* -- residual check of eigenpairs (the last step of `beyn`'s callers: which Ritz pairs are eigenpairs) --------------
+ * res_out[j] = || sum_k c_jk A_k v_j || / sum_k |c_jk| || A_k v_j ||   for the n pairs (coeff_table: n x T complex, row j =
+ * the coefficients of L(omega_j); v_j = column j of the column-major d x n matrix P on the host, or P_dev on the device).
+ * This componentwise-scaled backward error is meaningful in the presence of penalty rows (1e15-sized admittance entries,
+ * src/Helmholtz.jl:151-156), where ||L(omega) v|| / ||v|| is not. */
+int wae_eig_residuals(wae_family *h, int32_t n, const double *coeff_table, const double *P, uint64_t P_dev, double *res_out);
+
 /* -- Beyn moments with snapshot-projection initial guesses -----------------------------------------------------
  * The solutions X(z) = L(z)^{-1} V along a contour form a low-dimensional manifold (a handful of poles near the
  * contour plus a smooth part) -- the observation behind the reference's `generate_subspace`/`project`

@@ -445,3 +445,23 @@ def test_beyn_moments_with_projected_guesses_match_plain_and_oracle():
     A2 = buf.cpu().numpy().view(np.complex128).reshape((d, l, 2), order="F")
     assert relerr(A2, A0) < 1e-8
     Lp._drop_device()
+
+
+def test_eig_residuals_entry(rijke):
+    """wae_eig_residuals against the same quantity assembled from the oracle's matrices; host and device inputs."""
+    import torch
+    Lo, Lp = rijke
+    d = Lo.size()
+    fam = Lp.device()
+    P = RNG.standard_normal((d, 5)) + 1j * RNG.standard_normal((d, 5))
+    oms = 2 * np.pi * np.array([200 + 3j, 350 - 8j, 500.0, 710 + 40j, 90 + 1j])
+    C = np.array([Lp.coefficients(w) for w in oms])
+    want = []
+    for j, w in enumerate(oms):
+        cs = Lo.coefficients(w)
+        parts = [ck * (t.coeff @ P[:, j]) for ck, t in zip(cs, Lo.terms) if ck is not None and ck != 0]
+        want.append(np.linalg.norm(sum(parts)) / sum(np.linalg.norm(p) for p in parts))
+    got = fam.eig_residuals(C, P=P)
+    assert np.allclose(got, want, rtol=1e-12)
+    Pt = torch.from_numpy(np.ascontiguousarray(P.T)).to("cuda:0")            # (n, d) row-major == column-major d x n
+    assert np.allclose(fam.eig_residuals(C, P_dev=Pt.data_ptr()), want, rtol=1e-12)

@@ -952,6 +952,58 @@ int wae_spmv_sum_cols(wae_family *h, const double *coeffs, int32_t ncoef, const 
     });
 }
 
+int wae_eig_residuals(wae_family *h, int32_t n, const double *coeff_table, const double *P, uint64_t P_dev, double *res_out) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && n > 0 && coeff_table && (P || P_dev) && res_out, "bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        const int T = h->T;
+        const size_t cnt = (size_t)h->d * n;
+        DevBuf<cplx> xi, yi, pcd, nrm, part;
+        xi.alloc(cnt); yi.alloc(cnt); nrm.alloc((size_t)n); part.alloc((size_t)1024 * n);
+        const cplx *src = (const cplx *)(uintptr_t)P_dev;
+        if (!src) {
+            ensure(h->io_a, cnt);
+            HIP_CHECK(hipMemcpyAsync(h->io_a.p, P, cnt * sizeof(cplx), hipMemcpyHostToDevice, st));
+            src = h->io_a.p;
+        }
+        launch_colmajor_to_inter(src, h->d, n, xi.p, n, st);
+        std::vector<cplx> tab((size_t)n * h->nplanes), hn(n);
+        std::vector<zc> pc;
+        auto pass = [&](int only_term, std::vector<double> &out) {     // norms of (sum_k c_jk A_k v_j), k = all or one term
+            std::vector<double> ck((size_t)2 * T);
+            for (int j = 0; j < n; ++j) {
+                for (int k = 0; k < T; ++k) {
+                    const bool on = only_term < 0 || k == only_term;
+                    ck[2 * k] = on ? coeff_table[((size_t)j * T + k) * 2] : 0.0;
+                    ck[2 * k + 1] = on ? coeff_table[((size_t)j * T + k) * 2 + 1] : 0.0;
+                }
+                plane_coeffs(h, ck.data(), WAE_OP_N, pc);
+                for (int q = 0; q < h->nplanes; ++q) { const zc c = pc[h->slot_plane[0][q]]; tab[(size_t)j * h->nplanes + q] = cplx{c.real(), c.imag()}; }
+            }
+            pcd.upload(tab.data(), tab.size(), st);
+            launch_spmv(h->ops[0].dev(WAE_OP_N), pcd.p, 1, xi.p, yi.p, nullptr, 0.0, n, MODE_AX, st);
+            launch_norms(yi.p, h->d, n, part.p, nrm.p, st);
+            HIP_CHECK(hipMemcpyAsync(hn.data(), nrm.p, (size_t)n * sizeof(cplx), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            out.resize(n);
+            for (int j = 0; j < n; ++j) out[j] = hn[j].x;
+        };
+        std::vector<double> num, one, den(n, 0.0);
+        pass(-1, num);
+        for (int k = 0; k < T; ++k) {
+            bool used = false;
+            for (int j = 0; j < n && !used; ++j) used = coeff_table[((size_t)j * T + k) * 2] != 0.0 || coeff_table[((size_t)j * T + k) * 2 + 1] != 0.0;
+            if (!used) continue;
+            pass(k, one);
+            for (int j = 0; j < n; ++j) den[j] += one[j];
+        }
+        for (int j = 0; j < n; ++j) res_out[j] = num[j] / std::max(den[j], 1e-300);
+        xi.release(); yi.release(); pcd.release(); nrm.release(); part.release();
+        return WAE_OK;
+    });
+}
+
 int wae_spmv_sum(wae_family *h, const double *coeffs, const double *X, double *Y, int32_t r, int32_t op) {
     return wae_spmv_sum_cols(h, coeffs, 1, X, Y, r, op);
 }

@@ -147,7 +147,14 @@ def moments2eigs_device(buf, shape, tol_sigma=0.0):
     A = torch.view_as_complex(buf.view(-1, 2)).view(K2, l, d).permute(2, 1, 0)       # (d, l, 2K) strided view
     B0 = torch.cat([torch.cat([A[:, :, i + j] for j in range(K)], dim=1) for i in range(K)], dim=0)
     B1 = torch.cat([torch.cat([A[:, :, i + j + 1] for j in range(K)], dim=1) for i in range(K)], dim=0)
-    U, S, Wh = torch.linalg.svd(B0, full_matrices=False)
+    if B0.shape[0] > 8 * B0.shape[1]:
+        # tall-skinny: thin QR, then the SVD of the small triangular factor (the same factorisation up to rounding;
+        # rocSOLVER's Jacobi SVD of the d x l matrix itself took 65 ms at d = 2e5, this takes a few)
+        Qf, Rf = torch.linalg.qr(B0)
+        Ur, S, Wh = torch.linalg.svd(Rf)
+        U = Qf @ Ur
+    else:
+        U, S, Wh = torch.linalg.svd(B0, full_matrices=False)
     if tol_sigma > 0:
         m = S > tol_sigma
         U, S, Wh = U[:, m], S[m], Wh[m, :]

@@ -203,6 +203,17 @@ class DeviceFamily:
         self.last_code = code
         return A
 
+    def eig_residuals(self, coeff_table, P=None, P_dev=0):
+        """wae_eig_residuals: ||L(ω_j) v_j|| / Σ_k |c_jk| ||A_k v_j|| for every pair; P (host, d x n) or P_dev (device
+        pointer of the column-major d x n matrix)."""
+        ct = np.ascontiguousarray(coeff_table, dtype=np.complex128)
+        n = ct.shape[0]
+        out = np.zeros(n, dtype=np.float64)
+        Pf = None if P is None else np.asfortranarray(np.asarray(P, dtype=np.complex128))
+        check(_lib.lib().wae_eig_residuals(self.handle, n, zptr(ct), None if Pf is None else zptr(Pf), int(P_dev),
+                                           out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
     def arnoldi(self, coeffsA, coeffsM, m, v0, op=OP_N, tol=1e-12, maxit=300):
         cA = np.ascontiguousarray(coeffsA, dtype=np.complex128)
         cM = np.ascontiguousarray(coeffsM, dtype=np.complex128)
