@@ -734,6 +734,73 @@ static void dots_impl(const cplx *V, size_t stride, int nv, const cplx *W, int64
         done += chunk;
     }
 }
+// block version: partial[blk][i*nw + j][b] = sum over this block's rows of conj(V_i[row][b]) W_j[row][b], j < nw <= NW.
+// Reads V once for NW right-hand vectors (the projected-operator build of the snapshot basis, lib.hip rb_append, is a
+// tall-skinny Gram product: with one w per launch it re-read the whole basis for every new column).
+template <int MAXV, int NW>
+__global__ __launch_bounds__(256) void dots_multi_kernel(const cplx *__restrict__ V, size_t sv, int nv, const cplx *__restrict__ W, size_t sw, int nw,
+                                                         int64_t n, int nb, cplx *__restrict__ partial) {
+    __shared__ cplx sm[256];
+    const int tid = threadIdx.x;
+    const int R = 256 / nb;
+    const int b = tid % nb, rl = tid / nb;
+    cplx acc[MAXV][NW];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+        for (int j = 0; j < NW; ++j) acc[i][j] = cplx{0.0, 0.0};
+    if (rl < R) {
+        for (int64_t row = (int64_t)blockIdx.x * R + rl; row < n; row += (int64_t)gridDim.x * R) {
+            const size_t e = (size_t)row * nb + b;
+            cplx w[NW];
+#pragma unroll
+            for (int j = 0; j < NW; ++j) w[j] = j < nw ? W[(size_t)j * sw + e] : cplx{0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                if (i < nv) {
+                    const cplx v = V[(size_t)i * sv + e];
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) {
+                        acc[i][j].x += v.x * w[j].x + v.y * w[j].y;
+                        acc[i][j].y += v.x * w[j].y - v.y * w[j].x;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            if (i < nv && j < nw) {
+                sm[tid] = acc[i][j];
+                __syncthreads();
+                if (tid < nb) {
+                    cplx s = sm[tid];
+                    for (int k = 1; k < R; ++k) { s.x += sm[k * nb + tid].x; s.y += sm[k * nb + tid].y; }
+                    partial[((size_t)blockIdx.x * nv * nw + (size_t)i * nw + j) * nb + tid] = s;
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+// out[(i*nw + j)*nb + b] = V_i[:,b]^H W_j[:,b]   (nv arbitrary, nw <= 4)
+void launch_dots_multi(const cplx *V, size_t sv, int nv, const cplx *W, size_t sw, int nw, int64_t n, int nb, cplx *partial, cplx *out,
+                       hipStream_t st) {
+    if (nb < 1 || nb > 256 || nw < 1 || nw > 4) throw WaeError(WAE_ERR_INVALID, "dots_multi: nb in 1..256, nw in 1..4");
+    int done = 0;
+    while (done < nv) {
+        const int chunk = std::min(8, nv - done);
+        const int nblk = 768;
+        hipLaunchKernelGGL((dots_multi_kernel<8, 4>), dim3(nblk), dim3(256), 0, st, V + (size_t)done * sv, sv, chunk, W, sw, nw, n, nb, partial);
+        HIP_CHECK(hipGetLastError());
+        const int count = chunk * nw * nb;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((count + 31) / 32), dim3(256), 0, st, partial, nblk, count, out + (size_t)done * nw * nb, 0);
+        HIP_CHECK(hipGetLastError());
+        done += chunk;
+    }
+}
 void launch_dots(const cplx *V, size_t stride, int nv, const cplx *W, int64_t n, int nb, cplx *partial, cplx *out, hipStream_t st,
                  const unsigned char *cmask) {
     dots_impl(V, stride, nv, W, n, nb, partial, out, 0, st, cmask);

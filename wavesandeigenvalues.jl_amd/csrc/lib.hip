@@ -59,7 +59,7 @@ struct RbState {                     // snapshot basis of wae_beyn_moments_rb (o
     std::vector<int> kact;           // terms that take part in the projection
     std::vector<zc> Hk;              // Hk[ki][(s*cap + i)*l + c] = q_i^H A_k q_s   (column c's basis)
     std::vector<zc> g;               // g[i*l + c] = q_i^H v_c
-    DevBuf<cplx> W, Vi, hb, alpha, ycoef;   // W_k = A_k Q (resident), probe columns interleaved, small scratch
+    DevBuf<cplx> W, Vi, hb, alpha, alpha2, ycoef;   // W_k = A_k Q (resident), probe columns interleaved, small scratch
 };
 
 struct wae_family {
@@ -98,7 +98,7 @@ struct wae_family {
     cplx *h_pinned = nullptr;        // (restart+2)*NB
     size_t pc_stride_level = 0;      // elements per level in pcdev
     ~wae_family() {
-        for (auto *b : {&dense_planes, &Ainv, &V, &W, &Z, &Xs, &Bs, &U, &partial, &hdev, &ydev, &pcdev, &one_dev, &io_a, &io_b, &zw_dev, &rbQ, &rb.W, &rb.Vi, &rb.hb, &rb.alpha, &rb.ycoef}) b->release();
+        for (auto *b : {&dense_planes, &Ainv, &V, &W, &Z, &Xs, &Bs, &U, &partial, &hdev, &ydev, &pcdev, &one_dev, &io_a, &io_b, &zw_dev, &rbQ, &rb.W, &rb.Vi, &rb.hb, &rb.alpha, &rb.alpha2, &rb.ycoef}) b->release();
         dstatus.release();
         plane_col_dev.release();
         cmask.release();
@@ -720,22 +720,94 @@ static void rb_reset(wae_family *h, cplx *Q, int cap, int l, const double *table
     R.g.assign((size_t)cap * l, zc(0));
     if (R.Vi.n < vecl) R.Vi.alloc(vecl);
     HIP_CHECK(hipMemcpyAsync(R.Vi.p, Vinter, vecl * sizeof(cplx), hipMemcpyDeviceToDevice, h->stream));
-    if (R.hb.n < (size_t)2 * cap * l) R.hb.alloc((size_t)2 * cap * l);
+    if (R.hb.n < (size_t)4 * (cap + 4) * l) R.hb.alloc((size_t)4 * (cap + 4) * l);
     if (R.alpha.n < (size_t)l) R.alpha.alloc(l);
+    if (R.alpha2.n < (size_t)cap * l) R.alpha2.alloc((size_t)cap * l);
 }
 
 // the store slots S .. S+count-1 hold new raw vectors: orthonormalise them per column against the basis (classical
 // Gram-Schmidt, two passes), then extend  g = Q^H V  and every projected term  H_k = Q^H A_k Q  by the new rows/columns.
-// W_k = A_k Q stays resident (HBM is plentiful: C2 6.5 GB, C3 16 GB), so a new row costs dot products only.
-static void rb_append(wae_family *h, int count) {
+// W_k = A_k Q stays resident (HBM is plentiful: C2 6.5 GB, C3 16 GB), so a new row costs dot products only.  The new
+// vectors are handled four at a time (dots_multi reads the basis once per block): the build is a tall-skinny Gram product.
+static void rb_append_block(wae_family *h, int cnt, const std::vector<std::vector<std::vector<zc>>> &pck) {
     RbState &R = h->rb;
     hipStream_t st = h->stream;
     const int64_t d = h->d;
-    const int l = R.l, cap = R.cap;
+    const int l = R.l, cap = R.cap, S = R.S;
     const size_t vecl = (size_t)d * l;
-    WAE_REQUIRE(R.S + count <= cap, "snapshot store is full");
-    std::vector<cplx> hh((size_t)cap * l), n0(l), n1(l);
+    std::vector<cplx> hh((size_t)(S + cnt) * cnt * l), n0((size_t)cnt * l), n1(l);
     const OpDev A0 = h->ops[0].dev(WAE_OP_N);
+    cplx *qn = R.Q + (size_t)S * vecl;                       // the block of new vectors
+    for (int j = 0; j < cnt; ++j) launch_norms(qn + (size_t)j * vecl, d, l, h->partial.p, R.hb.p + (size_t)j * l, st);
+    rb_d2h(h, R.hb.p, n0.data(), (size_t)cnt * l);
+    // (1) against the existing basis: block classical Gram-Schmidt, two passes
+    for (int pass = 0; pass < 2 && S > 0; ++pass) {
+        launch_dots_multi(R.Q, vecl, S, qn, vecl, cnt, d, l, h->partial.p, R.hb.p, st);       // hb[(i*cnt + j)*l + c]
+        rb_d2h(h, R.hb.p, hh.data(), (size_t)S * cnt * l);
+        std::vector<cplx> cj((size_t)S * l);
+        for (int j = 0; j < cnt; ++j) {
+            for (int i = 0; i < S; ++i)
+                for (int c = 0; c < l; ++c) cj[(size_t)i * l + c] = hh[((size_t)i * cnt + j) * l + c];
+            R.alpha2.upload(cj.data(), cj.size(), st);
+            launch_axpy_neg(R.Q, vecl, S, R.alpha2.p, qn + (size_t)j * vecl, d, l, st);
+            HIP_CHECK(hipStreamSynchronize(st));             // cj is re-filled for the next vector
+        }
+    }
+    // (2) inside the block, vector by vector; normalise (a vector that adds nothing to a column's span is zeroed there)
+    for (int j = 0; j < cnt; ++j) {
+        cplx *q = qn + (size_t)j * vecl;
+        for (int pass = 0; pass < 2 && j > 0; ++pass) {
+            launch_dots(qn, vecl, j, q, d, l, h->partial.p, R.hb.p, st);
+            launch_axpy_neg(qn, vecl, j, R.hb.p, q, d, l, st);
+        }
+        launch_norms(q, d, l, h->partial.p, R.hb.p, st);
+        rb_d2h(h, R.hb.p, n1.data(), l);
+        for (int c = 0; c < l; ++c) {
+            const double nrm0 = n0[(size_t)j * l + c].x;
+            n1[c] = (n1[c].x > 1e-9 * nrm0 && nrm0 > 0.0) ? cplx{n1[c].x, 0.0} : cplx{0.0, 0.0};
+        }
+        R.alpha.upload(n1.data(), l, st);
+        launch_scale_inv(q, R.alpha.p, q, d, l, st);
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    // (3) g = Q^H V for the new vectors
+    launch_dots_multi(qn, vecl, cnt, R.Vi.p, vecl, 1, d, l, h->partial.p, R.hb.p, st);
+    rb_d2h(h, R.hb.p, hh.data(), (size_t)cnt * l);
+    for (int j = 0; j < cnt; ++j)
+        for (int c = 0; c < l; ++c) R.g[(size_t)(S + j) * l + c] = zc(hh[(size_t)j * l + c].x, hh[(size_t)j * l + c].y);
+    // (4) projected terms: new columns (all rows) and new rows (old columns)
+    for (size_t ki = 0; ki < R.kact.size(); ++ki) {
+        cplx *Wk = R.W.p + ki * (size_t)cap * vecl;
+        cplx *wn = Wk + (size_t)S * vecl;
+        upload_pc(h, pck[ki]);
+        for (int j = 0; j < cnt; ++j)
+            launch_spmv(A0, pc_level(h, 0), l, qn + (size_t)j * vecl, wn + (size_t)j * vecl, nullptr, 0.0, l, MODE_AX, st);
+        zc *H = &R.Hk[ki * (size_t)cap * cap * l];
+        launch_dots_multi(R.Q, vecl, S + cnt, wn, vecl, cnt, d, l, h->partial.p, R.hb.p, st);  // q_i^H A_k q_{S+j}, i < S+cnt
+        rb_d2h(h, R.hb.p, hh.data(), (size_t)(S + cnt) * cnt * l);
+        for (int i = 0; i < S + cnt; ++i)
+            for (int j = 0; j < cnt; ++j)
+                for (int c = 0; c < l; ++c) {
+                    const cplx v = hh[((size_t)i * cnt + j) * l + c];
+                    H[((size_t)(S + j) * cap + i) * l + c] = zc(v.x, v.y);
+                }
+        if (S > 0) {
+            launch_dots_multi(Wk, vecl, S, qn, vecl, cnt, d, l, h->partial.p, R.hb.p, st);     // (A_k q_i)^H q_{S+j} = conj(row S+j), i < S
+            rb_d2h(h, R.hb.p, hh.data(), (size_t)S * cnt * l);
+            for (int i = 0; i < S; ++i)
+                for (int j = 0; j < cnt; ++j)
+                    for (int c = 0; c < l; ++c) {
+                        const cplx v = hh[((size_t)i * cnt + j) * l + c];
+                        H[((size_t)i * cap + S + j) * l + c] = zc(v.x, -v.y);
+                    }
+        }
+    }
+    R.S += cnt;
+}
+
+static void rb_append(wae_family *h, int count) {
+    RbState &R = h->rb;
+    WAE_REQUIRE(R.S + count <= R.cap, "snapshot store is full");
     std::vector<std::vector<std::vector<zc>>> pck(R.kact.size());
     for (size_t ki = 0; ki < R.kact.size(); ++ki) {
         std::vector<double> ek((size_t)2 * h->T, 0.0);
@@ -743,42 +815,7 @@ static void rb_append(wae_family *h, int count) {
         pck[ki].resize(1);
         plane_coeffs(h, ek.data(), WAE_OP_N, pck[ki][0]);
     }
-    for (int s = R.S; s < R.S + count; ++s) {
-        cplx *q = R.Q + (size_t)s * vecl;
-        launch_norms(q, d, l, h->partial.p, R.hb.p, st);
-        rb_d2h(h, R.hb.p, n0.data(), l);
-        for (int pass = 0; pass < 2 && s > 0; ++pass) {
-            launch_dots(R.Q, vecl, s, q, d, l, h->partial.p, R.hb.p, st);
-            launch_axpy_neg(R.Q, vecl, s, R.hb.p, q, d, l, st);
-        }
-        launch_norms(q, d, l, h->partial.p, R.hb.p, st);
-        rb_d2h(h, R.hb.p, n1.data(), l);
-        for (int c = 0; c < l; ++c)             // a snapshot that adds nothing to a column's span is zeroed there
-            n1[c] = (n1[c].x > 1e-9 * n0[c].x && n0[c].x > 0.0) ? cplx{n1[c].x, 0.0} : cplx{0.0, 0.0};
-        R.alpha.upload(n1.data(), l, st);
-        launch_scale_inv(q, R.alpha.p, q, d, l, st);
-        launch_dots(q, 0, 1, R.Vi.p, d, l, h->partial.p, R.hb.p, st);
-        rb_d2h(h, R.hb.p, hh.data(), l);
-        for (int c = 0; c < l; ++c) R.g[(size_t)s * l + c] = zc(hh[c].x, hh[c].y);
-        for (size_t ki = 0; ki < R.kact.size(); ++ki) {
-            cplx *Wk = R.W.p + ki * (size_t)cap * vecl;
-            cplx *w = Wk + (size_t)s * vecl;
-            upload_pc(h, pck[ki]);
-            launch_spmv(A0, pc_level(h, 0), l, q, w, nullptr, 0.0, l, MODE_AX, st);
-            launch_dots(R.Q, vecl, s + 1, w, d, l, h->partial.p, R.hb.p, st);          // column s: q_i^H A_k q_s, i <= s
-            rb_d2h(h, R.hb.p, hh.data(), (size_t)(s + 1) * l);
-            zc *H = &R.Hk[ki * (size_t)cap * cap * l];
-            for (int i = 0; i <= s; ++i)
-                for (int c = 0; c < l; ++c) H[((size_t)s * cap + i) * l + c] = zc(hh[(size_t)i * l + c].x, hh[(size_t)i * l + c].y);
-            if (s > 0) {
-                launch_dots(Wk, vecl, s, q, d, l, h->partial.p, R.hb.p, st);           // (A_k q_i)^H q_s = conj(row s), i < s
-                rb_d2h(h, R.hb.p, hh.data(), (size_t)s * l);
-                for (int i = 0; i < s; ++i)
-                    for (int c = 0; c < l; ++c) H[((size_t)i * cap + s) * l + c] = zc(hh[(size_t)i * l + c].x, -hh[(size_t)i * l + c].y);
-            }
-        }
-    }
-    R.S += count;
+    for (int done = 0; done < count; done += 4) rb_append_block(h, std::min(4, count - done), pck);
 }
 
 // Xs[row][sy*l + c] = Q_c (sum_k c_k(z_sy) Q_c^H A_k Q_c)^{-1} Q_c^H v_c : Galerkin guesses of one chunk
