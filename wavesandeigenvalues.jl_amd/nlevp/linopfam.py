@@ -311,7 +311,7 @@ class LinearOperatorFamily:
         self.solver_opts = {}
         self.solver_ref = None          # reference value of the eigenvalue parameter for the multigrid set-up
         self.solver_ref_coeffs = None   # or: explicit reference coefficients (one per term) for the set-up
-        self.rb_snapshots = 0           # Beyn: number of snapshot points for projected initial guesses (0 = off)
+        self.rb_snapshots = None        # Beyn: snapshot points for projected initial guesses (None = automatic, 0 = off)
 
     # -- term management -------------------------------------------------------------------------------
     def push(self, T):
