@@ -333,7 +333,7 @@ static cplx *vcycle(wae_family *h, const Batch &bt, int l, const cplx *b, const 
     // for op = T/C the transfer operators are unchanged (real): (R A P)^H = R A^H P
     launch_spmv(h->xfer[l].devR(), h->one_dev.p, 1 << 30, t, h->lb[l + 1].p, nullptr, 0.0, bt.nb, MODE_AX, st, cm);
     const cplx *xc = vcycle(h, bt, l + 1, h->lb[l + 1].p, cm);
-    launch_spmv(h->xfer[l].devP(), h->one_dev.p, 1 << 30, xc, x, x, 0.0, bt.nb, MODE_ADD, st, cm);
+    launch_prolong_add(h->xfer[l].p_ptr.p, h->xfer[l].p_col.p, h->xfer[l].p_val.p, h->xfer[l].nf, xc, x, bt.nb, st, cm);
     for (int s = 0; s < h->nsweeps; ++s) {
         launch_spmv(A, pc, bt.cps, x, t, b, h->jac_w, bt.nb, MODE_JAC, st, cm);
         std::swap(x, t);

@@ -169,6 +169,9 @@ void launch_inter_to_colmajor(const cplx *Xi, int nb, int64_t d, int r, cplx *Xc
 // replicate V (col-major d x l) into an interleaved block: column b -> V[:, b % l]
 void launch_replicate(const cplx *Vc, int64_t d, int l, cplx *Xi, int nb, hipStream_t s);
 // snapshot-basis helpers: one system's l columns out of a batch; X = sum_i y[i][b] Q_i[row][b % l]; zero selected columns
+// V-cycle prolongation: X += P Xc (P real CSR, n fine rows)
+void launch_prolong_add(const int *ptr, const int *col, const double *val, int64_t n, const cplx *Xc, cplx *X, int nb, hipStream_t s,
+                        const unsigned char *cmask = nullptr);
 // out[(i*nw + j)*nb + b] = V_i[:,b]^H W_j[:,b], nw <= 4: one pass over V for nw right-hand vectors
 void launch_dots_multi(const cplx *V, size_t sv, int nv, const cplx *W, size_t sw, int nw, int64_t n, int nb, cplx *partial, cplx *out,
                        hipStream_t s);
