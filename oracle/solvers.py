@@ -15,6 +15,7 @@ Third-party numerics the reference delegates to and what stands in for them here
 """
 from __future__ import annotations
 
+import copy
 from math import factorial
 
 import numpy as np
@@ -641,3 +642,65 @@ def traceiter(L, z, maxiter=10, tol=0.0, relax=1.0):
         flag = itsol_unknown
     flag = _finish(n, maxiter, z, z0, tol, flag)
     return Solution(L.params, [], [], L.eigval), n, flag
+
+
+# ----------------------------------------------------------------------------------------------
+# reduced-basis helpers  (beyn.jl:429-595)
+# ----------------------------------------------------------------------------------------------
+def _orth_append(Q, x):
+    """next column of the incremental QR (beyn.jl:604-626 builds Householder reflectors; the span of the first k
+    columns is the same for Gram-Schmidt, the column phases differ -- nothing downstream depends on them)."""
+    x = np.array(x, dtype=complex).ravel()
+    for _ in range(2):
+        if Q.shape[1]:
+            x = x - Q @ (Q.conj().T @ x)
+    return np.hstack([Q, (x / np.linalg.norm(x))[:, None]])
+
+
+def generate_subspace(L, Y, tol, Z, include_Y=True):
+    """beyn.jl:429-560: greedy orthonormal basis Q such that the Galerkin solution of L(z) x = y in span(Q) has
+    residual <= tol for every sample point z in Z and every column y of Y.  Returns Q, resnorm."""
+    Y = np.asarray(Y, dtype=complex)
+    d, k = Y.shape
+    Z = list(Z)
+    Q = np.zeros((d, 0), dtype=complex)
+    A0 = L(Z[0])
+    for kk in range(k):
+        Q = _orth_append(Q, Y[:, kk] if include_Y else _solve(A0, Y[:, kk]))
+    resnorm = np.zeros(len(Z) * k)
+    for idx, z in enumerate(Z):
+        if Q.shape[1] == d:
+            break
+        Lz = L(z)
+        QLQ = Q.conj().T @ (Lz @ Q)
+        QY = Q.conj().T @ Y
+        for kk in range(k):
+            X = Q @ np.linalg.solve(QLQ, QY[:, kk])
+            res = np.linalg.norm(Lz @ X - Y[:, kk])
+            if res > tol:
+                Q = _orth_append(Q, _solve(Lz, Y[:, kk]))
+                QLQ = Q.conj().T @ (Lz @ Q)
+                QY = Q.conj().T @ Y
+                X = Q @ np.linalg.solve(QLQ, QY[:, kk])
+                res = np.linalg.norm(Lz @ X - Y[:, kk])
+            resnorm[kk + idx * k] = res
+    return Q, resnorm
+
+
+def generate_subspace_contour(L, Y, tol, G, N, include_Y=True):
+    """beyn.jl:562-577: sample points = N Gauss-Legendre nodes on every edge of the polygon G"""
+    xg, _ = np.polynomial.legendre.leggauss(N)
+    G = list(G)
+    Z = np.concatenate([xg * (G[(i + 1) % len(G)] - G[i]) / 2 + (G[i] + G[(i + 1) % len(G)]) / 2 for i in range(len(G))])
+    return generate_subspace(L, Y, tol, Z, include_Y=include_Y)
+
+
+def project(L, Q):
+    """beyn.jl:579-595: the family P(z) = Q' L(z) Q, term by term"""
+    P = LinearOperatorFamily([L.eigval], [L.params[L.eigval]])
+    P.params = copy.deepcopy(L.params)
+    P.eigval, P.auxval, P.mode, P.active = L.eigval, L.auxval, L.mode, list(L.active)
+    for t in L.terms:
+        M = Q.conj().T @ (t.coeff @ Q)
+        P.push(Term(np.asarray(M), t.func, t.params, t.symbol, t.operator))
+    return P

@@ -1,7 +1,8 @@
 """Public names of the reference's NLEVP module (src/NLEVP_exports.jl:1-17), device-backed."""
 from .algebra import (exp_az, exp_delay, exp_pm, generate_1_gz, generate_exp_az, generate_gz_hz,  # noqa: F401
                       generate_Sigma_y_exp_ikx, generate_z_g_z, pow0, pow1, pow2, pow_, pow_a, tau_delay)
-from .beyn import (beyn, compute_moment_matrices, gauss_points, initialize_V, inpoly, moments2eigs, pos_test, wn)  # noqa: F401
+from .beyn import (beyn, compute_moment_matrices, gauss_points, generate_subspace, initialize_V, inpoly, moments2eigs,
+                   pos_test, project, wn)  # noqa: F401
 from .linopfam import (DeviceFamily, LinearOperatorFamily, Operator, Solution, Term, conv_radius, estimate_pol, pade,  # noqa: F401
                        pade_, poly_roots, polyval)
 from .local_solvers import (count_poles_and_zeros, decode_error_flag, eigs, householder, householder_update, inveriter,  # noqa: F401

@@ -171,3 +171,75 @@ def beyn(L, G, l=5, K=1, N=16, tol=0.0, pos_test_=True, output=False, random=Fal
     if pos_test_:
         Om, P = pos_test(Om, P, G)
     return (Om, P, S) if return_sigma else (Om, P)
+
+
+# ------------------------------------------------------------------------------------------------------
+# reduced-basis helpers  (beyn.jl:395-595)
+# ------------------------------------------------------------------------------------------------------
+def _orth_append(Q, x):
+    """next column of the incremental QR (beyn.jl:604-626 uses Householder reflectors; Gram-Schmidt with
+    re-orthogonalisation spans the same nested subspaces, only the column phases differ)."""
+    x = np.array(x, dtype=np.complex128).ravel()
+    for _ in range(2):
+        if Q.shape[1]:
+            x = x - Q @ (Q.conj().T @ x)
+    return np.hstack([Q, (x / np.linalg.norm(x))[:, None]])
+
+
+def generate_subspace(L, Y, tol, Z, N=None, output=False, tol_err=np.inf, include_Y=True):
+    """Q, resnorm = generate_subspace(L, Y, tol, Z[, N])   (beyn.jl:429-577)
+
+    Greedy orthonormal basis Q such that the Galerkin solution of L(z) x = y in span(Q) has residual <= tol for every
+    sample point z in Z and every column y of Y (with N given, Z is a polygon and N Gauss-Legendre nodes per edge are
+    the sample points).  The exact solves L(z)\\y and the products L(z)·Q run on the device; the small projected
+    solves on the host.  As in the reference the residual is the plain 2-norm of L(z)X - y."""
+    Y = np.asarray(Y, dtype=np.complex128)
+    if Y.ndim == 1:
+        Y = Y[:, None]
+    d, k = Y.shape
+    if N is not None:
+        Z, _ = gauss_points(Z, N)
+    Z = list(Z)
+    Q = np.zeros((d, 0), dtype=np.complex128)
+    A = L(Z[0])
+    first = Y if include_Y else A.solve(Y)
+    for kk in range(k):
+        Q = _orth_append(Q, first[:, kk])
+    resnorm = np.zeros(len(Z) * k)
+    for idx, z in enumerate(Z):
+        if Q.shape[1] == d:
+            break
+        A = L(z)
+        AQ = A @ Q                                    # d x dim on the device, kept and extended column by column
+        QY = Q.conj().T @ Y
+        for kk in range(k):
+            X = Q @ np.linalg.solve(Q.conj().T @ AQ, QY[:, kk])
+            res = np.linalg.norm(A @ X - Y[:, kk])
+            if res > tol:
+                Q = _orth_append(Q, A.solve(Y[:, kk]))
+                AQ = np.hstack([AQ, (A @ Q[:, -1])[:, None]])
+                QY = Q.conj().T @ Y
+                X = Q @ np.linalg.solve(Q.conj().T @ AQ, QY[:, kk])
+                res = np.linalg.norm(A @ X - Y[:, kk])
+            resnorm[kk + idx * k] = res
+            if output:
+                print(kk + idx * k + 1, "/", len(Z) * k, " dim", Q.shape[1], " res", res)
+    return Q, resnorm
+
+
+def project(L, Q):
+    """P = project(L, Q): the family P(z) = Q' L(z) Q, term by term (beyn.jl:579-595).  The projected terms are small
+    dense matrices; P is an ordinary (device-backed) family, so beyn / householder / ... run on it unchanged."""
+    from .linopfam import LinearOperatorFamily, Term
+    Q = np.asarray(Q, dtype=np.complex128)
+    P = LinearOperatorFamily([L.eigval], [L.params[L.eigval]], device=L.device_id)
+    P.params = dict(L.params)
+    P.eigval, P.auxval, P.mode, P.active = L.eigval, L.auxval, L.mode, list(L.active)
+    P.solver_tol, P.solver_maxit, P.solver_ref = L.solver_tol, L.solver_maxit, L.solver_ref
+    P.solver_opts = {"max_coarse": max(128, Q.shape[1])}          # one dense level: the projected operator is inverted directly
+    for k, t in enumerate(L.terms):
+        M = Q.conj().T @ (L.term_operator(k) @ Q)
+        P.push(Term(np.asarray(M), t.func, t.params, t.symbol, t.operator))
+    for key, val in L.params.items():
+        P.params[key] = val
+    return P
