@@ -8,9 +8,12 @@ combustor (BASELINE.json configs[1]: ~200k DoF Helmholtz NLEVP with nÂ·exp(-iÏ‰Ï
 
 One "step" = one complete pass of the hot path: all quadrature points of the contour (4 edges x 32 Gauss-Legendre
 nodes = 128 shifted systems x l=16 probe columns), each solved on the device by multigrid-GMRES whose operator
-application is the fused multi-term CSR SpMV; moment accumulation in HBM; (N>1: quadrature points are dealt
-round-robin to the ranks, partial moment tensors are summed with one RCCL all-reduce over xGMI); Hankel SVD +
-small eigenproblem + position test + residual check of every eigenpair on rank 0.  Inputs (all term matrices,
+application is the fused multi-term CSR SpMV; moment accumulation in HBM.  By default (--rb 32) 32 snapshot points are
+solved first and every other system starts from the Galerkin projection of its solution on them: same
+moments to the inner tolerance, same stopping test; --rb 0 solves every system from a zero guess.  N>1: snapshot and
+remaining points are dealt round-robin to the ranks, the snapshot solutions are all-gathered and the partial moment
+tensors summed with one RCCL all-reduce over xGMI.  Then QR+SVD of the moments on the GPU, small eigenproblem,
+position test and the residual check of every eigenpair (on the device) on rank 0.  Inputs (all term matrices,
 the multigrid hierarchy, the probe matrix) are resident in HBM before the timed region.
 
 The printed JSON line carries, besides the driver's contract fields,
@@ -208,7 +211,10 @@ def main():
             "config": {"workload": f"annular combustor Helmholtz NLEVP (P1), preset {args.preset}: d={d}, "
                                    f"L(w)=w^2 M+K+w Y C+n exp(-i w tau) Q, Beyn l={args.l} K=1 N={args.N}/edge "
                                    f"({4 * args.N} shifted systems x {args.l} columns), contour 150..1000 Hz x +-150 Hz, inner tol {args.tol:g}",
-                       "parallelism": f"quadrature points round-robin over {world} GPU(s), one all-reduce of the moments",
+                       "parallelism": (f"quadrature points round-robin over {world} GPU(s); {args.rb} snapshot points solved first, their "
+                                       "solutions all-gathered, the other points start from the projection on them; one all-reduce of the moments"
+                                       if args.rb > 0 else
+                                       f"quadrature points round-robin over {world} GPU(s), one all-reduce of the moments"),
                        "batch_columns": args.batch},
             "eigenpairs": n_eig, "eigenvalues_hz": [[float(x.real), float(x.imag)] for x in np.sort_complex(Om[good] / 2 / np.pi)],
             "eig_residual_max": float(r[good].max()) if n_eig else None, "n_inside_before_residual_test": int(len(Om)),
