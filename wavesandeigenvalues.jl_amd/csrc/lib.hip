@@ -579,6 +579,8 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
             }
         }
         mk = nullptr;
+        bool any_stalled_now = false;
+        for (int b = 0; b < nb; ++b) any_stalled_now = any_stalled_now || stalled[b];
         // y = R^{-1} g per column, zero-padded to j steps;  x += V y
         const int ju = std::min(j, m);
         std::vector<cplx> y((size_t)std::max(ju, 1) * nb, cplx{0.0, 0.0});
@@ -601,6 +603,14 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
             HIP_CHECK(hipStreamSynchronize(st));       // y is a stack vector
         }
         if (nan_seen) break;
+        // A short recurrence that ended with every column converged by its Arnoldi estimate needs no confirmation by a
+        // true residual (another SpMV + V-cycle): over <= 12 steps the estimate equals the preconditioned residual to
+        // rounding.  Long recurrences (Gram-Schmidt drift) and stalled columns are always re-checked at the loop top.
+        if (j <= 12 && !any_stalled_now) {
+            bool all_est = true;
+            for (int b = 0; b < nb; ++b) if (bnorm[b] > 0.0 && !(relres[b] <= tol)) all_est = false;
+            if (all_est) break;
+        }
     }
     if (have_x0 && !nan_seen) penalty_polish(h, bt, B, X);
     static const bool dbg = getenv("WAE_GMRES_DEBUG") && atoi(getenv("WAE_GMRES_DEBUG"));
