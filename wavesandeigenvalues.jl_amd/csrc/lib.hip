@@ -1,6 +1,7 @@
 // libwaehip.so -- family handle, multigrid-preconditioned batched GMRES, Beyn moment loop, C ABI.
 // gfx950 only.  See include/waehip.h for the contract of every exported function.
 #include <algorithm>
+#include <future>
 #include <chrono>
 #include <cmath>
 #include <map>
@@ -828,9 +829,11 @@ static void rb_append(wae_family *h, int count) {
     for (int done = 0; done < count; done += 4) rb_append_block(h, std::min(4, count - done), pck);
 }
 
-// Xs[row][sy*l + c] = Q_c (sum_k c_k(z_sy) Q_c^H A_k Q_c)^{-1} Q_c^H v_c : Galerkin guesses of one chunk
-static void rb_guess(wae_family *h, const double *ct_chunk, int ns, cplx *X) {
-    RbState &R = h->rb;
+// Galerkin guesses of one chunk, Xs[row][sy*l + c] = Q_c (sum_k c_k(z_sy) Q_c^H A_k Q_c)^{-1} Q_c^H v_c, in two steps: the
+// S x S solves (host only, reads the projected terms -- safe to run on a helper thread while the device works on the
+// previous chunk), and the application of the coefficients on the device.
+static std::vector<cplx> rb_guess_coeffs(const wae_family *h, const double *ct_chunk, int ns) {
+    const RbState &R = h->rb;
     const int S = R.S, l = R.l, cap = R.cap, T = h->T, nb = ns * l;
     std::vector<cplx> Y((size_t)S * nb);
     std::vector<zc> Hs((size_t)S * S), rhs(S);
@@ -856,8 +859,13 @@ static void rb_guess(wae_family *h, const double *ct_chunk, int ns, cplx *X) {
             }
         }
     }
+    return Y;
+}
+static void rb_apply_guess(wae_family *h, const std::vector<cplx> &Y, int ns, cplx *X) {
+    RbState &R = h->rb;
+    const int S = (int)(Y.size() / ((size_t)ns * R.l));
     R.ycoef.upload(Y.data(), Y.size(), h->stream);
-    launch_lincomb_rep(R.Q, (size_t)h->d * l, S, R.ycoef.p, X, h->d, nb, l, h->stream);
+    launch_lincomb_rep(R.Q, (size_t)h->d * R.l, S, R.ycoef.p, X, h->d, ns * R.l, R.l, h->stream);
     HIP_CHECK(hipStreamSynchronize(h->stream));
 }
 
@@ -1387,6 +1395,15 @@ int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const doub
             WAE_REQUIRE(mode != 2 || R.S > 0, "mode 2 needs a basis: run mode 0 (or 1) first");
         }
 
+        // with a fixed basis (modes 1/2, no enrichment) the coefficients of the next chunk's guesses are computed on a helper
+        // thread while the device solves the current chunk
+        const bool fixed_basis = mode != 0 && enrich_its >= (1 << 30);
+        std::future<std::vector<cplx>> next_Y;
+        auto launch_coeffs = [&](int q0) {
+            const int nq = std::min(spc, npts - q0);
+            return std::async(std::launch::async, [h, coeff_table, q0, nq, T]() { return rb_guess_coeffs(h, coeff_table + (size_t)q0 * 2 * T, nq); });
+        };
+        if (fixed_basis && npts > 0 && R.S > 0) next_Y = launch_coeffs(0);
         for (int p0 = 0; p0 < npts; p0 += spc) {
             const int ns = std::min(spc, npts - p0);
             Batch bt;
@@ -1403,7 +1420,16 @@ int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const doub
             launch_replicate(h->io_a.p, d, l, h->Bs.p, bt.nb, st);
             const bool guess = R.S > 0;            // mode 0 is progressive: later snapshot chunks start from the earlier ones
             const double ta = now_s();
-            if (guess) rb_guess(h, coeff_table + (size_t)p0 * 2 * T, ns, h->Xs.p);
+            if (guess) {
+                std::vector<cplx> Y;
+                if (next_Y.valid()) {
+                    Y = next_Y.get();
+                    if (p0 + spc < npts) next_Y = launch_coeffs(p0 + spc);
+                } else {
+                    Y = rb_guess_coeffs(h, coeff_table + (size_t)p0 * 2 * T, ns);
+                }
+                rb_apply_guess(h, Y, ns, h->Xs.p);
+            }
             const double tb = now_s();
             const int its = solve_chunk(h, bt, pcs, h->Bs.p, h->Xs.p, tol, maxit, &li, nullptr, guess);
             launch_beyn_accum(h->Xs.p, bt.nb, d, l, ns, h->zw_dev.p, h->zw_dev.p + ns, npow, Ad, st);
