@@ -159,10 +159,20 @@ int wae_eig_residuals(wae_family *h, int32_t n, const double *coeff_table, const
  *   Q_dev : device pointer of the snapshot store, or 0 for a store owned by the handle; a caller-owned store is
  *           what a multi-GPU driver all-gathers between modes 0 and 1.
  *   accumulate != 0: add to the moments already in out_dev instead of zeroing them first (requires out_dev).
- * Everything else as wae_beyn_moments. */
+ * Everything else as wae_beyn_moments.
+ *   l_total, col0: the moment tensor has l_total columns and V holds columns col0 .. col0+l-1 of the probe matrix
+ *           (l_total <= 0: l_total = l, col0 = 0).  A multi-GPU driver lets every rank take ALL snapshot points for its
+ *           own slice of the probe columns (mode 0 stays progressive and leaves a finished basis for that slice), then
+ *           exchanges the bases: wae_rb_export / all-gather / wae_rb_import, and runs mode 2 on its share of the points. */
 int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const double *w, const double *coeff_table, const double *V,
                         int32_t l, int32_t K, double tol, int32_t maxit, int32_t mode, int32_t nbasis, int32_t slot0, uint64_t Q_dev,
-                        double *A_out, uint64_t out_dev, int32_t accumulate, wae_solve_info *info);
+                        double *A_out, uint64_t out_dev, int32_t accumulate, int32_t l_total, int32_t col0, wae_solve_info *info);
+/* The snapshot basis of the handle, host side: S vectors per column, l columns, nk projected terms kact[0..nk-1];
+ * Hk dense [ki][s][i][c] (= q_i^H A_k q_s of column c's basis, c fastest), g [i][c] (= q_i^H v_c); complex interleaved.
+ * export: pass NULL arrays to query the sizes first.  import: installs a basis whose vectors lie in Q_dev
+ * (S x d x l, interleaved [row][column], orthonormal per column) for mode 2. */
+int wae_rb_export(wae_family *h, int32_t *S_out, int32_t *l_out, int32_t *nk_out, int32_t *kact_out, double *Hk_out, double *g_out);
+int wae_rb_import(wae_family *h, int32_t S, int32_t l, uint64_t Q_dev, int32_t nk, const int32_t *kact, const double *Hk, const double *g);
 
 /* -- shift-invert Arnoldi factorisation for (A, M), A = sum cA_k A_k, M = sum cM_k A_k -----------------
  * The device half of `Arpack.eigs(A,M,nev=nev,sigma=0,v0=v0)` and of the adjoint call on (A',M')

@@ -497,3 +497,47 @@ def test_generate_subspace_and_project_match_oracle():
         assert np.min(np.abs(Om - w)) < 1e-7 * abs(w)
     P._drop_device()
     Lp._drop_device()
+
+
+def test_projected_guesses_column_split_exchange():
+    """The multi-GPU snapshot phase in one process: "rank r" takes ALL snapshot points for its half of the probe columns
+    (wae_beyn_moments_rb mode 0 with l_total/col0), the finished bases are exported, concatenated as the all-gather would,
+    imported, and the remaining points run in mode 2.  Same moments as the plain path."""
+    import json
+    import os
+    import torch
+    from wae_amd.helmholtz.family import annulus_family
+    from wae_amd.nlevp.beyn import coefficient_table, gauss_points, snapshot_split, spread_order
+    gold = json.load(open(os.path.join(F.GOLDEN_DIR, "annulus_small_beyn.json")))
+    Lp, pb = annulus_family("small", n=gold["n"], tau=gold["tau"])
+    Lp.solver_tol = 1e-11
+    Lp.solver_ref = 2 * np.pi * 500.0
+    Gam = np.array([150 - 150j, 1000 - 150j, 1000 + 150j, 150 + 150j]) * 2 * np.pi
+    d, l, ls, S = pb["d"], 16, 8, 24
+    V = np.random.default_rng(5).standard_normal((d, l)) + 0j
+    A0 = compute_moment_matrices(Lp, Gam, V, K=1, N=32, rb=0)
+    fam = Lp.device()
+    its0 = fam.last_info["iters_total"]
+    zs, ws = gauss_points(Gam, 32)
+    ct = coefficient_table(Lp, zs)
+    idx, rest = snapshot_split(len(zs), S)
+    idx = spread_order(idx)
+    buf = torch.zeros(d * l * 2 * 2, dtype=torch.float64, device="cuda:0")
+    kw = dict(K=1, tol=Lp.solver_tol, maxit=Lp.solver_maxit, out_dev=buf.data_ptr())
+    slabs, parts = [], []
+    for r in range(2):
+        local = torch.empty(S * d * ls * 2, dtype=torch.float64, device="cuda:0")
+        fam.beyn_moments_rb(zs[idx], ws[idx], ct[idx], V[:, r * ls:(r + 1) * ls], 0, S, Q_dev=local.data_ptr(),
+                            accumulate=(r > 0), l_total=l, col0=r * ls, **kw)
+        slabs.append(local)
+        parts.append(fam.rb_export())
+    kact = parts[0][0]
+    assert np.array_equal(kact, parts[1][0]) and parts[0][1].shape == (len(kact), S, S, ls)
+    store = torch.stack(slabs).view(2, S, d, ls, 2).permute(1, 2, 0, 3, 4).contiguous()
+    fam.rb_import(store.data_ptr(), kact, np.concatenate([p[1] for p in parts], axis=3), np.concatenate([p[2] for p in parts], axis=1))
+    fam.beyn_moments_rb(zs[rest], ws[rest], ct[rest], V, 2, S, Q_dev=store.data_ptr(), accumulate=True, **kw)
+    assert fam.last_info["n_unconverged"] == 0
+    assert fam.last_info["iters_total"] < 0.5 * its0 * len(rest) / len(zs)      # the imported basis does its job
+    A2 = buf.cpu().numpy().view(np.complex128).reshape((d, l, 2), order="F")
+    assert relerr(A2, A0) < 1e-8
+    Lp._drop_device()

@@ -1051,7 +1051,8 @@ void launch_replicate(const cplx *Vc, int64_t d, int l, cplx *Xi, int nb, hipStr
 
 // A[(p*l+c)*d + row] += sum_s w[s] z[s]^p X[row][s*l+c]
 __global__ __launch_bounds__(256) void beyn_accum_kernel(const cplx *__restrict__ Xi, int nb, int64_t d, int l, int nsys,
-                                                         const cplx *__restrict__ w, const cplx *__restrict__ z, int npow, cplx *__restrict__ A) {
+                                                         const cplx *__restrict__ w, const cplx *__restrict__ z, int npow, cplx *__restrict__ A,
+                                                         int lA, int c0) {
     const size_t total = (size_t)d * l;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const size_t c = e / d, row = e - c * d;
@@ -1059,7 +1060,7 @@ __global__ __launch_bounds__(256) void beyn_accum_kernel(const cplx *__restrict_
             cplx t = cmul(w[s], Xi[row * nb + (size_t)s * l + c]);
             const cplx zs = z[s];
             for (int p = 0; p < npow; ++p) {
-                cplx *dst = A + ((size_t)p * l + c) * d + row;
+                cplx *dst = A + ((size_t)p * lA + c0 + c) * d + row;
                 cplx a = *dst;
                 *dst = cplx{a.x + t.x, a.y + t.y};
                 t = cmul(t, zs);
@@ -1067,8 +1068,10 @@ __global__ __launch_bounds__(256) void beyn_accum_kernel(const cplx *__restrict_
         }
     }
 }
-void launch_beyn_accum(const cplx *Xi, int nb, int64_t d, int l, int nsys, const cplx *w, const cplx *z, int npow, cplx *A, hipStream_t st) {
-    hipLaunchKernelGGL(beyn_accum_kernel, dim3(grid_for((size_t)d * l)), dim3(256), 0, st, Xi, nb, d, l, nsys, w, z, npow, A);
+void launch_beyn_accum(const cplx *Xi, int nb, int64_t d, int l, int nsys, const cplx *w, const cplx *z, int npow, cplx *A, hipStream_t st,
+                       int lA, int c0) {
+    if (lA <= 0) lA = l;
+    hipLaunchKernelGGL(beyn_accum_kernel, dim3(grid_for((size_t)d * l)), dim3(256), 0, st, Xi, nb, d, l, nsys, w, z, npow, A, lA, c0);
     HIP_CHECK(hipGetLastError());
 }
 

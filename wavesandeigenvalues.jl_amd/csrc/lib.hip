@@ -1344,13 +1344,15 @@ int wae_beyn_moments(wae_family *h, int32_t npts, const double *z, const double 
 
 int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const double *w, const double *coeff_table, const double *V, int32_t l, int32_t K,
                         double tol, int32_t maxit, int32_t mode, int32_t nbasis, int32_t slot0, uint64_t Q_dev, double *A_out, uint64_t out_dev,
-                        int32_t accumulate, wae_solve_info *info) {
+                        int32_t accumulate, int32_t l_total, int32_t col0, wae_solve_info *info) {
     return guarded([&]() {
         WAE_REQUIRE(h && npts >= 0 && (npts == 0 || (z && w && coeff_table)) && V && l > 0 && K > 0, "bad argument");
         WAE_REQUIRE(A_out || out_dev, "no output buffer");
         WAE_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (take snapshots), 1 (rebuild the basis from the store, use it) or 2 (use it)");
         WAE_REQUIRE(nbasis >= 0 && slot0 >= 0 && (mode == 2 || slot0 + (mode == 0 ? npts : 0) <= nbasis), "snapshot slots out of range");
         WAE_REQUIRE(!accumulate || out_dev, "accumulate needs a device-resident moment buffer");
+        if (l_total <= 0) { l_total = l; col0 = 0; }
+        WAE_REQUIRE(col0 >= 0 && col0 + l <= l_total, "column slice out of range");
         require_solver(h);
         WAE_REQUIRE(l <= h->NB, "l exceeds the solver batch width");
         HIP_CHECK(hipSetDevice(h->device));
@@ -1360,7 +1362,7 @@ int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const doub
         const double t0 = now_s();
         const int64_t d = h->d;
         const int npow = 2 * K;
-        const size_t acnt = (size_t)d * l * npow;
+        const size_t acnt = (size_t)d * l_total * npow;      // the moment tensor has l_total columns; this call fills l of them
         const size_t vecl = (size_t)d * l;
         const int T = h->T;
         RbState &R = h->rb;
@@ -1432,7 +1434,7 @@ int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const doub
             }
             const double tb = now_s();
             const int its = solve_chunk(h, bt, pcs, h->Bs.p, h->Xs.p, tol, maxit, &li, nullptr, guess);
-            launch_beyn_accum(h->Xs.p, bt.nb, d, l, ns, h->zw_dev.p, h->zw_dev.p + ns, npow, Ad, st);
+            launch_beyn_accum(h->Xs.p, bt.nb, d, l, ns, h->zw_dev.p, h->zw_dev.p + ns, npow, Ad, st, l_total, col0);
             if (rbdbg) HIP_CHECK(hipStreamSynchronize(st));
             const double tc = now_s();
             // mode 0 keeps every solution; modes 1/2 enrich the basis where the guesses were poor (a region of the
@@ -1455,6 +1457,43 @@ int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const doub
         const int rc_ = info_code(li);
         if (info) *info = li;
         return rc_;
+    });
+}
+
+int wae_rb_export(wae_family *h, int32_t *S_out, int32_t *l_out, int32_t *nk_out, int32_t *kact_out, double *Hk_out, double *g_out) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && S_out && l_out && nk_out, "bad argument");
+        const RbState &R = h->rb;
+        *S_out = R.S; *l_out = R.l; *nk_out = (int32_t)R.kact.size();
+        if (kact_out) for (size_t i = 0; i < R.kact.size(); ++i) kact_out[i] = R.kact[i];
+        const int S = R.S, l = R.l, cap = R.cap;
+        if (Hk_out)                                              // dense [ki][s][i][c], c fastest
+            for (size_t ki = 0; ki < R.kact.size(); ++ki)
+                for (int s = 0; s < S; ++s)
+                    for (int i = 0; i < S; ++i)
+                        for (int c = 0; c < l; ++c) {
+                            const zc v = R.Hk[ki * (size_t)cap * cap * l + ((size_t)s * cap + i) * l + c];
+                            const size_t o = (((ki * S + s) * (size_t)S + i) * l + c) * 2;
+                            Hk_out[o] = v.real(); Hk_out[o + 1] = v.imag();
+                        }
+        if (g_out)
+            for (int i = 0; i < S; ++i)
+                for (int c = 0; c < l; ++c) { g_out[((size_t)i * l + c) * 2] = R.g[(size_t)i * l + c].real(); g_out[((size_t)i * l + c) * 2 + 1] = R.g[(size_t)i * l + c].imag(); }
+        return WAE_OK;
+    });
+}
+
+int wae_rb_import(wae_family *h, int32_t S, int32_t l, uint64_t Q_dev, int32_t nk, const int32_t *kact, const double *Hk, const double *g) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && S > 0 && l > 0 && Q_dev && nk >= 0 && (nk == 0 || kact) && Hk && g, "bad argument");
+        RbState &R = h->rb;
+        R.Q = (cplx *)(uintptr_t)Q_dev; R.cap = S; R.l = l; R.S = S;
+        R.kact.assign(kact, kact + nk);
+        R.Hk.resize((size_t)nk * S * S * l);
+        for (size_t i = 0; i < R.Hk.size(); ++i) R.Hk[i] = zc(Hk[2 * i], Hk[2 * i + 1]);     // cap == S: same dense layout
+        R.g.resize((size_t)S * l);
+        for (size_t i = 0; i < R.g.size(); ++i) R.g[i] = zc(g[2 * i], g[2 * i + 1]);
+        return WAE_OK;
     });
 }
 

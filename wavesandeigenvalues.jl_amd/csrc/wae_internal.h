@@ -180,8 +180,9 @@ void launch_scatter_add_rows(const cplx *D, const int *rows, int64_t nrows, int 
 void launch_extract_cols(const cplx *X, int nb, int off, int l, cplx *out, int64_t n, hipStream_t s);
 void launch_lincomb_rep(const cplx *Q, size_t stride, int nv, const cplx *y, cplx *X, int64_t n, int nb, int l, hipStream_t s);
 void launch_mask_cols(cplx *X, const cplx *keep, int64_t n, int nb, hipStream_t s);
-// Beyn accumulation: A[(p*l+c)*d + row] += sum_s w[s] z[s]^p X[row][s*l+c], s < nsys, p < npow
-void launch_beyn_accum(const cplx *Xi, int nb, int64_t d, int l, int nsys, const cplx *w, const cplx *z, int npow, cplx *A, hipStream_t s);
+// Beyn accumulation: A[(p*lA+c0+c)*d + row] += sum_s w[s] z[s]^p X[row][s*l+c], s < nsys, p < npow  (lA columns in A; 0 = l)
+void launch_beyn_accum(const cplx *Xi, int nb, int64_t d, int l, int nsys, const cplx *w, const cplx *z, int npow, cplx *A, hipStream_t s,
+                       int lA = 0, int c0 = 0);
 // X[row][t] = sum_i G[i][t] V_i[row], V_i = V + i*stride (single vectors), X interleaved with leading dimension T
 void launch_gemv_multi(const cplx *V, size_t stride, int k, const cplx *G, cplx *X, int64_t d, int T, hipStream_t s);
 // triad for bandwidth measurement

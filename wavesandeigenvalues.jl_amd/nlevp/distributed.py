@@ -59,13 +59,32 @@ def beyn_moments_distributed(G, N, shape, moment_fn):
     return buf.cpu().numpy().view(np.complex128).reshape(shape, order="F")
 
 
+def _allgather_dev(local, world):
+    """all-gather equal-sized device tensors into one flat device tensor (rank-major); through the host under gloo"""
+    import torch
+    dd = _dist()
+    out = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
+    if dd.get_backend() == "nccl":
+        dd.all_gather_into_tensor(out, local)                # RCCL over xGMI, device to device
+    else:                                                    # gloo rehearsal on one box
+        parts = [torch.empty(local.numel(), dtype=local.dtype) for _ in range(world)]
+        dd.all_gather(parts, local.cpu())
+        out.copy_(torch.cat(parts))
+    return out
+
+
 def beyn_moments_distributed_rb(L, G, V, K, N, S, timings=None, extra=None):
-    """Sharded moments with snapshot-projection initial guesses (wae_beyn_moments_rb).  Two exchange steps:
-    (1) the S snapshot points are dealt round-robin, every rank solves its share from a zero guess, and the raw
-    solutions (S x d x l) are all-gathered so that every rank holds the same snapshot store; (2) the remaining points
-    are dealt round-robin and start from the projection on that store; the partial moments are summed with one
-    all-reduce.  Returns the flat float64 CUDA tensor of the column-major d x l x 2K moments (on every rank) and the
-    solver statistics of this rank."""
+    """Sharded moments with snapshot-projection initial guesses (wae_beyn_moments_rb).  Two exchange steps.
+
+    (1) Snapshot phase, split by PROBE COLUMN: every rank solves all S snapshot points for its l/world columns.  The
+    per-column bases are independent, so each rank's progressive snapshot phase is exactly the single-GPU one for its
+    columns and leaves a finished (orthonormal, projected) basis; the bases are exchanged -- all-gather of the basis
+    vectors (S x d x l complex in all) and of the small projected terms -- and installed with wae_rb_import: no rank
+    repeats another rank's orthogonalisation.  (2) The remaining points are dealt round-robin and start from the
+    projection; the partial moments (snapshot contributions in each rank's own columns included) are summed with one
+    all-reduce.  When l is not divisible by the world size the snapshot POINTS are split instead and every rank
+    rebuilds the basis from the gathered raw snapshots (mode 1).
+    Returns the flat float64 CUDA tensor of the column-major d x l x 2K moments (on every rank) and solver statistics."""
     import time
 
     import torch
@@ -73,41 +92,63 @@ def beyn_moments_distributed_rb(L, G, V, K, N, S, timings=None, extra=None):
     d, l = V.shape
     dev = torch.device("cuda", L.device_id)
     zs, ws = gauss_points(G, N)
-    S = min(int(S), len(zs))
-    S = max(world, (S // world) * world)                      # equal snapshot shares (all_gather wants equal sizes)
     from .beyn import coefficient_table, snapshot_split, spread_order
-    idx, rest = snapshot_split(len(zs), S)
-    idx = spread_order(idx)
-    S = len(idx)
     fam = L.ensure_solver()
     ct = coefficient_table(L, zs)
-    mine = idx[rank::world]
-    per = len(mine)
     buf = torch.zeros(d * l * 2 * K * 2, dtype=torch.float64, device=dev)
-    cap = S + (0 if extra is None else int(extra))            # optional room for adaptive enrichment (WAE_RB_ENRICH)
-    store = torch.empty(cap * d * l * 2, dtype=torch.float64, device=dev)
-    local = store if world == 1 else torch.empty(per * d * l * 2, dtype=torch.float64, device=dev)
     kw = dict(K=K, tol=L.solver_tol, maxit=L.solver_maxit, out_dev=buf.data_ptr())
+    by_column = world > 1 and l % world == 0
     t0 = time.perf_counter()
-    fam.beyn_moments_rb(zs[mine], ws[mine], ct[mine], V, 0, cap if world == 1 else per, Q_dev=local.data_ptr(), **kw)
-    i0 = dict(fam.last_info)
-    t1 = time.perf_counter()
-    dd = _dist()
-    if world > 1:
+    if by_column or world == 1:
+        S = min(int(S), len(zs))
+        idx, rest = snapshot_split(len(zs), S)
+        idx = spread_order(idx)
+        S = len(idx)
+        ls = l // world
+        c0 = rank * ls
+        cap = S + (0 if (extra is None or world > 1) else int(extra))
+        local = torch.empty(cap * d * ls * 2, dtype=torch.float64, device=dev)
+        fam.beyn_moments_rb(zs[idx], ws[idx], ct[idx], V[:, c0:c0 + ls], 0, cap, Q_dev=local.data_ptr(), l_total=l, col0=c0, **kw)
+        i0 = dict(fam.last_info)
+        snap_cols = S * ls
+        t1 = time.perf_counter()
+        if world > 1:
+            kact, Hk, g = fam.rb_export()
+            torch.cuda.synchronize(dev)
+            slabs = _allgather_dev(local, world)                                     # [rank][s][row][c_local]
+            store = slabs.view(world, S, d, ls, 2).permute(1, 2, 0, 3, 4).contiguous()  # [s][row][c]: columns back in order
+            del slabs
+            small = torch.from_numpy(np.concatenate([Hk.ravel(), g.ravel()]).view(np.float64).copy()).to(dev)
+            allsm = _allgather_dev(small, world).cpu().numpy().view(np.complex128).reshape(world, -1)
+            nH = Hk.size
+            Hk_all = np.concatenate([allsm[r, :nH].reshape(Hk.shape) for r in range(world)], axis=3)
+            g_all = np.concatenate([allsm[r, nH:].reshape(g.shape) for r in range(world)], axis=1)
+            fam.rb_import(store.data_ptr(), kact, Hk_all, g_all)
+            torch.cuda.synchronize(dev)
+        else:
+            store = local
+        t2 = time.perf_counter()
+        mine2 = rest[rank::world]
+        fam.beyn_moments_rb(zs[mine2], ws[mine2], ct[mine2], V, 2, S if world > 1 else cap, Q_dev=store.data_ptr(), accumulate=True, **kw)
+    else:
+        S = min(int(S), len(zs))
+        S = max(world, (S // world) * world)                      # equal snapshot shares (all_gather wants equal sizes)
+        idx, rest = snapshot_split(len(zs), S)
+        idx = spread_order(idx)
+        S = len(idx)
+        mine = idx[rank::world]
+        per = len(mine)
+        local = torch.empty(per * d * l * 2, dtype=torch.float64, device=dev)
+        fam.beyn_moments_rb(zs[mine], ws[mine], ct[mine], V, 0, per, Q_dev=local.data_ptr(), **kw)
+        i0 = dict(fam.last_info)
+        snap_cols = per * l
+        t1 = time.perf_counter()
         torch.cuda.synchronize(dev)
-        if dd.get_backend() == "nccl":
-            dd.all_gather_into_tensor(store[:S * d * l * 2], local)          # RCCL over xGMI, device to device
-        else:                                                # gloo rehearsal on one box: through the host
-            parts = [torch.empty(local.numel(), dtype=torch.float64) for _ in range(world)]
-            dd.all_gather(parts, local.cpu())
-            store[:S * d * l * 2].copy_(torch.cat(parts))
+        store = _allgather_dev(local, world)
         torch.cuda.synchronize(dev)
-    t2 = time.perf_counter()
-    mine2 = rest[rank::world]
-    # one rank: the progressive basis built while taking the snapshots is complete (mode 2); several ranks: rebuild it
-    # from the gathered store (mode 1)
-    fam.beyn_moments_rb(zs[mine2], ws[mine2], ct[mine2], V, 2 if world == 1 else 1, cap, slot0=0 if world == 1 else S,
-                        Q_dev=store.data_ptr(), accumulate=True, **kw)
+        t2 = time.perf_counter()
+        mine2 = rest[rank::world]
+        fam.beyn_moments_rb(zs[mine2], ws[mine2], ct[mine2], V, 1, S, slot0=S, Q_dev=store.data_ptr(), accumulate=True, **kw)
     i1 = dict(fam.last_info)
     t3 = time.perf_counter()
     allreduce_sum_(buf)
@@ -121,7 +162,8 @@ def beyn_moments_distributed_rb(L, G, V, K, N, S, timings=None, extra=None):
             "n_unconverged": i0["n_unconverged"] + i1["n_unconverged"], "levels": i1["levels"],
             "relres_max": max(i0["relres_max"], i1["relres_max"]), "seconds": i0["seconds"] + i1["seconds"],
             "snapshot_iters": i0["iters_total"], "projected_iters": i1["iters_total"], "snapshots": S,
-            "snapshot_columns": per * l, "projected_columns": len(mine2) * l}
+            "snapshot_columns": snap_cols, "projected_columns": len(mine2) * l,
+            "snapshot_split": "columns" if by_column else ("points" if world > 1 else "none")}
     return buf, info
 
 

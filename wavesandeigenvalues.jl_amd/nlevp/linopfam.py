@@ -183,7 +183,7 @@ class DeviceFamily:
         return A
 
     def beyn_moments_rb(self, z, w, coeff_table, V, mode, nbasis, slot0=0, Q_dev=0, K=1, tol=1e-10, maxit=300, out_dev=0,
-                        accumulate=False):
+                        accumulate=False, l_total=0, col0=0):
         """wae_beyn_moments_rb: mode 0 solves the points and stores their solutions as snapshots, mode 1 starts every
         system from the Galerkin projection on the snapshot basis (include/waehip.h)."""
         z = np.ascontiguousarray(z, dtype=np.complex128)
@@ -194,14 +194,34 @@ class DeviceFamily:
         info = SolveInfo()
         A, aptr = None, None
         if not out_dev:
-            A = np.zeros((self.d, l, 2 * K), dtype=np.complex128, order="F")
+            A = np.zeros((self.d, l_total if l_total > 0 else l, 2 * K), dtype=np.complex128, order="F")
             aptr = zptr(A)
         code = check(_lib.lib().wae_beyn_moments_rb(self.handle, len(z), zptr(z), zptr(w), zptr(ct), zptr(Vf), l, K, tol, maxit,
                                                     int(mode), int(nbasis), int(slot0), int(Q_dev), aptr, int(out_dev),
-                                                    1 if accumulate else 0, C.byref(info)))
+                                                    1 if accumulate else 0, int(l_total), int(col0), C.byref(info)))
         self.last_info = info.as_dict()
         self.last_code = code
         return A
+
+    def rb_export(self):
+        """wae_rb_export: (kact, Hk[nk, S, S, l], g[S, l]) of the snapshot basis in the handle"""
+        S, l, nk = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        check(_lib.lib().wae_rb_export(self.handle, C.byref(S), C.byref(l), C.byref(nk), None, None, None))
+        kact = np.zeros(max(nk.value, 1), dtype=np.int32)
+        Hk = np.zeros((nk.value, S.value, S.value, l.value), dtype=np.complex128)
+        g = np.zeros((S.value, l.value), dtype=np.complex128)
+        check(_lib.lib().wae_rb_export(self.handle, C.byref(S), C.byref(l), C.byref(nk), kact.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       zptr(Hk), zptr(g)))
+        return kact[:nk.value], Hk, g
+
+    def rb_import(self, Q_dev, kact, Hk, g):
+        """wae_rb_import: install a basis (vectors in Q_dev: S x d x l interleaved, orthonormal per column) for mode 2"""
+        kact = np.ascontiguousarray(kact, dtype=np.int32)
+        Hk = np.ascontiguousarray(Hk, dtype=np.complex128)
+        g = np.ascontiguousarray(g, dtype=np.complex128)
+        S, l = g.shape
+        assert Hk.shape == (len(kact), S, S, l)
+        check(_lib.lib().wae_rb_import(self.handle, S, l, int(Q_dev), len(kact), kact.ctypes.data_as(C.POINTER(C.c_int32)), zptr(Hk), zptr(g)))
 
     def eig_residuals(self, coeff_table, P=None, P_dev=0):
         """wae_eig_residuals: ||L(ω_j) v_j|| / Σ_k |c_jk| ||A_k v_j|| for every pair; P (host, d x n) or P_dev (device
