@@ -92,6 +92,9 @@ int wae_spmv_sum_multi(wae_family *h, const double *coeffs, const double *X, dou
  * opts (may be NULL -> defaults): [0] strength threshold (0.02), [1] max coarse size (128),
  *   [2] Jacobi weight (0.8), [3] pre/post sweeps (1), [4] GMRES restart (30), [5] penalty-row ratio (1e8),
  *   [6] batch width (columns solved in lock-step, 64).
+ *   [7] bit mask (as a double) of terms kept OUT of the shape matrix that the strength graph, the aggregates and the
+ *       prolongator smoothing are built from (0).  Bloch families (src/Helmholtz.jl:508-513) pass the seam parts here:
+ *       the solution jumps by exp(i b 2pi/N) across the seam, so no aggregate may span it.
  */
 int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts, int32_t nopts);
 

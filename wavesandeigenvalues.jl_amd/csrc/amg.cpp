@@ -258,10 +258,12 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
 }
 
 void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, const AmgOptions &opt, std::vector<AmgLevel> &levels,
-               std::vector<char> *penalty_rows) {
+               std::vector<char> *penalty_rows, const std::vector<zc> *pc_shape) {
     levels.clear();
-    CsrZ Aref = csr_lincomb(planes, pc_ref);
-    const int64_t n0 = Aref.n;
+    const CsrZ Afull = csr_lincomb(planes, pc_ref);
+    const CsrZ Ashape = pc_shape ? csr_lincomb(planes, *pc_shape) : CsrZ();
+    const CsrZ &Aref = pc_shape ? Ashape : Afull;          // the shape matrix comes from here, the penalty test from Afull
+    const int64_t n0 = Afull.n;
     // Real shape matrix S for strength-of-connection / aggregation / prolongator smoothing: the real part of the
     // STRUCTURALLY SYMMETRIC part of A_ref.  One-sided couplings (the flame term Q = s g^T couples every flame
     // node to the few reference nodes, Helmholtz.jl:464-487) are long-range and non-elliptic: letting them into
@@ -291,8 +293,8 @@ void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, c
     std::vector<double> dabs(n0);
     for (int64_t i = 0; i < n0; ++i) {
         zc dg = 0;
-        for (int p = Aref.ptr[i]; p < Aref.ptr[i + 1]; ++p)
-            if (Aref.col[p] == i) dg = Aref.val[p];
+        for (int p = Afull.ptr[i]; p < Afull.ptr[i + 1]; ++p)
+            if (Afull.col[p] == i) dg = Afull.val[p];
         dabs[i] = std::abs(dg);
     }
     std::vector<char> skip(n0, 0);

@@ -1136,7 +1136,16 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
         plane_coeffs(h, coeffs_ref, WAE_OP_N, pc);
         std::vector<AmgLevel> lv;
         std::vector<char> pen;
-        amg_setup(h->planes0, pc, ao, lv, &pen);
+        // opts[7]: bit k set = term k stays out of the shape matrix (strength graph, aggregation, prolongator smoothing)
+        const uint64_t excl = (uint64_t)opt(7, 0.0);
+        std::vector<zc> pc_shape;
+        if (excl) {
+            std::vector<double> cs(coeffs_ref, coeffs_ref + (size_t)2 * h->T);
+            for (int k = 0; k < h->T && k < 52; ++k)
+                if (excl >> k & 1) cs[2 * k] = cs[2 * k + 1] = 0.0;
+            plane_coeffs(h, cs.data(), WAE_OP_N, pc_shape);
+        }
+        amg_setup(h->planes0, pc, ao, lv, &pen, excl ? &pc_shape : nullptr);
         hipStream_t st = h->stream;
         {   // the penalty rows' own sub-block, plane by plane (compact numbering)
             std::vector<int> rows, loc(pen.size(), -1);
