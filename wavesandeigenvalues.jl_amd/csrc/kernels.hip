@@ -695,7 +695,7 @@ void launch_add(const cplx *X, cplx *Y, size_t count, hipStream_t st) {
 // partial[blk][i][b] = sum over this block's rows of conj(V_i[row][b]) W[row][b];  any nb <= 256
 // (thread t owns column t % nb and every R-th row, R = 256 / nb; threads beyond R*nb idle)
 constexpr int DOT_BLOCKS = 1024;
-template <int MAXV>
+template <int MAXV, bool POW2>
 __global__ __launch_bounds__(256) void dots_kernel(const cplx *__restrict__ V, size_t stride, int nv, const cplx *__restrict__ W,
                                                    int64_t n, int nb, cplx *__restrict__ partial,
                                                    const unsigned char *__restrict__ cmask) {
@@ -721,17 +721,38 @@ __global__ __launch_bounds__(256) void dots_kernel(const cplx *__restrict__ V, s
             }
         }
     }
+    // block reduction over the R row-groups.  When nb is a power of two (<= 64) the lanes of a wavefront that own the
+    // same column are reduced with xor shuffles first and only one value per wavefront and column goes through LDS; the
+    // general case sums the R LDS entries of a column serially (at nb = 1 that was 256 serial reads per vector: 168 us
+    // per launch in the narrow-batch solves of the Newton-type iterations).
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         if (i < nv) {
-            sm[tid] = acc[i];
-            __syncthreads();
-            if (tid < nb) {
-                cplx s = sm[tid];
-                for (int k = 1; k < R; ++k) { s.x += sm[k * nb + tid].x; s.y += sm[k * nb + tid].y; }
-                partial[((size_t)blockIdx.x * nv + i) * nb + tid] = s;
+            if (POW2) {
+                cplx v = acc[i];
+                for (int m = 32; m >= nb; m >>= 1) {
+                    v.x += __shfl_xor(v.x, m);
+                    v.y += __shfl_xor(v.y, m);
+                }
+                const int lane = tid & 63, wv = tid >> 6;
+                if (lane < nb) sm[wv * nb + lane] = v;
+                __syncthreads();
+                if (tid < nb) {
+                    cplx s = sm[tid];
+                    for (int k = 1; k < 4; ++k) { s.x += sm[k * nb + tid].x; s.y += sm[k * nb + tid].y; }
+                    partial[((size_t)blockIdx.x * nv + i) * nb + tid] = s;
+                }
+                __syncthreads();
+            } else {
+                sm[tid] = acc[i];
+                __syncthreads();
+                if (tid < nb) {
+                    cplx s = sm[tid];
+                    for (int k = 1; k < R; ++k) { s.x += sm[k * nb + tid].x; s.y += sm[k * nb + tid].y; }
+                    partial[((size_t)blockIdx.x * nv + i) * nb + tid] = s;
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
 }
@@ -761,10 +782,16 @@ static void dots_impl(const cplx *V, size_t stride, int nv, const cplx *W, int64
         const cplx *Vc = V + (size_t)done * stride;
         // one resident round only: dots_kernel<32> holds 3 waves/SIMD (768 workgroups on 256 CUs); a 1024-block grid ran a
         // second, one-third-full round
-        const int nblk = chunk <= 16 ? DOT_BLOCKS : 768;
-        if (chunk <= 8) hipLaunchKernelGGL(dots_kernel<8>, dim3(nblk), dim3(256), 0, st, Vc, stride, chunk, W, n, nb, partial, cmask);
-        else if (chunk <= 16) hipLaunchKernelGGL(dots_kernel<16>, dim3(nblk), dim3(256), 0, st, Vc, stride, chunk, W, n, nb, partial, cmask);
-        else hipLaunchKernelGGL(dots_kernel<32>, dim3(nblk), dim3(256), 0, st, Vc, stride, chunk, W, n, nb, partial, cmask);
+        // small problems (narrow batches): fewer, fuller workgroups -- the second-stage reduction reads nblk partials per output
+        const int64_t steps = (n + (256 / nb) - 1) / (256 / nb);
+        const int nblk = (int)std::max<int64_t>(32, std::min<int64_t>(chunk <= 16 ? DOT_BLOCKS : 768, (steps + 3) / 4));
+        const bool pow2 = nb <= 64 && (nb & (nb - 1)) == 0;     // wavefront-shuffle reduction needs the columns to tile a wavefront
+#define WAE_DOTS(MV) do { if (pow2) hipLaunchKernelGGL((dots_kernel<MV, true>), dim3(nblk), dim3(256), 0, st, Vc, stride, chunk, W, n, nb, partial, cmask); \
+                          else hipLaunchKernelGGL((dots_kernel<MV, false>), dim3(nblk), dim3(256), 0, st, Vc, stride, chunk, W, n, nb, partial, cmask); } while (0)
+        if (chunk <= 8) WAE_DOTS(8);
+        else if (chunk <= 16) WAE_DOTS(16);
+        else WAE_DOTS(32);
+#undef WAE_DOTS
         HIP_CHECK(hipGetLastError());
         int count = chunk * nb;
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((count + 31) / 32), dim3(256), 0, st, partial, nblk, count, out + (size_t)done * nb, do_sqrt);
