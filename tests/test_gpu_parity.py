@@ -541,3 +541,35 @@ def test_projected_guesses_column_split_exchange():
     A2 = buf.cpu().numpy().view(np.complex128).reshape((d, l, 2), order="F")
     assert relerr(A2, A0) < 1e-8
     Lp._drop_device()
+
+
+def test_householder_many_matches_single_runs():
+    """Several start values refined in lock-step (wae_arnoldi_shiftinvert_batch) give what the single runs give; the
+    batched Arnoldi factorisation satisfies its defining relation column by column."""
+    from wae_amd.nlevp import householder_many
+    Lp = helmholtz_family(F.rijke_terms(), n=0.01, tau=0.001)
+    Lp.solver_ref = 2 * np.pi * 400.0
+    starts = [2 * np.pi * 340.0, 2 * np.pi * 700.0, 2 * np.pi * 250.0]
+    single = [householder(Lp, z0, maxiter=12, tol=1e-10) for z0 in starts]
+    many = householder_many(Lp, starts, maxiter=12, tol=1e-10)
+    w1 = c(G["G1"]["omega"])
+    assert abs(many[0][0].params["ω"] - w1) < 1e-9 * abs(w1)                   # tutorial_04's eigenvalue
+    for (s1, n1, f1), (s2, n2, f2) in zip(single, many):
+        assert abs(s1.params["ω"] - s2.params["ω"]) <= 1e-9 * abs(s1.params["ω"])
+        assert f2 in (0, 1) and abs(n1 - n2) <= 1
+        ov = abs(np.vdot(s1.v, s2.v)) / (np.linalg.norm(s1.v) * np.linalg.norm(s2.v))
+        assert ov > 1 - 1e-8
+    # Arnoldi relation of the batch: (A_s - 0 M)^-1 M V_m = V_{m+1} H, per system
+    fam = Lp.device()
+    d, T = Lp.size(), len(Lp.terms)
+    zs = [2 * np.pi * (300 + 5j), 2 * np.pi * (650 - 3j)]
+    cA = np.array([Lp.coefficients(z) for z in zs])
+    cM = np.zeros(T, dtype=complex); cM[-1] = -1.0
+    V0 = RNG.standard_normal((d, 2)) + 1j * RNG.standard_normal((d, 2))
+    H, V = fam.arnoldi_batch(cA, cM, 4, V0, tol=1e-12)
+    for s in range(2):
+        MV = fam.spmv(cM, np.asfortranarray(V[s][:, :4]))
+        lhs = fam.solve(cA[s], MV, tol=1e-12)
+        assert relerr(lhs, V[s] @ H[s]) < 1e-7
+        assert np.allclose(V[s].conj().T @ V[s], np.eye(5), atol=1e-9)
+    Lp._drop_device()

@@ -1506,75 +1506,108 @@ int wae_rb_import(wae_family *h, int32_t S, int32_t l, uint64_t Q_dev, int32_t n
     });
 }
 
-int wae_arnoldi_shiftinvert(wae_family *h, const double *coeffsA, const double *coeffsM, int32_t m, const double *v0, int32_t op, double tol,
-                            int32_t maxit, double *H_out, double *V_out, wae_solve_info *info) {
+int wae_arnoldi_shiftinvert_batch(wae_family *h, int32_t nsys, const double *coeffsA, const double *coeffsM, int32_t m, const double *v0, int32_t op,
+                                  double tol, int32_t maxit, double *H_out, double *V_out, wae_solve_info *info) {
     return guarded([&]() {
-        WAE_REQUIRE(h && coeffsA && coeffsM && v0 && H_out && V_out && m >= 1 && m <= 256, "bad argument");
+        WAE_REQUIRE(h && nsys >= 1 && coeffsA && coeffsM && v0 && H_out && V_out && m >= 1 && m <= 256, "bad argument");
         WAE_REQUIRE(op == WAE_OP_N || op == WAE_OP_C || op == WAE_OP_T, "bad op");
         require_solver(h);
+        WAE_REQUIRE(nsys <= h->NB, "more systems than the solver batch width");
         HIP_CHECK(hipSetDevice(h->device));
         hipStream_t st = h->stream;
         wae_solve_info li;
         memset(&li, 0, sizeof(li));
         const double t0 = now_s();
         const int64_t d = h->d;
-        DevBuf<cplx> EV, t, pcM, hcol;
-        EV.alloc((size_t)d * (m + 1));
-        t.alloc((size_t)d);
-        hcol.alloc((size_t)2 * (m + 2));
+        const int T = h->T;
+        const size_t vec = (size_t)d * nsys;
+        DevBuf<cplx> EV, t, pcM, hcol, stage;
+        EV.alloc(vec * (m + 1));
+        t.alloc(vec);
+        stage.alloc(vec);
+        hcol.alloc((size_t)2 * (m + 2) * nsys);
+        // per-system plane coefficients of M (level-0 slot order) and of A (all levels)
+        std::vector<cplx> tab((size_t)nsys * h->nplanes);
         std::vector<zc> pcm;
-        plane_coeffs(h, coeffsM, op, pcm);
-        std::vector<cplx> tab(h->nplanes);
-        for (int q = 0; q < h->nplanes; ++q) { const zc c = pcm[h->slot_plane[0][q]]; tab[q] = cplx{c.real(), c.imag()}; }
+        std::vector<std::vector<zc>> pcs(nsys);
+        for (int sy = 0; sy < nsys; ++sy) {
+            plane_coeffs(h, coeffsM + (size_t)sy * 2 * T, op, pcm);
+            for (int q = 0; q < h->nplanes; ++q) { const zc c = pcm[h->slot_plane[0][q]]; tab[(size_t)sy * h->nplanes + q] = cplx{c.real(), c.imag()}; }
+            plane_coeffs(h, coeffsA + (size_t)sy * 2 * T, op, pcs[sy]);
+        }
         pcM.upload(tab.data(), tab.size(), st);
         Batch bt;
-        bt.nb = 1; bt.cps = 1; bt.nsys = 1; bt.op = op;
-        std::vector<std::vector<zc>> pcs(1);
-        plane_coeffs(h, coeffsA, op, pcs[0]);
+        bt.nb = nsys; bt.cps = 1; bt.nsys = nsys; bt.op = op;
         upload_pc(h, pcs);
         dense_setup(h, bt);
-        std::vector<zc> H((size_t)(m + 1) * m, zc(0));
-        // v_0 = v0 / ||v0||
-        HIP_CHECK(hipMemcpyAsync(t.p, v0, (size_t)d * sizeof(cplx), hipMemcpyHostToDevice, st));
-        launch_norms(t.p, d, 1, h->partial.p, hcol.p, st);
-        launch_scale_inv(t.p, hcol.p, EV.p, d, 1, st);
+        std::vector<std::vector<zc>> H(nsys, std::vector<zc>((size_t)(m + 1) * m, zc(0)));
+        std::vector<char> dead(nsys, 0);
+        // v_0 = v0 / ||v0||, column by column
+        HIP_CHECK(hipMemcpyAsync(stage.p, v0, vec * sizeof(cplx), hipMemcpyHostToDevice, st));
+        launch_colmajor_to_inter(stage.p, d, nsys, t.p, nsys, st);
+        launch_norms(t.p, d, nsys, h->partial.p, hcol.p, st);
+        launch_scale_inv(t.p, hcol.p, EV.p, d, nsys, st);
         const OpDev Mop = h->ops[0].dev(op);
-        std::vector<cplx> hh(m + 2);
+        std::vector<cplx> hh((size_t)(m + 2) * nsys), al(nsys);
         int done = 0;
         for (int j = 0; j < m; ++j) {
-            launch_spmv(Mop, pcM.p, 1 << 30, EV.p + (size_t)j * d, t.p, nullptr, 0.0, 1, MODE_AX, st);
-            gmres(h, bt, t.p, h->Xs.p, tol, maxit, &li);
+            launch_spmv(Mop, pcM.p, 1, EV.p + (size_t)j * vec, t.p, nullptr, 0.0, nsys, MODE_AX, st);
+            // Close to an eigenvalue of the NLEVP the operator is nearly singular along the wanted eigenvector and every
+            // solution of the process is dominated by that direction; the start vector (the caller's current estimate of
+            // it) is passed as the guess direction, the Krylov solve then only supplies the rest (WAE_ARNOLDI_GUESS=0: off)
+            static const bool use_dir = !(getenv("WAE_ARNOLDI_GUESS") && atoi(getenv("WAE_ARNOLDI_GUESS")) == 0);
+            gmres(h, bt, t.p, h->Xs.p, tol, maxit, &li, use_dir ? EV.p : nullptr);
             cplx *w = h->Xs.p;
-            // classical Gram-Schmidt, two passes
-            std::vector<zc> hc(j + 2, zc(0));
-            for (int pass = 0; pass < 2; ++pass) {
-                launch_dots(EV.p, (size_t)d, j + 1, w, d, 1, h->partial.p, hcol.p, st);
-                launch_axpy_neg(EV.p, (size_t)d, j + 1, hcol.p, w, d, 1, st);
-                HIP_CHECK(hipMemcpyAsync(hh.data(), hcol.p, (size_t)(j + 1) * sizeof(cplx), hipMemcpyDeviceToHost, st));
+            std::vector<std::vector<zc>> hc(nsys, std::vector<zc>(j + 2, zc(0)));
+            for (int pass = 0; pass < 2; ++pass) {               // classical Gram-Schmidt, two passes, per column
+                launch_dots(EV.p, vec, j + 1, w, d, nsys, h->partial.p, hcol.p, st);
+                launch_axpy_neg(EV.p, vec, j + 1, hcol.p, w, d, nsys, st);
+                HIP_CHECK(hipMemcpyAsync(hh.data(), hcol.p, (size_t)(j + 1) * nsys * sizeof(cplx), hipMemcpyDeviceToHost, st));
                 HIP_CHECK(hipStreamSynchronize(st));
-                for (int i = 0; i <= j; ++i) hc[i] += zc(hh[i].x, hh[i].y);
+                for (int sy = 0; sy < nsys; ++sy)
+                    for (int i = 0; i <= j; ++i) hc[sy][i] += zc(hh[(size_t)i * nsys + sy].x, hh[(size_t)i * nsys + sy].y);
             }
-            launch_norms(w, d, 1, h->partial.p, hcol.p, st);
-            HIP_CHECK(hipMemcpyAsync(hh.data(), hcol.p, sizeof(cplx), hipMemcpyDeviceToHost, st));
+            launch_norms(w, d, nsys, h->partial.p, hcol.p, st);
+            HIP_CHECK(hipMemcpyAsync(hh.data(), hcol.p, (size_t)nsys * sizeof(cplx), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
-            hc[j + 1] = hh[0].x;
-            for (int i = 0; i <= j + 1; ++i) H[(size_t)j * (m + 1) + i] = hc[i];
             done = j + 1;
-            double scale = 0.0;
-            for (int i = 0; i <= j; ++i) scale = std::max(scale, std::abs(hc[i]));
-            if (!(hh[0].x > 1e-14 * scale)) { H[(size_t)j * (m + 1) + j + 1] = 0; break; }
-            launch_scale_inv(w, hcol.p, EV.p + (size_t)(j + 1) * d, d, 1, st);
+            bool any_alive = false;
+            for (int sy = 0; sy < nsys; ++sy) {
+                double scale = 0.0;
+                for (int i = 0; i <= j; ++i) scale = std::max(scale, std::abs(hc[sy][i]));
+                const bool brk = dead[sy] || !(hh[sy].x > 1e-14 * scale);    // invariant subspace: this column stops here
+                hc[sy][j + 1] = brk ? zc(0) : zc(hh[sy].x);
+                if (!dead[sy]) for (int i = 0; i <= j + 1; ++i) H[sy][(size_t)j * (m + 1) + i] = hc[sy][i];
+                if (brk) dead[sy] = 1;
+                al[sy] = brk ? cplx{0.0, 0.0} : cplx{hh[sy].x, 0.0};
+                any_alive = any_alive || !brk;
+            }
+            if (!any_alive) break;
+            h->ydev.upload(al.data(), nsys, st);
+            launch_scale_inv(w, h->ydev.p, EV.p + (size_t)(j + 1) * vec, d, nsys, st);
+            HIP_CHECK(hipStreamSynchronize(st));
         }
-        if (done < m) launch_fill_zero(EV.p + (size_t)(done + 1) * d, (size_t)(m - done) * d, st);
-        HIP_CHECK(hipMemcpyAsync(V_out, EV.p, (size_t)d * (m + 1) * sizeof(cplx), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        memcpy(H_out, H.data(), H.size() * sizeof(zc));
-        EV.release(); t.release(); pcM.release(); hcol.release();
+        if (done < m) launch_fill_zero(EV.p + (size_t)(done + 1) * vec, (size_t)(m - done) * vec, st);
+        // V_out[sys] = d x (m+1) column-major
+        for (int j = 0; j <= m; ++j) {
+            launch_inter_to_colmajor(EV.p + (size_t)j * vec, nsys, d, nsys, stage.p, st);
+            for (int sy = 0; sy < nsys; ++sy)
+                HIP_CHECK(hipMemcpyAsync(V_out + ((size_t)sy * (m + 1) + j) * d * 2, stage.p + (size_t)sy * d, (size_t)d * sizeof(cplx),
+                                         hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
+        for (int sy = 0; sy < nsys; ++sy) memcpy(H_out + (size_t)sy * (m + 1) * m * 2, H[sy].data(), H[sy].size() * sizeof(zc));
+        EV.release(); t.release(); pcM.release(); hcol.release(); stage.release();
         li.seconds = now_s() - t0;
         const int rc_ = info_code(li);
         if (info) *info = li;
         return rc_;
     });
+}
+
+int wae_arnoldi_shiftinvert(wae_family *h, const double *coeffsA, const double *coeffsM, int32_t m, const double *v0, int32_t op, double tol,
+                            int32_t maxit, double *H_out, double *V_out, wae_solve_info *info) {
+    return wae_arnoldi_shiftinvert_batch(h, 1, coeffsA, coeffsM, m, v0, op, tol, maxit, H_out, V_out, info);
 }
 
 int wae_perturb(wae_family *h, const double *coeff_table, int32_t N, const double *v0, const double *v0adj, int32_t norm_mode_in, const double *coeffsY,

@@ -5,7 +5,8 @@ from .beyn import (beyn, compute_moment_matrices, gauss_points, generate_subspac
                    pos_test, project, wn)  # noqa: F401
 from .linopfam import (DeviceFamily, LinearOperatorFamily, Operator, Solution, Term, conv_radius, estimate_pol, pade,  # noqa: F401
                        pade_, poly_roots, polyval)
-from .local_solvers import (count_poles_and_zeros, decode_error_flag, eigs, householder, householder_update, inveriter,  # noqa: F401
+from .local_solvers import (count_poles_and_zeros, decode_error_flag, eigs, eigs_many, householder, householder_many,
+                            householder_update, inveriter,  # noqa: F401
                             itsol_arpack_9999, itsol_arpack_exception, itsol_converged, itsol_impossible, itsol_isnan,
                             itsol_maxiter, itsol_singular_exception, itsol_slow_convergence, itsol_unknown, lancaster,
                             mslp, padesolve, rf2s, traceiter)

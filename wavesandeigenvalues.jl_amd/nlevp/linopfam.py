@@ -252,6 +252,22 @@ class DeviceFamily:
         self.last_code = code
         return H, V
 
+    def arnoldi_batch(self, coeffsA, coeffsM, m, V0, op=OP_N, tol=1e-12, maxit=300):
+        """wae_arnoldi_shiftinvert_batch: nsys Arnoldi processes in lock-step.  coeffsA, coeffsM: (nsys, T); V0: (d, nsys).
+        Returns H (nsys, m+1, m) and V (nsys, d, m+1)."""
+        cA = np.ascontiguousarray(coeffsA, dtype=np.complex128).reshape(-1, self.T)
+        nsys = cA.shape[0]
+        cM = np.ascontiguousarray(np.broadcast_to(np.asarray(coeffsM, dtype=np.complex128).reshape(-1, self.T), (nsys, self.T)))
+        V0 = np.asfortranarray(np.asarray(V0, dtype=np.complex128).reshape(self.d, nsys))
+        H = np.zeros((nsys, m, m + 1), dtype=np.complex128)            # each block column-major (m+1) x m
+        V = np.zeros((nsys, m + 1, self.d), dtype=np.complex128)        # each block column-major d x (m+1)
+        info = SolveInfo()
+        code = check(_lib.lib().wae_arnoldi_shiftinvert_batch(self.handle, nsys, zptr(cA), zptr(cM), m, zptr(V0), op, tol, maxit,
+                                                              zptr(H), zptr(V), C.byref(info)))
+        self.last_info = info.as_dict()
+        self.last_code = code
+        return H.transpose(0, 2, 1), V.transpose(0, 2, 1)
+
     def perturb(self, coeff_table, N, v0, v0adj, norm_mode=1, coeffsY=None, tol=1e-12, maxit=400):
         """wae_perturb: the whole recurrence on the device. coeff_table[(m,n)] = T coefficients of L(m,n)."""
         ct = np.ascontiguousarray(coeff_table, dtype=np.complex128).reshape((N + 1) * (N + 1), self.T)

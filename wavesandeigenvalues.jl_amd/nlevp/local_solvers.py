@@ -439,3 +439,147 @@ def count_poles_and_zeros(L, G, N=16, output=False):
         X = L(z).solve(L(z, 1) @ eye)
         s += np.trace(X) * w
     return s / 2 / np.pi / 1j
+
+
+# ------------------------------------------------------------------------------------------------------
+# many start values at once: the Newton-type refinement of all the estimates a Beyn solve returned, in lock-step.
+# A single-column solve is latency-bound on the device (0.65 ms per Krylov iteration whether the batch holds one column
+# or eight), so refining 8 estimates together costs about as much as refining one.  Same iteration as `householder`
+# (Householder.jl:70-192) per start value; only the order of the device work changes.
+# ------------------------------------------------------------------------------------------------------
+def eigs_many(fam, cA, cM, v0s, op, sigmas, nev=1, tol=1e-12, maxiter=300, stol=1e-12, smax=400):
+    """`eigs` for nsys operator pairs (A_s - sigma_s M, M) in lock-step.  cA: (nsys, T) coefficient rows, cM: (T,).
+    Returns per system (lam[nev], V[d, nev], gap) or an EigsError instance."""
+    cA = np.asarray(cA, dtype=np.complex128)
+    nsys, d = cA.shape[0], fam.d
+    step = int(min(d, max(6, 2 * nev + 2)))
+    cAs = cA - np.asarray(sigmas, dtype=np.complex128)[:, None] * cM[None, :]
+    sig_out = np.conj(sigmas) if op == OP_C else np.asarray(sigmas)
+    V0 = np.asfortranarray(np.asarray(v0s, dtype=np.complex128).reshape(d, nsys)).copy()
+    out = [None] * nsys
+    pending = list(range(nsys))
+    total = 0
+    while pending and total < maxiter:
+        H, V = fam.arnoldi_batch(cAs[pending], cM, step, V0[:, pending], op=op, tol=stol, maxit=smax)
+        total += step
+        failed = fam.last_info["n_unconverged"] > 0 and fam.last_info["relres_max"] > 1e-4
+        still = []
+        for q, s in enumerate(pending):
+            Hs, Vs = H[q], V[q]
+            m = step
+            for j in range(step):
+                if Hs[j + 1, j] == 0:
+                    m = j + 1
+                    break
+            theta, Yr = np.linalg.eig(Hs[:m, :m])
+            order = np.argsort(-np.abs(theta))
+            theta, Yr = theta[order], Yr[:, order]
+            k = min(nev, m)
+            res = np.abs(Hs[m, m - 1]) * np.abs(Yr[m - 1, :k])
+            X = Vs[:, :m] @ Yr[:, :k]
+            X = X / np.linalg.norm(X, axis=0)
+            gap = abs(1.0 / theta[k]) if m > k else np.inf
+            out[s] = (sig_out[s] + 1.0 / theta[:k], X, gap)
+            if not (np.all(res <= tol * np.abs(theta[:k])) or m < step or m >= d):
+                if failed:
+                    out[s] = EigsError("inner solves stalled")
+                else:
+                    V0[:, s] = X @ np.ones(k)
+                    still.append(s)
+        pending = still
+    return out
+
+
+def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, v0s=None, v0s_adj=None, output=False):
+    """[(sol, n, flag), ...] = householder_many(L, zs; ...): `householder` for several start values, the device work
+    (two shift-invert Arnoldi processes per Newton step and start value) batched over the start values."""
+    zs = [complex(z) for z in zs]
+    ns = len(zs)
+    d = L.size()
+    fam = L.ensure_solver()
+    active, mode = L.active, L.mode
+    V = np.ones((d, ns), dtype=np.complex128) if v0s is None else np.array(v0s, dtype=np.complex128).reshape(d, ns)
+    W = np.conj(V) if v0s_adj is None else np.array(v0s_adj, dtype=np.complex128).reshape(d, ns)
+    z = list(zs)
+    z0 = [complex(np.inf)] * ns
+    lam = [np.inf] * ns
+    n = [0] * ns
+    flag = [1] * ns
+    hist = [[] for _ in range(ns)]
+    state = [dict() for _ in range(ns)]
+    T = len(L.terms)
+    cM = np.zeros(T, dtype=np.complex128)
+    cM[T - 1] = -1.0                                      # M = -L.terms[end].coeff  (Householder.jl:92)
+    upd = lambda c: householder_update([factorial(i) * ci for i, ci in enumerate(c)])   # noqa: E731
+    while True:
+        act = [s for s in range(ns) if flag[s] == 1 and abs(z[s] - z0[s]) > tol and n[s] < maxiter]
+        if not act:
+            break
+        cA, sig = [], []
+        for s in act:
+            hist[s].append(z[s])
+            z0[s] = z[s]
+            L.params[L.eigval] = z[s]
+            L.params[L.auxval] = 0
+            cA.append(L.coefficients(z[s]))
+            gp, lp = state[s].get("gap", np.inf), state[s].get("lam", np.inf)
+            sig.append(1e-5 * gp if (np.isfinite(gp) and lp < 1e-4 * gp) else 0.0)
+        cA = np.array(cA)
+        try:
+            right = eigs_many(fam, cA, cM, V[:, act], OP_N, sig, stol=L.solver_tol, smax=L.solver_maxit)
+            left = eigs_many(fam, cA, cM, W[:, act], OP_C, sig, stol=L.solver_tol, smax=L.solver_maxit)
+        except WaeError as e:
+            for s in act:
+                flag[s] = -6 if e.code == -2 else -2
+            break
+        for q, s in enumerate(act):
+            if isinstance(right[q], Exception) or isinstance(left[q], Exception):
+                flag[s] = -4
+                continue
+            lam_r, v_r, gap = right[q]
+            lam_l, v_l, _ = left[q]
+            state[s]["gap"] = gap if np.isfinite(gap) else state[s].get("gap", np.inf)
+            state[s]["lam"] = float(np.min(np.abs(lam_r)))
+            L.params[L.eigval] = z[s]
+            L.params[L.auxval] = lam_r[0]
+            L.active = [L.auxval, L.eigval]
+            try:
+                sol = Solution(L.params, v_r[:, 0], v_l[:, 0], L.auxval)
+                perturb_(sol, L, L.eigval, order, mode="householder")
+                dz = upd(sol.eigval_pert[f"{L.eigval}/Taylor"])
+            except WaeError as e:
+                flag[s] = -6 if e.code == -2 else -2
+                continue
+            finally:
+                L.active = [L.eigval]
+            lam[s] = lam_r[0]
+            if output:
+                print(s, n[s], "\t", abs(lam[s]), "\t", abs(dz), "\t", z[s])
+            z[s] = z[s] + relax * dz
+            V[:, s] = (1 - relax) * V[:, s] + relax * v_r[:, 0]
+            W[:, s] = (1 - relax) * W[:, s] + relax * v_l[:, 0]
+            n[s] += 1
+    out = []
+    for s in range(ns):
+        f = flag[s]
+        L.params[L.eigval] = z[s]
+        L.params[L.auxval] = lam[s] if np.isfinite(lam[s]) else 0
+        if f == 1:
+            hist[s].append(z[s])
+            if n[s] >= maxiter:
+                f = -1
+            elif abs(lam[s]) <= lam_tol:
+                f = 1
+            elif abs(z[s] - z0[s]) <= tol:
+                f = 0
+            elif np.isnan(z[s]):
+                f = -5
+            else:
+                f = -3
+        L.active, L.mode = active, mode
+        v0, v0a = _normalise(L, V[:, s].copy(), W[:, s].copy())
+        sol = Solution(L.params, v0, v0a, L.eigval)
+        sol.history = hist[s]
+        out.append((sol, n[s], f))
+    L.active, L.mode = active, mode
+    return out
