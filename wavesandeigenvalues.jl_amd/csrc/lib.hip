@@ -1552,11 +1552,7 @@ int wae_arnoldi_shiftinvert_batch(wae_family *h, int32_t nsys, const double *coe
         int done = 0;
         for (int j = 0; j < m; ++j) {
             launch_spmv(Mop, pcM.p, 1, EV.p + (size_t)j * vec, t.p, nullptr, 0.0, nsys, MODE_AX, st);
-            // Close to an eigenvalue of the NLEVP the operator is nearly singular along the wanted eigenvector and every
-            // solution of the process is dominated by that direction; the start vector (the caller's current estimate of
-            // it) is passed as the guess direction, the Krylov solve then only supplies the rest (WAE_ARNOLDI_GUESS=0: off)
-            static const bool use_dir = !(getenv("WAE_ARNOLDI_GUESS") && atoi(getenv("WAE_ARNOLDI_GUESS")) == 0);
-            gmres(h, bt, t.p, h->Xs.p, tol, maxit, &li, use_dir ? EV.p : nullptr);
+            gmres(h, bt, t.p, h->Xs.p, tol, maxit, &li);
             cplx *w = h->Xs.p;
             std::vector<std::vector<zc>> hc(nsys, std::vector<zc>(j + 2, zc(0)));
             for (int pass = 0; pass < 2; ++pass) {               // classical Gram-Schmidt, two passes, per column
