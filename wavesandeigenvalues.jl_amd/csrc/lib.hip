@@ -350,6 +350,7 @@ struct ColState {
     std::vector<zc> g;
     std::vector<double> cs;
     std::vector<zc> sn;
+    std::vector<zc> cdef;   // deflation: c_j = u^H M^-1 A v_j, the component removed from every new Krylov vector
     int steps = 0;          // Arnoldi steps to use for the update
     bool conv = false;
 };
@@ -405,7 +406,18 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
     const size_t vec = (size_t)n * nb;
     // narrow batches get a longer recurrence from the same workspace (near-singular systems in the Newton-type
     // solvers stall under short restarts); they also afford a second Gram-Schmidt pass
-    const int m = (int)std::min<size_t>(150, h->V.n / vec - 1);
+    // Deflation of a known near-null direction g (guess_dir; the Newton-type solvers pass their current eigenvector
+    // estimate): with u = M^-1 A g, u^ = u/||u||, the Krylov process runs on P M^-1 A, P = I - u^ u^H (u^ sits in front of
+    // the basis and takes part in the Gram-Schmidt step; the coefficient c_j = u^H M^-1 A v_j it removes is kept), and
+    // the solution is x = V y + alpha g with alpha = (u^H r0 - sum_j y_j c_j)/||u||, which cancels the u^ component of
+    // the residual exactly.  Close to an eigenvalue of the NLEVP the operator is nearly singular along g: the undeflated
+    // solves needed 50-100 iterations of a long recurrence there, the deflated operator behaves like a regular shift.
+    static const bool env_defl = !(getenv("WAE_DEFLATE") && atoi(getenv("WAE_DEFLATE")) == 0);
+    // (a single-level hierarchy is the exact dense inverse: nothing to deflate, and the inverse of a numerically singular
+    // small matrix is not something to build a projector from)
+    const bool deflate = guess_dir != nullptr && env_defl && h->ops.size() > 1;
+    const int off = deflate ? 1 : 0;
+    const int m = (int)std::min<size_t>(150, h->V.n / vec - 1) - off;
     static const char *env_re = getenv("WAE_REORTH");
     const bool reorth = env_re ? atoi(env_re) != 0 : nb <= 8;
     const OpDev A = h->ops[0].dev(bt.op);
@@ -449,7 +461,26 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
         }
     };
     const unsigned char *mk = nullptr;
-    if (guess_dir) {
+    std::vector<double> unorm(nb, 0.0);
+    std::vector<zc> beta0(nb, zc(0));
+    if (deflate) {
+        launch_spmv(A, pc, bt.cps, guess_dir, h->W.p, nullptr, 0.0, nb, MODE_AX, st);
+        launch_copy(vcycle(h, bt, 0, h->W.p), h->V.p, vec, st);
+        launch_norms(h->V.p, n, nb, h->partial.p, h->hdev.p, st);
+        launch_norms(guess_dir, n, nb, h->partial.p, h->hdev.p + nb, st);
+        HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, (size_t)2 * nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        // ||M^-1 A g|| <= 1e-12 ||g||: g is a null vector to rounding, u^ would be noise -- no deflation for that column
+        std::vector<cplx> un(nb);
+        for (int b = 0; b < nb; ++b) {
+            unorm[b] = (hp[b].x > 1e-12 * hp[nb + b].x && hp[nb + b].x > 0.0) ? hp[b].x : 0.0;
+            un[b] = cplx{unorm[b], 0.0};
+        }
+        h->ydev.upload(un.data(), nb, st);
+        launch_scale_inv(h->V.p, h->ydev.p, h->V.p, n, nb, st);          // a column without deflation gets u^ = 0
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    if (guess_dir && !deflate) {
         // initial guess x0 = alpha * g, alpha = (M^-1 A g)^H (M^-1 b) / ||M^-1 A g||^2 per column: when the solution is
         // dominated by a known direction (inverse iteration close to an eigenvalue) the Krylov solve only has to
         // produce the small rest
@@ -471,7 +502,7 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
         first = false;
     }
     while (true) {
-        const cplx *z0;
+        cplx *z0;
         if (first) {
             z0 = vcycle(h, bt, 0, B);
         } else {
@@ -479,9 +510,14 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
             z0 = vcycle(h, bt, 0, h->W.p);
         }
         first = false;
+        if (deflate) {                                   // r0 <- P r0, beta0 = u^H r0
+            launch_dots(h->V.p, 0, 1, z0, n, nb, h->partial.p, h->hdev.p + nb, st);
+            launch_axpy_neg(h->V.p, 0, 1, h->hdev.p + nb, z0, n, nb, st);
+        }
         launch_norms(z0, n, nb, h->partial.p, h->hdev.p, st);
-        HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, (size_t)2 * nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
+        if (deflate) for (int b = 0; b < nb; ++b) beta0[b] = zc(hp[nb + b].x, hp[nb + b].y);
         if (x0_unchecked) {
             // a guess that is worse than no guess (an ill-conditioned projected system) is dropped, column by column
             x0_unchecked = false;
@@ -505,8 +541,25 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
             }
             if (!done[b]) all_done = false;
         }
-        if (all_done || total_it >= maxit || nan_seen) break;
-        launch_scale_inv(z0, h->hdev.p, h->V.p, n, nb, st);     // V0 = M^-1 r / beta
+        if (all_done || total_it >= maxit || nan_seen) {
+            // the projected residual is small, but its u^ component (beta0) has not been cancelled yet for THIS residual:
+            // x += (beta0/||u||) g.  (When the right-hand side lies along M^-1 A g -- an Arnoldi step started from an
+            // eigenvector -- that is the whole solution.)
+            if (deflate && !nan_seen) {
+                std::vector<cplx> al(nb, cplx{0.0, 0.0});
+                for (int b = 0; b < nb; ++b) {
+                    if (!(unorm[b] > 0.0)) continue;
+                    const zc a = beta0[b] / unorm[b];
+                    if (std::isfinite(a.real()) && std::isfinite(a.imag())) al[b] = cplx{a.real(), a.imag()};
+                }
+                h->ydev.upload(al.data(), nb, st);
+                launch_lincomb(guess_dir, 0, 1, h->ydev.p, h->U.p, n, nb, st);
+                launch_add(h->U.p, X, vec, st);
+                HIP_CHECK(hipStreamSynchronize(st));
+            }
+            break;
+        }
+        launch_scale_inv(z0, h->hdev.p, h->V.p + (size_t)off * vec, n, nb, st);     // V0 = M^-1 r / beta
         if (use_mask && nb >= 8) {
             for (int k = 0; k < nch; ++k) cm[k] = 0;
             for (int b = 0; b < nb; ++b) if (!done[b]) cm[b >> 3] = 1;
@@ -520,25 +573,27 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
             c.g[0] = hp[b].x;
             c.cs.assign(m, 0.0);
             c.sn.assign(m, zc(0));
+            c.cdef.assign(m, zc(0));
             c.steps = 0;
             c.conv = done[b];
         }
         int j = 0;
         for (; j < m && total_it < maxit; ++j) {
-            const cplx *vj = h->V.p + (size_t)j * vec;
+            const cplx *vj = h->V.p + (size_t)(off + j) * vec;
+            const int nvj = off + j + 1;                         // vectors in the orthogonalisation set (u^ first when deflating)
             launch_spmv(A, pc, bt.cps, vj, h->W.p, nullptr, 0.0, nb, MODE_AX, st, mk);
             cplx *w = vcycle(h, bt, 0, h->W.p, mk);              // w = M^-1 A v_j  (lives in a V-cycle buffer)
-            launch_dots(h->V.p, vec, j + 1, w, n, nb, h->partial.p, h->hdev.p, st, mk);
-            launch_axpy_neg(h->V.p, vec, j + 1, h->hdev.p, w, n, nb, st, mk);
+            launch_dots(h->V.p, vec, nvj, w, n, nb, h->partial.p, h->hdev.p, st, mk);
+            launch_axpy_neg(h->V.p, vec, nvj, h->hdev.p, w, n, nb, st, mk);
             if (reorth) {   // CGS2: h += V^H w', w' -= V (V^H w')
-                cplx *h2 = h->hdev.p + (size_t)(m + 2) * nb;
-                launch_dots(h->V.p, vec, j + 1, w, n, nb, h->partial.p, h2, st, mk);
-                launch_axpy_neg(h->V.p, vec, j + 1, h2, w, n, nb, st, mk);
-                launch_add(h2, h->hdev.p, (size_t)(j + 1) * nb, st);
+                cplx *h2 = h->hdev.p + (size_t)(off + m + 2) * nb;
+                launch_dots(h->V.p, vec, nvj, w, n, nb, h->partial.p, h2, st, mk);
+                launch_axpy_neg(h->V.p, vec, nvj, h2, w, n, nb, st, mk);
+                launch_add(h2, h->hdev.p, (size_t)nvj * nb, st);
             }
-            launch_norms(w, n, nb, h->partial.p, h->hdev.p + (size_t)(j + 1) * nb, st, mk);
-            launch_scale_inv(w, h->hdev.p + (size_t)(j + 1) * nb, h->V.p + (size_t)(j + 1) * vec, n, nb, st, mk);
-            HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, (size_t)(j + 2) * nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
+            launch_norms(w, n, nb, h->partial.p, h->hdev.p + (size_t)nvj * nb, st, mk);
+            launch_scale_inv(w, h->hdev.p + (size_t)nvj * nb, h->V.p + (size_t)nvj * vec, n, nb, st, mk);
+            HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, (size_t)(nvj + 1) * nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
             ++total_it;
             bool all_conv = true;
@@ -546,7 +601,8 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
                 ColState &c = cs[b];
                 if (c.conv) continue;
                 zc *Hc = &c.H[(size_t)j * (m + 1)];
-                for (int i = 0; i <= j + 1; ++i) Hc[i] = zc(hp[(size_t)i * nb + b].x, hp[(size_t)i * nb + b].y);
+                for (int i = 0; i <= j + 1; ++i) Hc[i] = zc(hp[(size_t)(off + i) * nb + b].x, hp[(size_t)(off + i) * nb + b].y);
+                if (deflate) c.cdef[j] = zc(hp[b].x, hp[b].y);
                 for (int i = 0; i < j; ++i) {
                     const zc a = Hc[i], bb = Hc[i + 1];
                     Hc[i] = c.cs[i] * a + c.sn[i] * bb;
@@ -599,9 +655,23 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
         }
         if (ju > 0) {
             h->ydev.upload(y.data(), (size_t)ju * nb, st);
-            launch_lincomb(h->V.p, vec, ju, h->ydev.p, h->U.p, n, nb, st);
+            launch_lincomb(h->V.p + (size_t)off * vec, vec, ju, h->ydev.p, h->U.p, n, nb, st);
             launch_add(h->U.p, X, vec, st);
             HIP_CHECK(hipStreamSynchronize(st));       // y is a stack vector
+        }
+        if (deflate) {                                    // x += alpha g: cancels the u^ component of the residual
+            std::vector<cplx> al(nb, cplx{0.0, 0.0});
+            for (int b = 0; b < nb; ++b) {
+                if (!(unorm[b] > 0.0)) continue;
+                zc acc = beta0[b];
+                for (int i = 0; i < cs[b].steps; ++i) acc -= zc(y[(size_t)i * nb + b].x, y[(size_t)i * nb + b].y) * cs[b].cdef[i];
+                acc /= unorm[b];
+                if (std::isfinite(acc.real()) && std::isfinite(acc.imag())) al[b] = cplx{acc.real(), acc.imag()};
+            }
+            h->ydev.upload(al.data(), nb, st);
+            launch_lincomb(guess_dir, 0, 1, h->ydev.p, h->U.p, n, nb, st);
+            launch_add(h->U.p, X, vec, st);
+            HIP_CHECK(hipStreamSynchronize(st));
         }
         if (nan_seen) break;
         // A short recurrence that ended with every column converged by its Arnoldi estimate needs no confirmation by a
@@ -1552,7 +1622,8 @@ int wae_arnoldi_shiftinvert_batch(wae_family *h, int32_t nsys, const double *coe
         int done = 0;
         for (int j = 0; j < m; ++j) {
             launch_spmv(Mop, pcM.p, 1, EV.p + (size_t)j * vec, t.p, nullptr, 0.0, nsys, MODE_AX, st);
-            gmres(h, bt, t.p, h->Xs.p, tol, maxit, &li);
+            // the start vector is the caller's estimate of the wanted eigenvector: deflated out of every solve of the process
+            gmres(h, bt, t.p, h->Xs.p, tol, maxit, &li, EV.p);
             cplx *w = h->Xs.p;
             std::vector<std::vector<zc>> hc(nsys, std::vector<zc>(j + 2, zc(0)));
             for (int pass = 0; pass < 2; ++pass) {               // classical Gram-Schmidt, two passes, per column
