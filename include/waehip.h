@@ -195,9 +195,12 @@ int wae_arnoldi_shiftinvert(wae_family *h, const double *coeffsA, const double *
  * refining all the estimates a Beyn solve returned costs about as much as refining one, because a single-column solve
  * is latency-bound.  coeffsA, coeffsM: nsys x T; v0: d x nsys column-major; H_out: nsys blocks of (m+1) x m;
  * V_out: nsys blocks of d x (m+1), column-major.  A column whose Krylov space becomes invariant stops (its later H
- * entries and basis vectors are zero). */
+ * entries and basis vectors are zero).  ritz_tol > 0: stop as soon as the dominant Ritz pair of every process has a
+ * relative residual |h_{k+1,k}| |y_k| / |theta| <= ritz_tol (the H columns and basis vectors of the steps not taken
+ * are zero); 0: always m steps. */
 int wae_arnoldi_shiftinvert_batch(wae_family *h, int32_t nsys, const double *coeffsA, const double *coeffsM, int32_t m, const double *v0,
-                                  int32_t op, double tol, int32_t maxit, double *H_out, double *V_out, wae_solve_info *info);
+                                  int32_t op, double tol, int32_t maxit, double ritz_tol, double *H_out, double *V_out,
+                                  wae_solve_info *info);
 
 /* -- adjoint perturbation recurrence -----------------------------------------------------------------
  * Replaces `perturb` / `perturb_disk` / `perturb_norm` (perturbation.jl:319-367,374-444,487-560) for a

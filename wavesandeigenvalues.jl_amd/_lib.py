@@ -79,8 +79,8 @@ def lib():
     L.wae_eig_residuals.argtypes = [C.c_void_p, C.c_int32, dp, dp, C.c_uint64, dp]
     L.wae_arnoldi_shiftinvert.argtypes = [C.c_void_p, dp, dp, C.c_int32, dp, C.c_int32, C.c_double, C.c_int32, dp, dp,
                                           C.POINTER(SolveInfo)]
-    L.wae_arnoldi_shiftinvert_batch.argtypes = [C.c_void_p, C.c_int32, dp, dp, C.c_int32, dp, C.c_int32, C.c_double, C.c_int32, dp, dp,
-                                                C.POINTER(SolveInfo)]
+    L.wae_arnoldi_shiftinvert_batch.argtypes = [C.c_void_p, C.c_int32, dp, dp, C.c_int32, dp, C.c_int32, C.c_double, C.c_int32, C.c_double,
+                                                dp, dp, C.POINTER(SolveInfo)]
     L.wae_perturb.argtypes = [C.c_void_p, dp, C.c_int32, dp, dp, C.c_int32, dp, C.c_double, C.c_int32, dp, dp,
                               C.POINTER(SolveInfo)]
     L.wae_bench_spmv.argtypes = [C.c_void_p, dp, C.c_int32, C.c_int32, dp]

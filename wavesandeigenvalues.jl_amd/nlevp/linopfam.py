@@ -252,7 +252,7 @@ class DeviceFamily:
         self.last_code = code
         return H, V
 
-    def arnoldi_batch(self, coeffsA, coeffsM, m, V0, op=OP_N, tol=1e-12, maxit=300):
+    def arnoldi_batch(self, coeffsA, coeffsM, m, V0, op=OP_N, tol=1e-12, maxit=300, ritz_tol=0.0):
         """wae_arnoldi_shiftinvert_batch: nsys Arnoldi processes in lock-step.  coeffsA, coeffsM: (nsys, T); V0: (d, nsys).
         Returns H (nsys, m+1, m) and V (nsys, d, m+1)."""
         cA = np.ascontiguousarray(coeffsA, dtype=np.complex128).reshape(-1, self.T)
@@ -263,7 +263,7 @@ class DeviceFamily:
         V = np.zeros((nsys, m + 1, self.d), dtype=np.complex128)        # each block column-major d x (m+1)
         info = SolveInfo()
         code = check(_lib.lib().wae_arnoldi_shiftinvert_batch(self.handle, nsys, zptr(cA), zptr(cM), m, zptr(V0), op, tol, maxit,
-                                                              zptr(H), zptr(V), C.byref(info)))
+                                                              float(ritz_tol), zptr(H), zptr(V), C.byref(info)))
         self.last_info = info.as_dict()
         self.last_code = code
         return H.transpose(0, 2, 1), V.transpose(0, 2, 1)

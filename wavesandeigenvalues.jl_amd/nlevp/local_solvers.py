@@ -82,7 +82,12 @@ def eigs(A, M, nev=1, v0=None, ncv=None, tol=1e-12, maxiter=300, sigma=0.0, retu
     total = 0
     failed_runs = 0
     while total < maxiter:
-        H, V = fam.arnoldi(cA, cM, step, v, op=A.op, tol=stol, maxit=smax)
+        if nev == 1:
+            # one wanted pair: the device stops the factorisation as soon as its Ritz residual is below tol
+            Hb, Vb = fam.arnoldi_batch(cA[None, :], cM, step, v[:, None], op=A.op, tol=stol, maxit=smax, ritz_tol=tol)
+            H, V = Hb[0], Vb[0]
+        else:
+            H, V = fam.arnoldi(cA, cM, step, v, op=A.op, tol=stol, maxit=smax)
         total += step
         # inner solves that did not even reach 1e-4 (far outside the range the multigrid hierarchy was built for, or
         # beyond what the mesh resolves) cannot produce Ritz pairs: give up like ARPACK does instead of restarting
@@ -92,7 +97,10 @@ def eigs(A, M, nev=1, v0=None, ncv=None, tol=1e-12, maxiter=300, sigma=0.0, retu
             if failed_runs >= 2:
                 raise EigsError(f"inner solves stalled at relative residual {fam.last_info['relres_max']:.1e}")
         m = step
-        for j in range(step):                # invariant subspace: H[j+1,j] == 0
+        while m > 1 and not H[:, m - 1].any():   # steps not taken (early exit on the device): zero columns
+            m -= 1
+        taken = m
+        for j in range(m):                   # invariant subspace: H[j+1,j] == 0
             if H[j + 1, j] == 0:
                 m = j + 1
                 break
@@ -106,7 +114,7 @@ def eigs(A, M, nev=1, v0=None, ncv=None, tol=1e-12, maxiter=300, sigma=0.0, retu
         last = (sig_out + 1.0 / theta[:k], X)
         if m > k:
             gap = abs(1.0 / theta[k])          # crude estimate of the next eigenvalue's modulus
-        if np.all(res <= tol * np.abs(theta[:k])) or m < step or m >= d:
+        if np.all(res <= tol * np.abs(theta[:k])) or m < taken or m >= d:
             return last + (gap,) if return_gap else last
         v = X @ np.ones(k)                    # restart with the wanted Ritz vectors
     if last is None:
@@ -460,14 +468,18 @@ def eigs_many(fam, cA, cM, v0s, op, sigmas, nev=1, tol=1e-12, maxiter=300, stol=
     pending = list(range(nsys))
     total = 0
     while pending and total < maxiter:
-        H, V = fam.arnoldi_batch(cAs[pending], cM, step, V0[:, pending], op=op, tol=stol, maxit=smax)
+        H, V = fam.arnoldi_batch(cAs[pending], cM, step, V0[:, pending], op=op, tol=stol, maxit=smax,
+                                 ritz_tol=tol if nev == 1 else 0.0)
         total += step
         failed = fam.last_info["n_unconverged"] > 0 and fam.last_info["relres_max"] > 1e-4
         still = []
         for q, s in enumerate(pending):
             Hs, Vs = H[q], V[q]
             m = step
-            for j in range(step):
+            while m > 1 and not Hs[:, m - 1].any():
+                m -= 1
+            taken = m
+            for j in range(m):
                 if Hs[j + 1, j] == 0:
                     m = j + 1
                     break
@@ -480,7 +492,7 @@ def eigs_many(fam, cA, cM, v0s, op, sigmas, nev=1, tol=1e-12, maxiter=300, stol=
             X = X / np.linalg.norm(X, axis=0)
             gap = abs(1.0 / theta[k]) if m > k else np.inf
             out[s] = (sig_out[s] + 1.0 / theta[:k], X, gap)
-            if not (np.all(res <= tol * np.abs(theta[:k])) or m < step or m >= d):
+            if not (np.all(res <= tol * np.abs(theta[:k])) or m < taken or m >= d):
                 if failed:
                     out[s] = EigsError("inner solves stalled")
                 else:
