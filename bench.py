@@ -8,7 +8,7 @@ combustor (BASELINE.json configs[1]: ~200k DoF Helmholtz NLEVP with nÂ·exp(-iÏ‰Ï
 
 One "step" = one complete pass of the hot path: all quadrature points of the contour (4 edges x 32 Gauss-Legendre
 nodes = 128 shifted systems x l=16 probe columns), each solved on the device by multigrid-GMRES whose operator
-application is the fused multi-term CSR SpMV; moment accumulation in HBM.  By default (--rb 32) 32 snapshot points are
+application is the fused multi-term CSR SpMV; moment accumulation in HBM.  By default (--rb 40) 40 snapshot points are
 solved first and every other system starts from the Galerkin projection of its solution on them: same
 moments to the inner tolerance, same stopping test; --rb 0 solves every system from a zero guess.  N>1: snapshot and
 remaining points are dealt round-robin to the ranks, the snapshot solutions are all-gathered and the partial moment
@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--sweeps", type=int, default=1)
     ap.add_argument("--n", type=float, default=1.0)
     ap.add_argument("--tau", type=float, default=2e-4)
-    ap.add_argument("--rb", type=int, default=32,
+    ap.add_argument("--rb", type=int, default=40,
                     help="snapshot points for projected initial guesses (wae_beyn_moments_rb); 0 = every system from a zero guess")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-preset", default="20k")
