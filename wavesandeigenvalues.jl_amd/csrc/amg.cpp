@@ -5,6 +5,7 @@
 #include <numeric>
 
 #include "amg.h"
+#include <future>
 
 template <class V> static void transpose_impl(int64_t n, int64_t m, const std::vector<int> &ptr, const std::vector<int> &col,
                                               const std::vector<V> &val, std::vector<int> &tptr, std::vector<int> &tcol, std::vector<V> &tval) {
@@ -313,12 +314,18 @@ void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, c
         CsrD R = csr_transpose(P);
         AmgLevel L;
         L.P = P; L.R = R;
-        std::vector<CsrZ> next;
-        next.reserve(cur.size());
-        for (const CsrZ &A : cur) next.push_back(galerkin(R, A, P));
+        // the triple products of the planes (and of the shape matrix) are independent: one host thread each
+        std::vector<CsrZ> next(cur.size());
+        {
+            std::vector<std::future<void>> jobs;
+            for (size_t q = 0; q < cur.size(); ++q)
+                jobs.push_back(std::async(std::launch::async, [&, q]() { next[q] = galerkin(R, cur[q], P); }));
+            CsrD Snext = galerkin_real(R, S, P);
+            for (auto &j : jobs) j.get();
+            S = std::move(Snext);
+        }
         L.coarse_planes = next;
         levels.push_back(std::move(L));
-        S = galerkin_real(R, S, P);
         n = S.n;
         skip.assign(n, 0);
         cur.swap(next);
