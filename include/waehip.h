@@ -215,6 +215,19 @@ int wae_perturb(wae_family *h, const double *coeff_table, int32_t N, const doubl
                 int32_t norm_mode, const double *coeffsY, double tol, int32_t maxit, double *lambda_out,
                 double *v_out, wae_solve_info *info);
 
+/* -- P1 assembly on the device (input production) ------------------------------------------------
+ * Mass and stiffness matrices of the P1 tetrahedral discretisation, as `discretize` assembles them for the "interior"
+ * domain (src/Helmholtz.jl:405-441 with the element kernels src/FEM/FEM.jl:704-710,1745-1766):
+ *     M_ab += |det J|/120 (1 + delta_ab),      K_ab += -c_tet^2 |det J|/6 grad(phi_a).grad(phi_b)
+ * points: 3 doubles per point (x,y,z); tets: 4 point indices (0-based) per tetrahedron; c_tet: speed of sound per
+ * tetrahedron (NULL = 1).  Triplets are sorted and summed on the device (hipCUB), deterministic, no atomics.  The two
+ * matrices share one CSR pattern (rowptr npoints+1, col nnz; real values).  wae_p1_assemble returns a handle, wae_p1_info
+ * the sizes, wae_p1_get copies the arrays out (any pointer may be NULL), wae_p1_free releases it. */
+int wae_p1_assemble(int32_t device, int64_t npoints, const double *points, int64_t ntets, const int32_t *tets, const double *c_tet, void **out);
+int wae_p1_info(const void *handle, int64_t *npoints, int64_t *nnz);
+int wae_p1_get(const void *handle, int32_t *rowptr, int32_t *col, double *mass, double *stiff);
+int wae_p1_free(void *handle);
+
 /* -- measurement helpers (bench.py) --------------------------------------------------------------------
  * Time `reps` launches of the fused multi-term SpMV on device-resident data with HIP events on the
  * library's own stream; r right-hand sides.  ms_out = average milliseconds per launch. */

@@ -138,7 +138,22 @@ def annulus_small():
     print("wrote annulus_small_beyn.json", len(out["eigs"]), "eigenvalues")
 
 
+def rijke_mesh():
+    """Geometry of the tutorial mesh as plain arrays (points in metres, tetrahedra 0-based, speed of sound per
+    tetrahedron): the input of the device assembly test.  Output: rijke_mesh.npz."""
+    from oracle import helmholtz_p1 as H
+    mesh, _ = H.rijke_tube(os.path.join(REF, "docs/src/Rijke_mm.msh"), n=0.01, tau=0.001)
+    gamma, R, Tu, Tb = 1.4, 287.05, 300.0, 1200.0
+    c = H.generate_field(mesh, lambda x, y, z: np.sqrt(gamma * R * Tu) if z < 0.0 else np.sqrt(gamma * R * Tb))
+    np.savez_compressed(os.path.join(HERE, "rijke_mesh.npz"), points=np.asarray(mesh.points, dtype=np.float64),
+                        tetrahedra=np.asarray(mesh.tetrahedra, dtype=np.int32), c_tet=np.asarray(c, dtype=np.float64))
+    print("wrote rijke_mesh.npz", mesh.points.shape, np.asarray(mesh.tetrahedra).shape)
+
+
 if __name__ == "__main__":
+    if "--mesh" in sys.argv:
+        rijke_mesh()
+        sys.exit(0)
     main()
     if "--annulus" in sys.argv:
         annulus_small()

@@ -573,3 +573,29 @@ def test_householder_many_matches_single_runs():
         assert relerr(lhs, V[s] @ H[s]) < 1e-7
         assert np.allclose(V[s].conj().T @ V[s], np.eye(5), atol=1e-9)
     Lp._drop_device()
+
+
+def test_device_p1_assembly_matches_reference_shaped_matrices():
+    """wae_p1_assemble against (i) the Rijke-tube M and K of the golden fixture -- produced by the oracle's restatement of
+    `discretize` and pinned by the tutorial eigenvalues G1/G5 -- from the tutorial mesh's geometry (tests/golden/
+    rijke_mesh.npz), and (ii) the numpy assembly of the synthetic annulus.  Same pattern, values to rounding."""
+    import os
+    from wae_amd.helmholtz.assemble import assemble_p1
+    z = np.load(os.path.join(F.GOLDEN_DIR, "rijke_mesh.npz"))
+    M, K = assemble_p1(z["points"], z["tetrahedra"], z["c_tet"])
+    t = F.rijke_terms()
+    for A, B in ((M, t["M"]), (K, t["K"])):
+        A, B = sp.csr_matrix(A), sp.csr_matrix(B)
+        A.sort_indices(); B.sort_indices()
+        assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+        assert np.max(np.abs(A.data - B.data)) <= 1e-13 * np.max(np.abs(B.data))
+    pb = annulus.build("small")
+    pts, tets, _ = annulus._mesh(*pb["info"]["grid"])
+    ctr = pts[tets].mean(axis=1)
+    c_tet = np.where(ctr[:, 2] < annulus.Z_JUMP, annulus.C_COLD, annulus.C_HOT)
+    M2, K2 = assemble_p1(pts, tets, c_tet)
+    for A, B in ((M2, pb["terms"]["M"]), (K2, pb["terms"]["K"])):
+        assert abs(A - B).max() <= 1e-13 * abs(B).max() and A.nnz == B.nnz
+    # errors are reported, not swallowed
+    with pytest.raises(_lib.WaeError):
+        assemble_p1(pts, tets + len(pts), c_tet)
