@@ -1216,6 +1216,16 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
             plane_coeffs(h, cs.data(), WAE_OP_N, pc_shape);
         }
         amg_setup(h->planes0, pc, ao, lv, &pen, excl ? &pc_shape : nullptr);
+        if (getenv("WAE_SETUP_DEBUG")) {
+            fprintf(stderr, "[setup] level 0: n=%lld nnz/plane:", (long long)h->planes0[0].n);
+            for (const CsrZ &A : h->planes0) fprintf(stderr, " %lld", (long long)A.nnz());
+            fprintf(stderr, "\n");
+            for (size_t l = 0; l < lv.size(); ++l) {
+                fprintf(stderr, "[setup] level %zu: n=%lld P nnz=%lld nnz/plane:", l + 1, (long long)lv[l].P.m, (long long)lv[l].P.col.size());
+                for (const CsrZ &A : lv[l].coarse_planes) fprintf(stderr, " %lld", (long long)A.nnz());
+                fprintf(stderr, "\n");
+            }
+        }
         hipStream_t st = h->stream;
         {   // the penalty rows' own sub-block, plane by plane (compact numbering)
             std::vector<int> rows, loc(pen.size(), -1);
