@@ -599,3 +599,24 @@ def test_device_p1_assembly_matches_reference_shaped_matrices():
     # errors are reported, not swallowed
     with pytest.raises(_lib.WaeError):
         assemble_p1(pts, tets + len(pts), c_tet)
+
+
+def test_projected_guesses_odd_shapes():
+    """snapshot projection with shapes that do not tile the lock-step batch: l = 5 probe columns (12 systems per chunk,
+    a ragged last chunk), K = 2 (four moments), 80 quadrature points, the automatic snapshot count; Rijke tube (C1)."""
+    Lp = helmholtz_family(F.rijke_terms(), n=0.0)
+    Lp.solver_ref = 2 * np.pi * 400.0
+    Lp.solver_tol = 1e-11
+    Gam = np.array([150 + 50j, 150 - 50j, 1000 - 50j, 1000 + 50j]) * 2 * np.pi
+    d = Lp.size()
+    V = RNG.standard_normal((d, 5)) + 1j * RNG.standard_normal((d, 5))
+    A0 = compute_moment_matrices(Lp, Gam, V, K=2, N=20, rb=0)
+    A1 = compute_moment_matrices(Lp, Gam, V, K=2, N=20)              # rb=None -> automatic: 25 of 80 points
+    info = Lp.device().last_info
+    assert A1.shape == (d, 5, 4) and info["snapshots"] == 25 and info["n_unconverged"] == 0
+    for p in range(4):
+        assert relerr(A1[:, :, p], A0[:, :, p]) < 1e-8
+    Om = moments2eigs(A1)[0]
+    f = np.sort(Om[(Om.real > 2 * np.pi * 150) & (Om.real < 2 * np.pi * 1000) & (abs(Om.imag) < 2 * np.pi * 50)].real) / 2 / np.pi
+    assert any(abs(f - 272.06) < 0.5) and any(abs(f - 694.97) < 0.5)   # G7: the two passive modes of the tube
+    Lp._drop_device()
