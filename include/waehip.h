@@ -227,6 +227,19 @@ int wae_p1_assemble(int32_t device, int64_t npoints, const double *points, int64
 int wae_p1_info(const void *handle, int64_t *npoints, int64_t *nnz);
 int wae_p1_get(const void *handle, int32_t *rowptr, int32_t *col, double *mass, double *stiff);
 int wae_p1_free(void *handle);
+/* Discrete-adjoint shape sensitivity (src/shape_sensitivity.jl:16-141) of an eigenvalue w.r.t. the coordinates of surface
+ * points, for the interior (M, K) and the admittance-boundary (w*Y*C) parts of the P1 Helmholtz operator.  As in the
+ * reference the operator derivative is a central difference (step h) of two local re-discretisations of the simplices
+ * that touch the point; here one device thread does that for one (point, simplex, coordinate).
+ *   pair_pt_t[i], pair_tet[i]: surface point and one tetrahedron containing it (npair_t pairs); pair_pt_s, pair_tri:
+ *   the same for boundary triangles (tris: 3 point indices each, c_tri: speed of sound of the adjacent tetrahedron).
+ *   omega: eigenvalue (re, im); omegaY: omega*Y (re, im); v, v_adj: eigenvectors, normalised v'v = 1, v_adj' L'(omega) v = 1.
+ *   out_t[3*npair_t], out_s[3*npair_s] (complex): -v_adj' (dL/dx) v contribution of every pair and coordinate; the
+ *   caller sums them per point (deterministic order). */
+int wae_p1_shape_sensitivity(int32_t device, int64_t npoints, const double *points, const int32_t *tets, const double *c_tet, int64_t npair_t,
+                             const int32_t *pair_pt_t, const int32_t *pair_tet, const int32_t *tris, const double *c_tri, int64_t npair_s,
+                             const int32_t *pair_pt_s, const int32_t *pair_tri, int64_t ntets, int64_t ntris, const double *omega,
+                             const double *omegaY, const double *v, const double *v_adj, double h, double *out_t, double *out_s);
 
 /* -- measurement helpers (bench.py) --------------------------------------------------------------------
  * Time `reps` launches of the fused multi-term SpMV on device-resident data with HIP events on the

@@ -1,0 +1,61 @@
+"""Oracle restatement of the discrete-adjoint shape sensitivity (test infrastructure, see oracle/__init__.py).
+
+Follows src/shape_sensitivity.jl:16-141 for a full (non-unit-cell) mesh: for every surface point and coordinate the
+operator derivative is a central finite difference of two re-discretisations restricted to the simplices that touch
+the point, and the eigenvalue sensitivity is -v_adj' (dL/dx) v with v' v = 1, v_adj' L'(w0) v = 1.  The point/simplex
+adjacency (the reference's tri_mask / tet_mask from Meshutils) is computed here directly.  Parity of this file is
+unpinned by any executed reference output (no tutorial output records a shape gradient)."""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+
+from . import helmholtz_p1 as H
+
+
+def adjacency(mesh, surface_points):
+    """tet_mask / tri_mask: for each surface point the tetrahedra / boundary triangles that contain it."""
+    tet_mask, tri_mask = [], []
+    for p in surface_points:
+        tet_mask.append(np.nonzero((mesh.tetrahedra == p).any(axis=1))[0])
+        tri_mask.append(np.nonzero((mesh.triangles == p).any(axis=1))[0])
+    return tri_mask, tet_mask
+
+
+def discrete_adjoint_shape_sensitivity(mesh, dscrp, c_tet, surface_points, tri_mask, tet_mask, L, sol, h=1e-9):
+    """shape_sensitivity.jl:16-141 (mesh.dos == 1).  Returns sens (3, npoints) complex, zero outside surface_points."""
+    w0 = sol.params[sol.eigval]
+    v0 = sol.v / np.sqrt(np.vdot(sol.v, sol.v))
+    saved = (L.active, L.mode, dict(L.params))
+    L.active, L.mode = [L.eigval], "all"
+    v0_adj = sol.v_adj / np.conj(np.vdot(sol.v_adj, L(w0, 1) @ v0))
+    L.active, L.mode, L.params = saved[0], saved[1], saved[2]
+    sens = np.zeros((3, mesh.points.shape[0]), dtype=complex)
+    for idx, p in enumerate(surface_points):
+        mh = H.Mesh()
+        mh.points = mesh.points.copy()
+        mh.triangles, mh.tetrahedra = mesh.triangles, mesh.tetrahedra
+        mh.domains = {}
+        for dom in dscrp:
+            dd = copy.deepcopy(mesh.domains[dom])
+            keep = tri_mask[idx] if dd["dimension"] == 2 else tet_mask[idx]
+            ks = set(int(k) for k in keep)
+            dd["simplices"] = [s for s in dd["simplices"] if int(s) in ks]
+            mh.domains[dom] = dd
+        base = mesh.points[p].copy()
+        local = {dom: val for dom, val in dscrp.items() if mh.domains[dom]["simplices"]}   # an empty domain contributes nothing
+        for crd in range(3):
+            mh.points[p] = base
+            mh.points[p, crd] += h
+            Dr = H.discretize_p1(mh, local, c_tet)
+            mh.points[p, crd] -= 2 * h
+            Dl = H.discretize_p1(mh, local, c_tet)
+            for D in (Dr, Dl):
+                for k, val in L.params.items():
+                    if k in D.params:
+                        D.params[k] = val
+            Dmat = (Dr(w0) - Dl(w0)) / (2 * h)
+            sens[crd, p] = -np.vdot(v0_adj, Dmat @ v0)
+        mh.points[p] = base
+    return sens

@@ -145,9 +145,29 @@ def rijke_mesh():
     mesh, _ = H.rijke_tube(os.path.join(REF, "docs/src/Rijke_mm.msh"), n=0.01, tau=0.001)
     gamma, R, Tu, Tb = 1.4, 287.05, 300.0, 1200.0
     c = H.generate_field(mesh, lambda x, y, z: np.sqrt(gamma * R * Tu) if z < 0.0 else np.sqrt(gamma * R * Tb))
+    tri2tet = H.link_triangles_to_tetrahedra(mesh)
+    outlet = np.asarray(mesh.domains["Outlet"]["simplices"], dtype=np.int64)
     np.savez_compressed(os.path.join(HERE, "rijke_mesh.npz"), points=np.asarray(mesh.points, dtype=np.float64),
-                        tetrahedra=np.asarray(mesh.tetrahedra, dtype=np.int32), c_tet=np.asarray(c, dtype=np.float64))
-    print("wrote rijke_mesh.npz", mesh.points.shape, np.asarray(mesh.tetrahedra).shape)
+                        tetrahedra=np.asarray(mesh.tetrahedra, dtype=np.int32), c_tet=np.asarray(c, dtype=np.float64),
+                        outlet_triangles=np.asarray(mesh.triangles, dtype=np.int32)[outlet],
+                        outlet_c=np.asarray(c, dtype=np.float64)[tri2tet[outlet]])
+    print("wrote rijke_mesh.npz", mesh.points.shape, np.asarray(mesh.tetrahedra).shape, len(outlet), "outlet triangles")
+    # shape gradient of the passive mode near 272 Hz at a few surface points (oracle, direct solver): input and expected
+    # output of the device shape-sensitivity test.  Unpinned by the reference (no recorded shape gradient exists).
+    from oracle import shape as OSH
+    from oracle import solvers as OS
+    dscrp = {"Interior": ("interior", ()), "Outlet": ("admittance", ("Y", 1e15))}
+    Lo = H.discretize_p1(mesh, dscrp, c)
+    sol, n, flag = OS.householder(Lo, 2 * np.pi * 270.0, maxiter=20, tol=1e-11)
+    tri_pts = np.unique(np.asarray(mesh.triangles))                  # all boundary points
+    out_pts = np.unique(np.asarray(mesh.triangles)[outlet])
+    rng = np.random.default_rng(0)
+    pick = np.concatenate([rng.choice(out_pts, 4, replace=False), rng.choice(np.setdiff1d(tri_pts, out_pts), 8, replace=False)])
+    tri_mask, tet_mask = OSH.adjacency(mesh, pick)
+    sens = OSH.discrete_adjoint_shape_sensitivity(mesh, dscrp, c, pick, tri_mask, tet_mask, Lo, sol)
+    np.savez_compressed(os.path.join(HERE, "rijke_shape.npz"), omega=np.array([sol.params["ω"]]), v=sol.v, v_adj=sol.v_adj,
+                        surface_points=pick.astype(np.int64), sens=sens[:, pick])
+    print("wrote rijke_shape.npz  omega/2pi =", sol.params["ω"] / 2 / np.pi, " |sens| range", np.abs(sens[:, pick]).min(), np.abs(sens[:, pick]).max())
 
 
 if __name__ == "__main__":

@@ -620,3 +620,25 @@ def test_projected_guesses_odd_shapes():
     f = np.sort(Om[(Om.real > 2 * np.pi * 150) & (Om.real < 2 * np.pi * 1000) & (abs(Om.imag) < 2 * np.pi * 50)].real) / 2 / np.pi
     assert any(abs(f - 272.06) < 0.5) and any(abs(f - 694.97) < 0.5)   # G7: the two passive modes of the tube
     Lp._drop_device()
+
+
+def test_shape_sensitivity_matches_oracle_fixture():
+    """wae_p1_shape_sensitivity against the oracle's restatement of discrete_adjoint_shape_sensitivity
+    (oracle/shape.py, full re-discretisations with a direct solver; tests/golden/rijke_shape.npz): the passive 272-Hz mode
+    of the Rijke tube, four points on the outlet (interior and admittance parts) and eight on the wall.  Both sides
+    difference with h = 1e-9, so they agree to the rounding of that difference, not better.  Unpinned by the reference."""
+    import os
+    from wae_amd.helmholtz.assemble import discrete_adjoint_shape_sensitivity
+    from wae_amd.nlevp import Solution
+    m = np.load(os.path.join(F.GOLDEN_DIR, "rijke_mesh.npz"))
+    g = np.load(os.path.join(F.GOLDEN_DIR, "rijke_shape.npz"))
+    Lp = helmholtz_family(F.rijke_terms(), n=0.0, flame=False)
+    w0 = complex(g["omega"][0])
+    sol = Solution({**Lp.params, "ω": w0}, g["v"], g["v_adj"], "ω")
+    sens = discrete_adjoint_shape_sensitivity(m["points"], m["tetrahedra"], m["c_tet"], g["surface_points"], sol, Lp,
+                                              bnd_tris=m["outlet_triangles"], bnd_c=m["outlet_c"], Y=1e15)
+    want = g["sens"]
+    scale = np.abs(want).max(axis=0)                       # per point
+    assert np.all(np.abs(sens - want).max(axis=0) <= 2e-5 * scale + 1e-9)
+    assert np.abs(want).max() > 1.0                        # a real gradient, not noise
+    Lp._drop_device()

@@ -31,6 +31,119 @@ template <class F> int wae_guarded(F &&f) {
     }
 }
 
+// local P1 matrices of one tetrahedron with corner coordinates X: M_ab = |det J|/120 (1+delta_ab), K_ab = -c^2 |det J|/6 grad_a.grad_b
+__device__ inline void p1_local(const double X[4][3], double c, double M[16], double K[16]) {
+    double J[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int a = 0; a < 3; ++a) J[r][a] = X[a][r] - X[3][r];
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+    const double adet = fabs(det);
+    const double id = 1.0 / det;
+    double G[4][3];
+    G[0][0] = c00 * id; G[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id; G[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+    G[1][0] = c01 * id; G[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id; G[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+    G[2][0] = c02 * id; G[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id; G[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+    for (int k = 0; k < 3; ++k) G[3][k] = -(G[0][k] + G[1][k] + G[2][k]);
+    const double ks = -(c * c) * adet / 6.0;
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) {
+            M[a * 4 + b] = adet * (a == b ? 2.0 : 1.0) / 120.0;
+            K[a * 4 + b] = ks * (G[a][0] * G[b][0] + G[a][1] * G[b][1] + G[a][2] * G[b][2]);
+        }
+}
+
+// Discrete-adjoint shape sensitivity (src/shape_sensitivity.jl:16-141), interior part: for the pair (surface point p,
+// adjacent tetrahedron t) and coordinate x:  out = -v_adj_loc^H [ w^2 (M+ - M-) + (K+ - K-) ] v_loc / (2h), M+-/K+- the local
+// matrices with x_p moved by +-h (central difference of two local re-discretisations, as the reference does).
+__global__ __launch_bounds__(256) void shape_tet_kernel(const double *__restrict__ pts, const int *__restrict__ tets, const double *__restrict__ c_tet,
+                                                        int64_t npair, const int *__restrict__ pair_pt, const int *__restrict__ pair_tet,
+                                                        double wr, double wi, const cplx *__restrict__ v, const cplx *__restrict__ vadj, double h,
+                                                        cplx *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= npair * 3) return;
+    const int64_t pr = e / 3;
+    const int crd = (int)(e - pr * 3);
+    const int t = pair_tet[pr], p = pair_pt[pr];
+    int vtx[4];
+    double X[4][3];
+    int a0 = -1;
+    for (int a = 0; a < 4; ++a) {
+        vtx[a] = tets[(size_t)t * 4 + a];
+        if (vtx[a] == p) a0 = a;
+        for (int k = 0; k < 3; ++k) X[a][k] = pts[(size_t)vtx[a] * 3 + k];
+    }
+    if (a0 < 0) { out[e] = cplx{0.0, 0.0}; return; }
+    const double c = c_tet ? c_tet[t] : 1.0;
+    const double x0 = X[a0][crd];
+    double Mp[16], Kp[16], Mm[16], Km[16];
+    X[a0][crd] = x0 + h; p1_local(X, c, Mp, Kp);
+    X[a0][crd] = x0 - h; p1_local(X, c, Mm, Km);
+    const double w2r = wr * wr - wi * wi, w2i = 2.0 * wr * wi;
+    const double s = 1.0 / (2.0 * h);
+    cplx acc = {0.0, 0.0};
+    for (int a = 0; a < 4; ++a) {
+        const cplx ya = vadj[vtx[a]];
+        for (int b = 0; b < 4; ++b) {
+            const double dm = (Mp[a * 4 + b] - Mm[a * 4 + b]) * s, dk = (Kp[a * 4 + b] - Km[a * 4 + b]) * s;
+            const cplx D = {w2r * dm + dk, w2i * dm};
+            const cplx xb = v[vtx[b]];
+            const cplx Dx = {D.x * xb.x - D.y * xb.y, D.x * xb.y + D.y * xb.x};
+            acc.x += ya.x * Dx.x + ya.y * Dx.y;          // conj(ya) * Dx
+            acc.y += ya.x * Dx.y - ya.y * Dx.x;
+        }
+    }
+    out[e] = cplx{-acc.x, -acc.y};
+}
+
+// boundary (admittance) part: C_ab = -i c |(x0-x2) x (x1-x2)| (1+delta_ab)/24 (FEM.jl:435-441, Helmholtz.jl:151-156,459),
+// operator term w*Y*C:  out = -v_adj_loc^H [ w Y (C+ - C-) ] v_loc / (2h)
+__global__ __launch_bounds__(256) void shape_tri_kernel(const double *__restrict__ pts, const int *__restrict__ tris, const double *__restrict__ c_tri,
+                                                        int64_t npair, const int *__restrict__ pair_pt, const int *__restrict__ pair_tri,
+                                                        double wyr, double wyi, const cplx *__restrict__ v, const cplx *__restrict__ vadj, double h,
+                                                        cplx *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= npair * 3) return;
+    const int64_t pr = e / 3;
+    const int crd = (int)(e - pr * 3);
+    const int t = pair_tri[pr], p = pair_pt[pr];
+    int vtx[3];
+    double X[3][3];
+    int a0 = -1;
+    for (int a = 0; a < 3; ++a) {
+        vtx[a] = tris[(size_t)t * 3 + a];
+        if (vtx[a] == p) a0 = a;
+        for (int k = 0; k < 3; ++k) X[a][k] = pts[(size_t)vtx[a] * 3 + k];
+    }
+    if (a0 < 0) { out[e] = cplx{0.0, 0.0}; return; }
+    auto area2 = [&]() {
+        const double u0 = X[0][0] - X[2][0], u1 = X[0][1] - X[2][1], u2 = X[0][2] - X[2][2];
+        const double w0 = X[1][0] - X[2][0], w1 = X[1][1] - X[2][1], w2 = X[1][2] - X[2][2];
+        const double n0 = u1 * w2 - u2 * w1, n1 = u2 * w0 - u0 * w2, n2 = u0 * w1 - u1 * w0;
+        return sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+    };
+    const double x0 = X[a0][crd];
+    X[a0][crd] = x0 + h; const double dp = area2();
+    X[a0][crd] = x0 - h; const double dm = area2();
+    const double dd = c_tri[t] * (dp - dm) / (2.0 * h) / 24.0;          // d/dx of c |..| /24; C = -i * that * (1+delta)
+    // w Y C' = (wyr + i wyi) * (-i) * dd * (1+delta) = (wyi - i wyr) dd (1+delta)
+    const cplx f = {wyi * dd, -wyr * dd};
+    cplx acc = {0.0, 0.0};
+    for (int a = 0; a < 3; ++a) {
+        const cplx ya = vadj[vtx[a]];
+        for (int b = 0; b < 3; ++b) {
+            const double m = (a == b) ? 2.0 : 1.0;
+            const cplx xb = v[vtx[b]];
+            const cplx Dx = {m * (f.x * xb.x - f.y * xb.y), m * (f.x * xb.y + f.y * xb.x)};
+            acc.x += ya.x * Dx.x + ya.y * Dx.y;
+            acc.y += ya.x * Dx.y - ya.y * Dx.x;
+        }
+    }
+    out[e] = cplx{-acc.x, -acc.y};
+}
+
 __global__ __launch_bounds__(256) void p1_local_kernel(const double *__restrict__ pts, const int *__restrict__ tets, const double *__restrict__ c_tet,
                                                        int64_t nt, int64_t np, unsigned long long *__restrict__ keys, double *__restrict__ mv,
                                                        double *__restrict__ kv) {
@@ -42,30 +155,14 @@ __global__ __launch_bounds__(256) void p1_local_kernel(const double *__restrict_
         v[a] = tets[t * 4 + a];
         for (int k = 0; k < 3; ++k) X[a][k] = pts[(size_t)v[a] * 3 + k];
     }
-    // J columns x_a - x_4, a = 1..3
-    double J[3][3];
-    for (int r = 0; r < 3; ++r)
-        for (int a = 0; a < 3; ++a) J[r][a] = X[a][r] - X[3][r];
-    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
-    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
-    const double adet = fabs(det);
-    const double id = 1.0 / det;
-    // inverse of J (rows of Jinv = gradients of the first three barycentric coordinates)
-    double G[4][3];
-    G[0][0] = c00 * id; G[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id; G[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
-    G[1][0] = c01 * id; G[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id; G[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
-    G[2][0] = c02 * id; G[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id; G[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
-    for (int k = 0; k < 3; ++k) G[3][k] = -(G[0][k] + G[1][k] + G[2][k]);
-    const double c = c_tet ? c_tet[t] : 1.0;
-    const double ks = -(c * c) * adet / 6.0;
+    double Ml[16], Kl[16];
+    p1_local(X, c_tet ? c_tet[t] : 1.0, Ml, Kl);
     for (int a = 0; a < 4; ++a)
         for (int b = 0; b < 4; ++b) {
             const size_t o = (size_t)t * 16 + a * 4 + b;
             keys[o] = (unsigned long long)v[a] * (unsigned long long)np + (unsigned long long)v[b];
-            mv[o] = adet * (a == b ? 2.0 : 1.0) / 120.0;
-            kv[o] = ks * (G[a][0] * G[b][0] + G[a][1] * G[b][1] + G[a][2] * G[b][2]);
+            mv[o] = Ml[a * 4 + b];
+            kv[o] = Kl[a * 4 + b];
         }
 }
 
@@ -154,6 +251,58 @@ int wae_p1_assemble(int32_t device, int64_t npoints, const double *points, int64
         for (int64_t r = npoints - 1; r >= 0; --r)
             if (H->rowptr[r] < 0) H->rowptr[r] = H->rowptr[r + 1];
         *out = H;
+        return WAE_OK;
+    });
+}
+
+int wae_p1_shape_sensitivity(int32_t device, int64_t npoints, const double *points, const int32_t *tets, const double *c_tet, int64_t npair_t,
+                             const int32_t *pair_pt_t, const int32_t *pair_tet, const int32_t *tris, const double *c_tri, int64_t npair_s,
+                             const int32_t *pair_pt_s, const int32_t *pair_tri, int64_t ntets, int64_t ntris, const double *omega,
+                             const double *omegaY, const double *v, const double *v_adj, double h, double *out_t, double *out_s) {
+    return wae_guarded([&]() {
+        if (!(npoints > 0 && points && v && v_adj && omega && h > 0.0)) throw WaeError(WAE_ERR_INVALID, "bad argument");
+        if (npair_t > 0 && !(tets && pair_pt_t && pair_tet && out_t && ntets > 0)) throw WaeError(WAE_ERR_INVALID, "bad tetrahedron pair arguments");
+        if (npair_s > 0 && !(tris && c_tri && pair_pt_s && pair_tri && out_s && omegaY && ntris > 0)) throw WaeError(WAE_ERR_INVALID, "bad triangle pair arguments");
+        for (int64_t i = 0; i < npair_t; ++i)
+            if (pair_tet[i] < 0 || pair_tet[i] >= ntets || pair_pt_t[i] < 0 || pair_pt_t[i] >= npoints) throw WaeError(WAE_ERR_INVALID, "pair index out of range");
+        for (int64_t i = 0; i < npair_s; ++i)
+            if (pair_tri[i] < 0 || pair_tri[i] >= ntris || pair_pt_s[i] < 0 || pair_pt_s[i] >= npoints) throw WaeError(WAE_ERR_INVALID, "pair index out of range");
+        for (int64_t i = 0; i < ntets * 4 && npair_t > 0; ++i)
+            if (tets[i] < 0 || tets[i] >= npoints) throw WaeError(WAE_ERR_INVALID, "tetrahedron refers to a point outside 0..npoints-1");
+        for (int64_t i = 0; i < ntris * 3 && npair_s > 0; ++i)
+            if (tris[i] < 0 || tris[i] >= npoints) throw WaeError(WAE_ERR_INVALID, "triangle refers to a point outside 0..npoints-1");
+        HIP_CHECK(hipSetDevice(device));
+        Dev<double> dpts((size_t)npoints * 3);
+        Dev<cplx> dv((size_t)npoints), dva((size_t)npoints);
+        HIP_CHECK(hipMemcpy(dpts.p, points, (size_t)npoints * 3 * sizeof(double), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dv.p, v, (size_t)npoints * sizeof(cplx), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dva.p, v_adj, (size_t)npoints * sizeof(cplx), hipMemcpyHostToDevice));
+        if (npair_t > 0) {
+            Dev<int> dt((size_t)ntets * 4), dpp((size_t)npair_t), dpt((size_t)npair_t);
+            Dev<double> dc(c_tet ? (size_t)ntets : 1);
+            Dev<cplx> dout((size_t)npair_t * 3);
+            HIP_CHECK(hipMemcpy(dt.p, tets, (size_t)ntets * 4 * sizeof(int), hipMemcpyHostToDevice));
+            if (c_tet) HIP_CHECK(hipMemcpy(dc.p, c_tet, (size_t)ntets * sizeof(double), hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(dpp.p, pair_pt_t, (size_t)npair_t * sizeof(int), hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(dpt.p, pair_tet, (size_t)npair_t * sizeof(int), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(shape_tet_kernel, dim3((unsigned)((npair_t * 3 + 255) / 256)), dim3(256), 0, 0, dpts.p, dt.p, c_tet ? dc.p : nullptr, npair_t,
+                               dpp.p, dpt.p, omega[0], omega[1], dv.p, dva.p, h, dout.p);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipMemcpy(out_t, dout.p, (size_t)npair_t * 3 * sizeof(cplx), hipMemcpyDeviceToHost));
+        }
+        if (npair_s > 0) {
+            Dev<int> dt((size_t)ntris * 3), dpp((size_t)npair_s), dpt((size_t)npair_s);
+            Dev<double> dc((size_t)ntris);
+            Dev<cplx> dout((size_t)npair_s * 3);
+            HIP_CHECK(hipMemcpy(dt.p, tris, (size_t)ntris * 3 * sizeof(int), hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(dc.p, c_tri, (size_t)ntris * sizeof(double), hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(dpp.p, pair_pt_s, (size_t)npair_s * sizeof(int), hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(dpt.p, pair_tri, (size_t)npair_s * sizeof(int), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(shape_tri_kernel, dim3((unsigned)((npair_s * 3 + 255) / 256)), dim3(256), 0, 0, dpts.p, dt.p, dc.p, npair_s, dpp.p, dpt.p,
+                               omegaY[0], omegaY[1], dv.p, dva.p, h, dout.p);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipMemcpy(out_s, dout.p, (size_t)npair_s * 3 * sizeof(cplx), hipMemcpyDeviceToHost));
+        }
         return WAE_OK;
     });
 }

@@ -34,3 +34,69 @@ def assemble_p1(points, tets, c_tet=None, device=0, dtype=np.complex128):
         L.wae_p1_free(h)
     shape = (n.value, n.value)
     return (sp.csr_matrix((m.astype(dtype), col, rowptr), shape=shape), sp.csr_matrix((k.astype(dtype), col.copy(), rowptr.copy()), shape=shape))
+
+
+def discrete_adjoint_shape_sensitivity(points, tets, c_tet, surface_points, sol, L, bnd_tris=None, bnd_c=None, Y=None, h=1e-9,
+                                       device=0):
+    """sens = discrete_adjoint_shape_sensitivity(...)   (src/shape_sensitivity.jl:16-141, full mesh, P1)
+
+    Sensitivity of the eigenvalue ``sol.params[sol.eigval]`` to a displacement of every point in ``surface_points`` along
+    x, y, z: -v_adj' (dL/dx) v with v'v = 1 and v_adj' L'(ω) v = 1 (the normalisation uses ``L``, the device-backed
+    family).  The interior operators M, K (all tetrahedra touching the point) and, if given, the admittance boundary
+    ω·Y·C (``bnd_tris``: boundary triangles, ``bnd_c``: speed of sound at each, ``Y``) take part; a flame term does not
+    (its volume and reference gradient are not local to one point).  Returns a complex array (3, len(surface_points))."""
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    tt = np.ascontiguousarray(tets, dtype=np.int32).reshape(-1, 4)
+    cc = None if c_tet is None else np.ascontiguousarray(c_tet, dtype=np.float64)
+    sp_ = np.asarray(surface_points, dtype=np.int64)
+    w0 = complex(sol.params[sol.eigval])
+    v = np.asarray(sol.v, dtype=np.complex128)
+    v = v / np.sqrt(np.vdot(v, v))
+    saved = (L.active, L.mode, dict(L.params))
+    L.active, L.mode = [L.eigval], "all"
+    try:
+        va = np.asarray(sol.v_adj, dtype=np.complex128)
+        va = va / np.conj(np.vdot(va, L(w0, 1) @ v))
+    finally:
+        L.active, L.mode, L.params = saved
+    v, va = np.ascontiguousarray(v), np.ascontiguousarray(va)
+    # (point, simplex) adjacency pairs, in surface-point order
+    lut = np.full(pts.shape[0], -1, dtype=np.int64)
+    lut[sp_] = np.arange(len(sp_))
+    loc_t = lut[tt]
+    it, ia = np.nonzero(loc_t >= 0)
+    pair_tet = it.astype(np.int32)
+    pair_pt_t = tt[it, ia].astype(np.int32)
+    own_t = loc_t[it, ia]
+    out_t = np.zeros((len(pair_tet), 3), dtype=np.complex128)
+    tri = None
+    npair_s = 0
+    pair_tri = pair_pt_s = own_s = None
+    out_s = np.zeros((0, 3), dtype=np.complex128)
+    if bnd_tris is not None and len(bnd_tris):
+        tri = np.ascontiguousarray(bnd_tris, dtype=np.int32).reshape(-1, 3)
+        loc_s = lut[tri]
+        js, ja = np.nonzero(loc_s >= 0)
+        pair_tri, pair_pt_s, own_s = js.astype(np.int32), tri[js, ja].astype(np.int32), loc_s[js, ja]
+        npair_s = len(pair_tri)
+        out_s = np.zeros((npair_s, 3), dtype=np.complex128)
+    dp = C.POINTER(C.c_double)
+    ip = C.POINTER(C.c_int32)
+    om = np.array([w0.real, w0.imag])
+    wy = complex(w0 * (Y if Y is not None else 0.0))
+    omy = np.array([wy.real, wy.imag])
+    bc = np.ascontiguousarray(bnd_c, dtype=np.float64) if npair_s else None
+
+    def P(a, t):
+        return None if a is None else a.ctypes.data_as(t)
+    _lib.check(_lib.lib().wae_p1_shape_sensitivity(
+        int(device), pts.shape[0], P(pts, dp), P(tt, ip), P(cc, dp), len(pair_tet), P(pair_pt_t, ip), P(pair_tet, ip),
+        P(tri, ip) if npair_s else None, P(bc, dp), npair_s, P(pair_pt_s, ip) if npair_s else None, P(pair_tri, ip) if npair_s else None,
+        tt.shape[0], 0 if tri is None else tri.shape[0], P(om, dp), P(omy, dp),
+        v.view(np.float64).ctypes.data_as(dp), va.view(np.float64).ctypes.data_as(dp), float(h),
+        out_t.view(np.float64).ctypes.data_as(dp) if len(pair_tet) else None, out_s.view(np.float64).ctypes.data_as(dp) if npair_s else None))
+    sens = np.zeros((3, len(sp_)), dtype=np.complex128)
+    np.add.at(sens.T, own_t, out_t)                                   # per point, in pair order: deterministic
+    if npair_s:
+        np.add.at(sens.T, own_s, out_s)
+    return sens
