@@ -120,8 +120,19 @@ function Base.:\(A::Operator, B::StridedVecOrMat{ComplexF64})
     return X
 end
 
-"moments of beyn.jl:62-74 / compute_moment_matrices (beyn.jl:251-268) in one device call"
-function compute_moment_matrices(fam::DeviceFamily, Γ, V::Matrix{ComplexF64}; K=1, N=16)
+# snapshot points for the projected initial guesses: rb indices spread evenly through the quadrature list, re-ordered so
+# that every prefix covers the contour (bit reversal) -- the device takes the snapshots progressively
+function _snapshot_split(n::Int, rb::Int)
+    rb = min(rb, n)
+    idx = unique(floor.(Int, ((0:rb-1) .+ 0.5) .* n ./ rb) .+ 1)
+    bits = max(1, ceil(Int, log2(length(idx))))
+    key = [parse(Int, reverse(string(i, base=2, pad=bits)), base=2) for i in 0:length(idx)-1]
+    return idx[sortperm(key)], setdiff(1:n, idx)
+end
+
+"moments of beyn.jl:62-74 / compute_moment_matrices (beyn.jl:251-268) on the device; `rb` = number of snapshot points
+for projected initial guesses (wae_beyn_moments_rb; default 5/16 of the points for contours of at least 64 points)"
+function compute_moment_matrices(fam::DeviceFamily, Γ, V::Matrix{ComplexF64}; K=1, N=16, rb=nothing)
     ensure_solver!(fam)
     L = fam.L
     X, W = FastGaussQuadrature.gausslegendre(N)
@@ -137,11 +148,25 @@ function compute_moment_matrices(fam::DeviceFamily, Γ, V::Matrix{ComplexF64}; K
     L.active, L.mode = saved
     d, l = size(V)
     A = zeros(ComplexF64, d, l, 2K); info = Ref{SolveInfo}()
-    check(ccall((:wae_beyn_moments, libwaehip), Cint,
-                (Ptr{Cvoid}, Int32, Ptr{ComplexF64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Int32, Int32, Float64, Int32,
-                 Ptr{ComplexF64}, UInt64, Ref{SolveInfo}),
-                fam.handle, length(zs), zs, ws, ct, V, l, K, fam.tol, fam.maxit, A, 0, info))
-    return A
+    npts = length(zs)
+    rb === nothing && (rb = (npts >= 64 && d >= 1000) ? max(16, div(5npts, 16)) : 0)
+    if rb == 0 || npts < 2rb
+        check(ccall((:wae_beyn_moments, libwaehip), Cint,
+                    (Ptr{Cvoid}, Int32, Ptr{ComplexF64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Int32, Int32, Float64, Int32,
+                     Ptr{ComplexF64}, UInt64, Ref{SolveInfo}),
+                    fam.handle, npts, zs, ws, ct, V, l, K, fam.tol, fam.maxit, A, 0, info))
+        return A
+    end
+    idx, rest = _snapshot_split(npts, rb)
+    A1 = zeros(ComplexF64, d, l, 2K)
+    sig = (Ptr{Cvoid}, Int32, Ptr{ComplexF64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Int32, Int32, Float64, Int32,
+           Int32, Int32, Int32, UInt64, Ptr{ComplexF64}, UInt64, Int32, Int32, Int32, Ref{SolveInfo})
+    # mode 0: the snapshot points (solutions kept in the handle's store); mode 2: all other points from the projection
+    check(ccall((:wae_beyn_moments_rb, libwaehip), Cint, sig, fam.handle, length(idx), zs[idx], ws[idx], ct[:, idx], V, l, K,
+                fam.tol, fam.maxit, 0, length(idx), 0, 0, A, 0, 0, 0, 0, info))
+    check(ccall((:wae_beyn_moments_rb, libwaehip), Cint, sig, fam.handle, length(rest), zs[rest], ws[rest], ct[:, rest], V, l, K,
+                fam.tol, fam.maxit, 2, length(idx), 0, 0, A1, 0, 0, 0, 0, info))
+    return A .+ A1                                                  # the moments are a plain sum over quadrature points
 end
 
 "Ω, P = beyn(Ld, Γ; l, K, N, tol, pos_test) -- src/NLEVP/beyn.jl:34-110 with the quadrature loop on the GPU"
