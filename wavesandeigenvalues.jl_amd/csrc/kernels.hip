@@ -174,8 +174,12 @@ constexpr int LDS_NNZ = 1024;     // nonzeros staged per chunk (4 KB of indices)
 // One workgroup = 32 rows x (8*NCH) batch columns: the staged matrix tile is reused for NCH column chunks, so the
 // matrix streams through the workgroup once per 8*NCH columns (once per launch at the default batch width 64) and
 // each gathered X row is consumed as NCH consecutive 128-B segments of one 1-KB interleaved row.
+// __launch_bounds__(256, 4): four workgroups per CU.  An ablation showed that the launch time is the sum of the
+// per-workgroup phases (stage -> barrier -> gather/FMA loop -> store) times workgroups-per-CU over resident workgroups -- a
+// latency chain, not a bandwidth limit -- so residency matters: at 130 VGPRs the compiler's default gave 3 waves per SIMD,
+// the bound makes it fit 126 VGPRs without spilling (4 waves: -10 %; forcing 5 spills or halves the unrolling: slower).
 template <int NCH>
-__global__ __launch_bounds__(256) void spmv_lds_kernel(OpDev op, const cplx *__restrict__ pc, int cps,
+__global__ __launch_bounds__(256, 4) void spmv_lds_kernel(OpDev op, const cplx *__restrict__ pc, int cps,
                                                        const cplx *__restrict__ X, cplx *Y, const cplx *B, double jac_w,
                                                        int nb, int mode, const unsigned char *__restrict__ cmask) {
     constexpr int C = 8;
