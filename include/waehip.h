@@ -115,11 +115,12 @@ typedef struct {
 int wae_solve(wae_family *h, const double *coeffs, int32_t ncoef, const double *B, double *X, int32_t r,
               int32_t op, double tol, int32_t maxit, wae_solve_info *info);
 
-/* wae_solve with an initial-guess direction per column: x0 = alpha_b * G[:,b], alpha_b = (A g_b)^H b_b / ||A g_b||^2.
- * The Newton-type solvers know the dominant direction of the solution close to an eigenvalue (the current
- * eigenvector iterate: `u = L(z)\(L(z,1)*x0)`, iterative_solvers.jl:307,571-572); an iterative inner solver then
- * only has to produce the small remainder, where the reference relies on UMFPACK factorising a nearly singular L(z).
- * G may be NULL (= wae_solve). */
+/* wae_solve with a known near-null direction per column, G[:,b].  The Newton-type solvers know the dominant direction of
+ * the solution close to an eigenvalue (the current eigenvector iterate: `u = L(z)\(L(z,1)*x0)`,
+ * iterative_solvers.jl:307,571-572), where the reference relies on UMFPACK factorising a nearly singular L(z).  Here the
+ * direction is deflated: with u^ = M^-1 A g / ||.|| the Krylov process runs on (I - u^ u^H) M^-1 A and the solution is
+ * x = x_K + alpha g, alpha cancelling the u^ component of the residual (single-level hierarchies, whose preconditioner is
+ * the exact inverse, fall back to the initial guess x0 = alpha g).  G may be NULL (= wae_solve). */
 int wae_solve_guess(wae_family *h, const double *coeffs, int32_t ncoef, const double *B, const double *G, double *X,
                     int32_t r, int32_t op, double tol, int32_t maxit, wae_solve_info *info);
 
