@@ -179,6 +179,22 @@ def beyn_distributed(L, G, l=5, K=1, N=16, V=None, pos_test_=True):
     return Om, P, S
 
 
+def _tall_gram(A, B, rows=512):
+    """A^H B for tall-skinny A, B (d x l): rocBLAS runs the l x l x d product as one long-K GEMM at ~10 GFLOP/s (21 ms for
+    d = 2e5, l = 16); as a batch of (l x rows)(rows x l) products plus a sum it takes a fraction of a millisecond."""
+    import torch
+    d = A.shape[0]
+    nfull = (d // rows) * rows
+    out = torch.zeros((A.shape[1], B.shape[1]), dtype=A.dtype, device=A.device)
+    if nfull:
+        Ab = A[:nfull].reshape(d // rows, rows, A.shape[1])
+        Bb = B[:nfull].reshape(d // rows, rows, B.shape[1])
+        out = torch.bmm(Ab.conj().transpose(1, 2), Bb).sum(dim=0)
+    if nfull < d:
+        out = out + A[nfull:].conj().T @ B[nfull:]
+    return out
+
+
 def moments2eigs_device(buf, shape, tol_sigma=0.0):
     """`moments2eigs` (beyn.jl:289-323) with the tall-skinny part kept on the GPU (torch.linalg.svd on the moment
     buffer that the all-reduce already left in HBM); only the (lK x lK) eigenproblem runs on the host.
@@ -200,7 +216,7 @@ def moments2eigs_device(buf, shape, tol_sigma=0.0):
     if tol_sigma > 0:
         m = S > tol_sigma
         U, S, Wh = U[:, m], S[m], Wh[m, :]
-    small = (U.conj().T @ B1 @ Wh.conj().T) / S.to(U.dtype)
+    small = (_tall_gram(U, B1.contiguous()) @ Wh.conj().T) / S.to(U.dtype)
     Om, Pt = np.linalg.eig(small.cpu().numpy())
     P = U[:d, :] @ torch.from_numpy(Pt).to(U.device)
     return Om, P, S.cpu().numpy()
