@@ -19,11 +19,11 @@ def wrap(name):
     f = getattr(fam, name)
     def g(*a, **k):
         t = time.time(); r = f(*a, **k); acc[name] = acc.get(name, 0.0) + time.time() - t; acc[name + "#"] = acc.get(name + "#", 0) + 1
-        acc[name + "_dev"] = acc.get(name + "_dev", 0.0) + fam.last_info.get("seconds", 0.0) if name in ("arnoldi", "perturb", "solve") else 0.0
-        acc[name + "_its"] = acc.get(name + "_its", 0) + (fam.last_info.get("iters_total", 0) if name in ("arnoldi", "perturb", "solve") else 0)
+        acc[name + "_dev"] = acc.get(name + "_dev", 0.0) + fam.last_info.get("seconds", 0.0) if name in ("arnoldi", "arnoldi_batch", "perturb", "solve") else 0.0
+        acc[name + "_its"] = acc.get(name + "_its", 0) + (fam.last_info.get("iters_total", 0) if name in ("arnoldi", "arnoldi_batch", "perturb", "solve") else 0)
         return r
     setattr(fam, name, g)
-for nm in ("arnoldi", "perturb", "solve", "spmv"):
+for nm in ("arnoldi", "arnoldi_batch", "perturb", "solve", "spmv"):
     wrap(nm)
 for start in (2 * np.pi * (737 + 3j), 2 * np.pi * (430 + 9j)):
     acc.clear()
