@@ -611,9 +611,9 @@ def test_projected_guesses_odd_shapes():
     d = Lp.size()
     V = RNG.standard_normal((d, 5)) + 1j * RNG.standard_normal((d, 5))
     A0 = compute_moment_matrices(Lp, Gam, V, K=2, N=20, rb=0)
-    A1 = compute_moment_matrices(Lp, Gam, V, K=2, N=20)              # rb=None -> automatic: 25 of 80 points
+    A1 = compute_moment_matrices(Lp, Gam, V, K=2, N=20)              # rb=None -> automatic: 40 of 80 points
     info = Lp.device().last_info
-    assert A1.shape == (d, 5, 4) and info["snapshots"] == 25 and info["n_unconverged"] == 0
+    assert A1.shape == (d, 5, 4) and info["snapshots"] == 40 and info["n_unconverged"] == 0
     for p in range(4):
         assert relerr(A1[:, :, p], A0[:, :, p]) < 1e-8
     Om = moments2eigs(A1)[0]

@@ -86,8 +86,8 @@ def spread_order(idx):
 def compute_moment_matrices(L, G, V=None, l=5, K=1, N=16, points=None, out_dev=0, rb=None):
     """beyn.jl:233-268.  ``points=(z, w)`` overrides the contour (used to shard the quadrature over GPUs).
 
-    ``rb`` = number of snapshot points (default ``L.rb_snapshots``; None = 5/16 of the points when there are at
-    least 64 of them and d >= 1000 (measured optimum on the 128-point benchmark contour: 40); 0 = every system from a zero guess): the solutions
+    ``rb`` = number of snapshot points (default ``L.rb_snapshots``; None = max(40, a quarter of the points), at most
+    half of them, when there are at least 64 points and d >= 1000 -- measured optima: 40 of 128 at C2, 64 of 256 at C3; 0 = every system from a zero guess): the solutions
     at ``rb`` points spread along the contour are kept in HBM, all other points start from their Galerkin projection on
     those (wae_beyn_moments_rb); same moments to the inner tolerance, several times fewer Krylov iterations."""
     d = L.size()
@@ -98,8 +98,8 @@ def compute_moment_matrices(L, G, V=None, l=5, K=1, N=16, points=None, out_dev=0
     fam = L.ensure_solver()
     ct = coefficient_table(L, zs) if len(zs) else np.zeros((0, len(L.terms)), dtype=np.complex128)
     rb = getattr(L, "rb_snapshots", None) if rb is None else rb
-    if rb is None:                                   # automatic: 5/16 of the points, for contours worth the set-up
-        rb = max(16, (5 * len(zs)) // 16) if (len(zs) >= 64 and d >= 1000) else 0
+    if rb is None:                                   # automatic, for contours worth the set-up
+        rb = min(max(40, len(zs) // 4), len(zs) // 2) if (len(zs) >= 64 and d >= 1000) else 0
     if not rb or len(zs) < 2 * rb:
         return fam.beyn_moments(zs, ws, ct, V, K=K, tol=L.solver_tol, maxit=L.solver_maxit, out_dev=out_dev)
     idx, rest = snapshot_split(len(zs), rb)
