@@ -884,9 +884,12 @@ void launch_norms(const cplx *X, int64_t n, int nb, cplx *partial, cplx *out, hi
 // Thread t owns column t % nb and every R-th row, R = 256 / nb (as in dots_kernel).
 constexpr int AXU = 8;
 constexpr int AX_MAXC = 4096;      // coefficients per launch (64 KB of LDS)
+// NORM: additionally partial[blk][b] = sum over this workgroup's rows of |W[row][b]|^2 (the Gram-Schmidt step needs the norm
+// of the vector it has just written: one pass over it less)
+template <bool NORM>
 __global__ __launch_bounds__(256) void axpy_neg_kernel(const cplx *__restrict__ V, size_t stride, int nv, const cplx *__restrict__ h,
                                                        cplx *W, int64_t n, int nb, double sign, const cplx *base,
-                                                       const unsigned char *__restrict__ cmask) {
+                                                       const unsigned char *__restrict__ cmask, cplx *__restrict__ partial) {
     extern __shared__ cplx hs[];
     const int tid = threadIdx.x;
     for (int k = tid; k < nv * nb; k += 256) {
@@ -896,7 +899,10 @@ __global__ __launch_bounds__(256) void axpy_neg_kernel(const cplx *__restrict__ 
     __syncthreads();
     const int R = 256 / nb;
     const int b = tid % nb, rl = tid / nb;
-    if (rl >= R || (cmask && !cmask[b >> 3])) return;
+    const bool live = rl < R && !(cmask && !cmask[b >> 3]);
+    if (!NORM && !live) return;
+    double nrm2 = 0.0;
+    if (live)
     for (int64_t row = (int64_t)blockIdx.x * R + rl; row < n; row += (int64_t)gridDim.x * R) {
         const size_t e = (size_t)row * nb + b;
         cplx acc = base ? base[e] : cplx{0.0, 0.0};
@@ -919,6 +925,26 @@ __global__ __launch_bounds__(256) void axpy_neg_kernel(const cplx *__restrict__ 
             acc.y += c.x * v.y + c.y * v.x;
         }
         W[e] = acc;
+        if (NORM) nrm2 += acc.x * acc.x + acc.y * acc.y;
+    }
+    if (NORM) {
+        __syncthreads();                        // hs is re-used for the reduction
+        double *sm = (double *)hs;
+        if (nb <= 64 && (nb & (nb - 1)) == 0) {
+            for (int m = 32; m >= nb; m >>= 1) nrm2 += __shfl_xor(nrm2, m);
+            const int lane = tid & 63, wv = tid >> 6;
+            if (lane < nb) sm[wv * nb + lane] = nrm2;
+            __syncthreads();
+            if (tid < nb) partial[(size_t)blockIdx.x * nb + tid] = cplx{sm[tid] + sm[nb + tid] + sm[2 * nb + tid] + sm[3 * nb + tid], 0.0};
+        } else {
+            sm[tid] = nrm2;
+            __syncthreads();
+            if (tid < nb) {
+                double sacc = sm[tid];
+                for (int k = 1; k < R; ++k) sacc += sm[k * nb + tid];
+                partial[(size_t)blockIdx.x * nb + tid] = cplx{sacc, 0.0};
+            }
+        }
     }
 }
 static void axpy_impl(const cplx *V, size_t stride, int nv, const cplx *c, cplx *W, int64_t n, int nb, double sign, const cplx *base,
@@ -932,14 +958,34 @@ static void axpy_impl(const cplx *V, size_t stride, int nv, const cplx *c, cplx 
     int done = 0;
     do {                                              // nv == 0 still writes W = base (or 0)
         const int chunk = std::min(nv - done, maxv);
-        hipLaunchKernelGGL(axpy_neg_kernel, dim3(grid), dim3(256), (size_t)std::max(chunk, 1) * nb * sizeof(cplx), st,
-                           V + (size_t)done * stride, stride, chunk, c + (size_t)done * nb, W, n, nb, sign, done ? (const cplx *)W : base, cmask);
+        hipLaunchKernelGGL(axpy_neg_kernel<false>, dim3(grid), dim3(256), (size_t)std::max(chunk, 1) * nb * sizeof(cplx), st,
+                           V + (size_t)done * stride, stride, chunk, c + (size_t)done * nb, W, n, nb, sign, done ? (const cplx *)W : base, cmask,
+                           (cplx *)nullptr);
         HIP_CHECK(hipGetLastError());
         done += chunk;
     } while (done < nv);
 }
 void launch_axpy_neg(const cplx *V, size_t stride, int nv, const cplx *h, cplx *W, int64_t n, int nb, hipStream_t st, const unsigned char *cmask) {
     axpy_impl(V, stride, nv, h, W, n, nb, -1.0, W, st, cmask);
+}
+// w -= V h and norms[b] = ||w[:,b]|| in one pass over w (falls back to two kernels when the coefficients do not fit one launch)
+void launch_axpy_neg_norm(const cplx *V, size_t stride, int nv, const cplx *h, cplx *W, int64_t n, int nb, cplx *partial, cplx *norms,
+                          hipStream_t st, const unsigned char *cmask) {
+    if (!n || nb < 1) return;
+    if (nb > 256) throw WaeError(WAE_ERR_INVALID, "axpy: nb must be in 1..256");
+    if (nv < 1 || nv > AX_MAXC / nb) {
+        axpy_impl(V, stride, nv, h, W, n, nb, -1.0, W, st, cmask);
+        launch_norms(W, n, nb, partial, norms, st, cmask);
+        return;
+    }
+    const int R = 256 / nb;
+    const int64_t steps = (n + R - 1) / R;
+    const unsigned grid = (unsigned)std::min<int64_t>(steps, 1024);
+    const size_t shm = std::max((size_t)nv * nb * sizeof(cplx), (size_t)256 * sizeof(double));
+    hipLaunchKernelGGL(axpy_neg_kernel<true>, dim3(grid), dim3(256), shm, st, V, stride, nv, h, W, n, nb, -1.0, (const cplx *)W, cmask, partial);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((nb + 31) / 32), dim3(256), 0, st, partial, (int)grid, nb, norms, 1);
+    HIP_CHECK(hipGetLastError());
 }
 void launch_lincomb(const cplx *V, size_t stride, int nv, const cplx *y, cplx *Y, int64_t n, int nb, hipStream_t st) {
     axpy_impl(V, stride, nv, y, Y, n, nb, 1.0, nullptr, st, nullptr);

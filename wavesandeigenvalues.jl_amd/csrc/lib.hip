@@ -584,14 +584,15 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
             launch_spmv(A, pc, bt.cps, vj, h->W.p, nullptr, 0.0, nb, MODE_AX, st, mk);
             cplx *w = vcycle(h, bt, 0, h->W.p, mk);              // w = M^-1 A v_j  (lives in a V-cycle buffer)
             launch_dots(h->V.p, vec, nvj, w, n, nb, h->partial.p, h->hdev.p, st, mk);
-            launch_axpy_neg(h->V.p, vec, nvj, h->hdev.p, w, n, nb, st, mk);
             if (reorth) {   // CGS2: h += V^H w', w' -= V (V^H w')
+                launch_axpy_neg(h->V.p, vec, nvj, h->hdev.p, w, n, nb, st, mk);
                 cplx *h2 = h->hdev.p + (size_t)(off + m + 2) * nb;
                 launch_dots(h->V.p, vec, nvj, w, n, nb, h->partial.p, h2, st, mk);
-                launch_axpy_neg(h->V.p, vec, nvj, h2, w, n, nb, st, mk);
+                launch_axpy_neg_norm(h->V.p, vec, nvj, h2, w, n, nb, h->partial.p, h->hdev.p + (size_t)nvj * nb, st, mk);
                 launch_add(h2, h->hdev.p, (size_t)nvj * nb, st);
+            } else {        // the update and the norm of its result in one pass
+                launch_axpy_neg_norm(h->V.p, vec, nvj, h->hdev.p, w, n, nb, h->partial.p, h->hdev.p + (size_t)nvj * nb, st, mk);
             }
-            launch_norms(w, n, nb, h->partial.p, h->hdev.p + (size_t)nvj * nb, st, mk);
             launch_scale_inv(w, h->hdev.p + (size_t)nvj * nb, h->V.p + (size_t)nvj * vec, n, nb, st, mk);
             HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, (size_t)(nvj + 1) * nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));

@@ -156,6 +156,8 @@ void launch_dots(const cplx *V, size_t stride, int nv, const cplx *W, int64_t n,
 void launch_axpy_neg(const cplx *V, size_t stride, int nv, const cplx *h, cplx *W, int64_t n, int nb, hipStream_t s,
                      const unsigned char *cmask = nullptr);
 // Y = sum_i y[i][b] V_i
+void launch_axpy_neg_norm(const cplx *V, size_t stride, int nv, const cplx *h, cplx *W, int64_t n, int nb, cplx *partial, cplx *norms,
+                          hipStream_t s, const unsigned char *cmask = nullptr);
 void launch_lincomb(const cplx *V, size_t stride, int nv, const cplx *y, cplx *Y, int64_t n, int nb, hipStream_t s);
 // norms: out[b] = ||X[:,b]||_2  (real part of out[b], imag 0)
 void launch_norms(const cplx *X, int64_t n, int nb, cplx *partial, cplx *out, hipStream_t s, const unsigned char *cmask = nullptr);
