@@ -761,20 +761,34 @@ __global__ __launch_bounds__(256) void dots_kernel(const cplx *__restrict__ V, s
     }
 }
 // out[e] = sum_k partial[k][e]: 32 outputs x 8 k-slices per workgroup, LDS tree over the slices
+// EPB outputs per workgroup, 256/EPB slices of the nblk partials each: with 32 outputs per workgroup the norms of one batch
+// (64 outputs, 768-1024 partials) ran on 2 workgroups, ~100 dependent-latency loads per lane (31 us per call, 3.7 % of a pass)
+template <int EPB>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const cplx *__restrict__ partial, int nblk, int count, cplx *__restrict__ out, int do_sqrt) {
     __shared__ cplx sm[256];
-    const int lane_e = threadIdx.x & 31, slice = threadIdx.x >> 5;
-    const int e = blockIdx.x * 32 + lane_e;
+    constexpr int NS = 256 / EPB;
+    const int lane_e = threadIdx.x % EPB, slice = threadIdx.x / EPB;
+    const int e = blockIdx.x * EPB + lane_e;
     cplx acc = {0.0, 0.0};
     if (e < count)
-        for (int k = slice; k < nblk; k += 8) { cplx p = partial[(size_t)k * count + e]; acc.x += p.x; acc.y += p.y; }
+        for (int k = slice; k < nblk; k += NS) { cplx p = partial[(size_t)k * count + e]; acc.x += p.x; acc.y += p.y; }
     sm[threadIdx.x] = acc;
     __syncthreads();
+#pragma unroll
+    for (int s = NS / 2; s >= 1; s >>= 1) {
+        if (slice < s) { sm[threadIdx.x].x += sm[threadIdx.x + s * EPB].x; sm[threadIdx.x].y += sm[threadIdx.x + s * EPB].y; }
+        __syncthreads();
+    }
     if (slice == 0 && e < count) {
-        for (int s = 1; s < 8; ++s) { acc.x += sm[s * 32 + lane_e].x; acc.y += sm[s * 32 + lane_e].y; }
+        acc = sm[threadIdx.x];
         if (do_sqrt) acc = cplx{sqrt(acc.x), 0.0};
         out[e] = acc;
     }
+}
+static void launch_reduce_partials(const cplx *partial, int nblk, int count, cplx *out, int do_sqrt, hipStream_t st) {
+    if (count <= 256) hipLaunchKernelGGL(reduce_partials_kernel<2>, dim3((count + 1) / 2), dim3(256), 0, st, partial, nblk, count, out, do_sqrt);
+    else hipLaunchKernelGGL(reduce_partials_kernel<8>, dim3((count + 7) / 8), dim3(256), 0, st, partial, nblk, count, out, do_sqrt);
+    HIP_CHECK(hipGetLastError());
 }
 
 static void dots_impl(const cplx *V, size_t stride, int nv, const cplx *W, int64_t n, int nb, cplx *partial, cplx *out, int do_sqrt, hipStream_t st,
@@ -798,8 +812,7 @@ static void dots_impl(const cplx *V, size_t stride, int nv, const cplx *W, int64
 #undef WAE_DOTS
         HIP_CHECK(hipGetLastError());
         int count = chunk * nb;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((count + 31) / 32), dim3(256), 0, st, partial, nblk, count, out + (size_t)done * nb, do_sqrt);
-        HIP_CHECK(hipGetLastError());
+        launch_reduce_partials(partial, nblk, count, out + (size_t)done * nb, do_sqrt, st);
         done += chunk;
     }
 }
@@ -865,8 +878,7 @@ void launch_dots_multi(const cplx *V, size_t sv, int nv, const cplx *W, size_t s
         hipLaunchKernelGGL((dots_multi_kernel<8, 4>), dim3(nblk), dim3(256), 0, st, V + (size_t)done * sv, sv, chunk, W, sw, nw, n, nb, partial);
         HIP_CHECK(hipGetLastError());
         const int count = chunk * nw * nb;
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((count + 31) / 32), dim3(256), 0, st, partial, nblk, count, out + (size_t)done * nw * nb, 0);
-        HIP_CHECK(hipGetLastError());
+        launch_reduce_partials(partial, nblk, count, out + (size_t)done * nw * nb, 0, st);
         done += chunk;
     }
 }
@@ -984,8 +996,7 @@ void launch_axpy_neg_norm(const cplx *V, size_t stride, int nv, const cplx *h, c
     const size_t shm = std::max((size_t)nv * nb * sizeof(cplx), (size_t)256 * sizeof(double));
     hipLaunchKernelGGL(axpy_neg_kernel<true>, dim3(grid), dim3(256), shm, st, V, stride, nv, h, W, n, nb, -1.0, (const cplx *)W, cmask, partial);
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((nb + 31) / 32), dim3(256), 0, st, partial, (int)grid, nb, norms, 1);
-    HIP_CHECK(hipGetLastError());
+    launch_reduce_partials(partial, (int)grid, nb, norms, 1, st);
 }
 void launch_lincomb(const cplx *V, size_t stride, int nv, const cplx *y, cplx *Y, int64_t n, int nb, hipStream_t st) {
     axpy_impl(V, stride, nv, y, Y, n, nb, 1.0, nullptr, st, nullptr);
