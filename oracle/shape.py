@@ -59,3 +59,86 @@ def discrete_adjoint_shape_sensitivity(mesh, dscrp, c_tet, surface_points, tri_m
             sens[crd, p] = -np.vdot(v0_adj, Dmat @ v0)
         mh.points[p] = base
     return sens
+
+
+
+# ---- surface bookkeeping and normalisations (plain loops; Meshutils.jl:884-948,1030-1071; shape_sensitivity.jl:143-245) ----
+def get_surface_points(triangles, tetrahedra):
+    """Meshutils.jl:884-948 for mesh.dos == 1 (0-based): sorted surface point list, triangles / tetrahedra per point."""
+    surface_points = []
+    for tri in triangles:
+        for p in tri:
+            if int(p) not in surface_points:
+                surface_points.append(int(p))
+    surface_points.sort()
+    pos = {p: i for i, p in enumerate(surface_points)}
+    tri_mask = [[] for _ in surface_points]
+    tet_mask = [[] for _ in surface_points]
+    for t, tri in enumerate(triangles):
+        for p in tri:
+            tri_mask[pos[int(p)]].append(t)
+    for t, tet in enumerate(tetrahedra):
+        for p in tet:
+            if int(p) in pos:
+                tet_mask[pos[int(p)]].append(t)
+    return surface_points, tri_mask, tet_mask
+
+
+def get_normal_vectors(points, triangles, tetrahedra, tri2tet):
+    """Meshutils.jl:1030-1071."""
+    out = np.zeros((3, len(triangles)))
+    for i, tri in enumerate(triangles):
+        tet = tetrahedra[tri2tet[i]]
+        D = [p for p in tet if p not in tri][0]
+        A, B, Cc = (points[int(k)] for k in tri)
+        N = np.cross(A - Cc, B - Cc)
+        N = N * np.sign(np.dot(N, Cc - points[int(D)]))
+        out[:, i] = N
+    return out
+
+
+def normalize_sensitivity(surface_points, normal_vectors, tri_mask, sens):
+    """shape_sensitivity.jl:143-184."""
+    ntri = normal_vectors.shape[1]
+    out = np.zeros((3, ntri), dtype=complex)
+    for crd in range(3):
+        e = np.zeros(3)
+        e[crd] = 1.0
+        A = [np.linalg.norm(normal_vectors[:, t]) / 2 for t in range(ntri)]
+        V = [abs(np.dot(normal_vectors[:, t], e)) / 6 for t in range(ntri)]
+        for idx, pnt in enumerate(surface_points):
+            tris = tri_mask[idx]
+            vol = sum(abs(V[t]) for t in tris)
+            if vol == 0:
+                continue
+            for t in tris:
+                if A[t] > 0:
+                    out[crd, t] += sens[crd, pnt] / A[t] * (abs(V[t]) / vol)
+    return out
+
+
+def bound_mass_normalize(surface_points, normal_vectors, triangles, sens):
+    """shape_sensitivity.jl:186-228 (dense solve)."""
+    pos = {int(p): i for i, p in enumerate(surface_points)}
+    n = len(surface_points)
+    B = np.zeros((n, n))
+    Mloc = np.array([[1 / 12, 1 / 24, 1 / 24], [1 / 24, 1 / 12, 1 / 24], [1 / 24, 1 / 24, 1 / 12]])
+    for t, tri in enumerate(triangles):
+        w = np.linalg.norm(normal_vectors[:, t])
+        for a in range(3):
+            for b in range(3):
+                B[pos[int(tri[a])], pos[int(tri[b])]] += Mloc[a, b] * w
+    out = np.zeros(sens.shape, dtype=complex)
+    idx = [int(p) for p in surface_points]
+    for i in range(3):
+        out[i, idx] = np.linalg.solve(B, sens[i, idx])
+    return out
+
+
+def normal_sensitivity(normal_vectors, normed_sens):
+    """shape_sensitivity.jl:230-245."""
+    out = np.zeros(normal_vectors.shape[1], dtype=complex)
+    for t in range(normal_vectors.shape[1]):
+        nvec = normal_vectors[:, t]
+        out[t] = np.dot(nvec / np.linalg.norm(nvec), normed_sens[:, t])
+    return out

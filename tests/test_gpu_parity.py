@@ -642,3 +642,31 @@ def test_shape_sensitivity_matches_oracle_fixture():
     assert np.all(np.abs(sens - want).max(axis=0) <= 2e-5 * scale + 1e-9)
     assert np.abs(want).max() > 1.0                        # a real gradient, not noise
     Lp._drop_device()
+
+
+def test_finite_difference_shape_sensitivity_confirms_the_adjoint_gradient():
+    """forward_finite_differences_shape_sensitivity (src/shape_sensitivity.jl:238-337: perturb the point, re-discretise the
+    adjacent simplices, re-solve the eigenvalue with householder on the device) against the discrete-adjoint gradient of
+    wae_p1_shape_sensitivity -- the reference's own consistency check between its two routes.  One outlet point and one
+    wall point; h = 1e-6.  The re-solved family is L + (D₊ − D₋), linear in the displacement, so its eigenvalue carries the
+    second-order term of a LINEARISED perturbation, which for a tangential move (z on the tube wall: first-order shift ~0) is
+    not cancelled by the operator's own second derivative: measured, the difference to the adjoint gradient is
+    ≈ 1.2e5·h in that component (11.5 at h = 1e-4 against a gradient of 145 in y), 0.1 at 1e-6; the re-solve itself
+    converges to ~1e-11 rad/s, i.e. 5e-6 in the quotient."""
+    import os
+    from wae_amd.helmholtz import shape as SH
+    from wae_amd.nlevp import Solution
+    m = np.load(os.path.join(F.GOLDEN_DIR, "rijke_mesh.npz"))
+    g = np.load(os.path.join(F.GOLDEN_DIR, "rijke_shape.npz"))
+    Lp = helmholtz_family(F.rijke_terms(), n=0.0, flame=False)
+    w0 = complex(g["omega"][0])
+    sol = Solution({**Lp.params, "ω": w0}, g["v"], g["v_adj"], "ω")
+    pick = g["surface_points"][[0, 8]]
+    adj = SH.discrete_adjoint_shape_sensitivity(m["points"], m["tetrahedra"], m["c_tet"], pick, sol, Lp,
+                                                bnd_tris=m["outlet_triangles"], bnd_c=m["outlet_c"], Y=1e15)
+    fd = SH.forward_finite_differences_shape_sensitivity(m["points"], m["tetrahedra"], m["c_tet"], pick, Lp, sol,
+                                                         bnd_tris=m["outlet_triangles"], bnd_c=m["outlet_c"], h=1e-6)
+    scale = np.abs(adj).max(axis=0)
+    assert np.all(scale > 1.0)
+    assert np.all(np.abs(fd - adj).max(axis=0) <= 2e-3 * scale), (fd, adj)
+    Lp._drop_device()

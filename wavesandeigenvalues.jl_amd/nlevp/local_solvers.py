@@ -159,7 +159,9 @@ def _aux_step(L, z, order, nev, v0, v0_adj, update, state):
     cand = []
     L.active = [L.auxval, L.eigval]
     try:
-        for i in range(nev):
+        # fewer than nev pairs come back when the Krylov space is numerically invariant (z on an eigenvalue: one
+        # shift-invert step already spans it); the candidates are then the pairs that exist
+        for i in range(min(nev, len(lam), len(lam_adj))):
             L.params[L.auxval] = lam[i]
             sol = Solution(L.params, v[:, i], v_adj[:, i], L.auxval)
             perturb_(sol, L, L.eigval, order, mode="householder")
