@@ -323,7 +323,11 @@ __global__ __launch_bounds__(256, 4) void spmv_lds_kernel(OpDev op, const cplx *
             cplx dg = {0.0, 0.0};
             const double dsg = op.conj_diag ? -1.0 : 1.0;
             for (int q = 0; q < npl; ++q) { cplx dq = op.diag[(size_t)row * npl + q]; dq.y *= dsg; cfma(dg, mypc[q], dq); }
-            if (mode == MODE_AX_DS) {
+            if (mode == MODE_AX_J0) {
+                out = acc[k];
+                const cplx r = cdiv(acc[k], dg);
+                const_cast<cplx *>(B)[e] = cplx{jac_w * r.x, jac_w * r.y};
+            } else if (mode == MODE_AX_DS) {
                 out = cdiv(acc[k], dg);
             } else if (mode == MODE_RES_DS) {
                 const cplx bv = B[e];
@@ -369,6 +373,11 @@ void launch_spmv(const OpDev &op, const cplx *pc, int cps, const cplx *X, cplx *
     if (envC > 0 && envC <= nb) C = envC;
     if (envS > 0) S = envS;
     if (op.n <= 0) return;
+    if (mode == MODE_AX_J0 && !(C == 8 && S == 1 && env_int("WAE_SPMV_LDS", 1))) {   // only the wide fine-level kernel fuses the sweep
+        launch_spmv(op, pc, cps, X, Y, nullptr, 0.0, nb, MODE_AX, st, cmask);
+        launch_jacobi0(op, pc, cps, Y, const_cast<cplx *>(B), jac_w, nb, st, cmask);
+        return;
+    }
     if (C == 8 && S == 1 && env_int("WAE_SPMV_LDS", 1)) {
         const int nch_env = env_int("WAE_SPMV_NCH", 0);
         int nchunks = (nb + 7) / 8;

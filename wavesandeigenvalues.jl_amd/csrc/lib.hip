@@ -314,7 +314,8 @@ static void dense_setup(wae_family *h, const Batch &bt) {
 }
 
 // x = Minv b on level l;  returns pointer to the result (either lx[l] or lt[l])
-static cplx *vcycle(wae_family *h, const Batch &bt, int l, const cplx *b, const unsigned char *cm = nullptr) {
+// have_x0: the first sweep of level l (x = w/diag b) is already in lx[l] (written by the SpMV that produced b, MODE_AX_J0)
+static cplx *vcycle(wae_family *h, const Batch &bt, int l, const cplx *b, const unsigned char *cm = nullptr, bool have_x0 = false) {
     const int L = (int)h->ops.size() - 1;
     hipStream_t st = h->stream;
     if (l == L) {
@@ -324,7 +325,7 @@ static cplx *vcycle(wae_family *h, const Batch &bt, int l, const cplx *b, const 
     const OpDev A = h->ops[l].dev(bt.op);
     const cplx *pc = pc_level(h, l);
     cplx *x = h->lx[l].p, *t = h->lt[l].p;
-    launch_jacobi0(A, pc, bt.cps, b, x, h->jac_w, bt.nb, st, cm);
+    if (!have_x0) launch_jacobi0(A, pc, bt.cps, b, x, h->jac_w, bt.nb, st, cm);
     for (int s = 1; s < h->nsweeps; ++s) {
         launch_spmv(A, pc, bt.cps, x, t, b, h->jac_w, bt.nb, MODE_JAC, st, cm);
         std::swap(x, t);
@@ -581,8 +582,9 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
         for (; j < m && total_it < maxit; ++j) {
             const cplx *vj = h->V.p + (size_t)(off + j) * vec;
             const int nvj = off + j + 1;                         // vectors in the orthogonalisation set (u^ first when deflating)
-            launch_spmv(A, pc, bt.cps, vj, h->W.p, nullptr, 0.0, nb, MODE_AX, st, mk);
-            cplx *w = vcycle(h, bt, 0, h->W.p, mk);              // w = M^-1 A v_j  (lives in a V-cycle buffer)
+            const bool fuse0 = h->ops.size() > 1;                // A v_j and the V-cycle's first sweep on it in one kernel
+            launch_spmv(A, pc, bt.cps, vj, h->W.p, fuse0 ? h->lx[0].p : nullptr, fuse0 ? h->jac_w : 0.0, nb, fuse0 ? MODE_AX_J0 : MODE_AX, st, mk);
+            cplx *w = vcycle(h, bt, 0, h->W.p, mk, fuse0);       // w = M^-1 A v_j  (lives in a V-cycle buffer)
             launch_dots(h->V.p, vec, nvj, w, n, nb, h->partial.p, h->hdev.p, st, mk);
             if (reorth) {   // CGS2: h += V^H w', w' -= V (V^H w')
                 launch_axpy_neg(h->V.p, vec, nvj, h->hdev.p, w, n, nb, st, mk);

@@ -125,12 +125,14 @@ struct Transfer {                   // P (n_fine x n_coarse) and R = P^T as sing
 };
 
 // kernel launch wrappers (kernels.hip) -----------------------------------------------------------------
-enum { MODE_AX = 0, MODE_RES = 1, MODE_JAC = 2, MODE_ADD = 3, MODE_AX_DS = 4, MODE_RES_DS = 5 };
+enum { MODE_AX = 0, MODE_RES = 1, MODE_JAC = 2, MODE_ADD = 3, MODE_AX_DS = 4, MODE_RES_DS = 5, MODE_AX_J0 = 6 };
 // Y = f(A X) over columns [0,nb) of interleaved multivectors (leading dimension nb).
 //   pc: [nsys][nplanes_total] plane coefficients; column b uses row b / cps.
 //   MODE_AX : Y = A X            MODE_RES: Y = B - A X
 //   MODE_JAC: Y = X + w/diag (B - A X)   (diag from op.diag and pc)      MODE_ADD: Y = B + A X
 //   MODE_AX_DS: Y = (A X)/diag          MODE_RES_DS: Y = (B - A X)/diag   (row-scaled operator / residual)
+//   MODE_AX_J0: Y = A X and, as a second OUTPUT through the B pointer, B = w/diag (A X): the product and the first
+//               (zero-guess) Jacobi sweep of the V-cycle applied to it, in one pass
 // cmask (optional): one byte per 8-column chunk, 0 = chunk converged -> its columns are skipped (outputs untouched)
 void launch_spmv(const OpDev &op, const cplx *pc, int cps, const cplx *X, cplx *Y, const cplx *B, double jac_w,
                  int nb, int mode, hipStream_t s, const unsigned char *cmask = nullptr);
