@@ -211,8 +211,11 @@ def main():
             "config": {"workload": f"annular combustor Helmholtz NLEVP (P1), preset {args.preset}: d={d}, "
                                    f"L(w)=w^2 M+K+w Y C+n exp(-i w tau) Q, Beyn l={args.l} K=1 N={args.N}/edge "
                                    f"({4 * args.N} shifted systems x {args.l} columns), contour 150..1000 Hz x +-150 Hz, inner tol {args.tol:g}",
-                       "parallelism": (f"quadrature points round-robin over {world} GPU(s); {args.rb} snapshot points solved first, their "
-                                       "solutions all-gathered, the other points start from the projection on them; one all-reduce of the moments"
+                       "parallelism": ((f"{args.rb} snapshot points solved first, split by probe column over {world} GPU(s) "
+                                        f"({args.l // world} columns each), their solutions all-gathered; " if args.l % world == 0 else
+                                        f"{args.rb} snapshot points solved first, round-robin over {world} GPU(s), their solutions all-gathered; ")
+                                       + f"the other {4 * args.N - args.rb} points round-robin over the GPUs, starting from the projection on "
+                                       "the snapshots; one all-reduce of the moments"
                                        if args.rb > 0 else
                                        f"quadrature points round-robin over {world} GPU(s), one all-reduce of the moments"),
                        "batch_columns": args.batch},
