@@ -114,7 +114,8 @@ def main():
     G = np.array(GAMMA_HZ) * 2 * np.pi
     zs, ws = gauss_points(G, args.N)
     zr, wr = shard_points(zs, ws, rank, world)           # round-robin shard of the quadrature points
-    V = np.random.default_rng(7).standard_normal((d, args.l)) + 0j   # probe matrix (beyn.jl:43, random=true), seeded
+    # probe matrix (beyn.jl:43, random=true), seeded; column-major like the Julia array the reference would hand over
+    V = np.asfortranarray(np.random.default_rng(7).standard_normal((d, args.l)) + 0j)
     K = 1
     buf = torch.zeros(d * args.l * 2 * K * 2, dtype=torch.float64, device=f"cuda:{local}")
 

@@ -163,6 +163,8 @@ int wae_eig_residuals(wae_family *h, int32_t n, const double *coeff_table, const
  *   Q_dev : device pointer of the snapshot store, or 0 for a store owned by the handle; a caller-owned store is
  *           what a multi-GPU driver all-gathers between modes 0 and 1.
  *   accumulate != 0: add to the moments already in out_dev instead of zeroing them first (requires out_dev).
+ *   V     : in mode 2 V may be NULL: the probe matrix of the mode 0/1 call that started the basis (kept on the device) is
+ *           used again, which saves the second host-to-device copy of a pass.  Not after wae_rb_import.
  * Everything else as wae_beyn_moments.
  *   l_total, col0: the moment tensor has l_total columns and V holds columns col0 .. col0+l-1 of the probe matrix
  *           (l_total <= 0: l_total = l, col0 = 0).  A multi-GPU driver lets every rank take ALL snapshot points for its

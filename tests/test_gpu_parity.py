@@ -535,6 +535,8 @@ def test_projected_guesses_column_split_exchange():
     assert np.array_equal(kact, parts[1][0]) and parts[0][1].shape == (len(kact), S, S, ls)
     store = torch.stack(slabs).view(2, S, d, ls, 2).permute(1, 2, 0, 3, 4).contiguous()
     fam.rb_import(store.data_ptr(), kact, np.concatenate([p[1] for p in parts], axis=3), np.concatenate([p[2] for p in parts], axis=1))
+    with pytest.raises(_lib.WaeError):          # an imported basis carries no probe matrix: V=None is refused, nothing is touched
+        fam.beyn_moments_rb(zs[rest], ws[rest], ct[rest], None, 2, S, Q_dev=store.data_ptr(), accumulate=True, l_total=l, **kw)
     fam.beyn_moments_rb(zs[rest], ws[rest], ct[rest], V, 2, S, Q_dev=store.data_ptr(), accumulate=True, **kw)
     assert fam.last_info["n_unconverged"] == 0
     assert fam.last_info["iters_total"] < 0.5 * its0 * len(rest) / len(zs)      # the imported basis does its job

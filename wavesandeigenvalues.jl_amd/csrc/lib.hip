@@ -61,6 +61,7 @@ struct RbState {                     // snapshot basis of wae_beyn_moments_rb (o
     std::vector<zc> Hk;              // Hk[ki][(s*cap + i)*l + c] = q_i^H A_k q_s   (column c's basis)
     std::vector<zc> g;               // g[i*l + c] = q_i^H v_c
     DevBuf<cplx> W, Vi, hb, alpha, alpha2, ycoef;   // W_k = A_k Q (resident), probe columns interleaved, small scratch
+    bool vi_valid = false;           // Vi holds the probe matrix the basis was started with (false after an import)
 };
 
 struct wae_family {
@@ -804,6 +805,7 @@ static void rb_reset(wae_family *h, cplx *Q, int cap, int l, const double *table
     R.g.assign((size_t)cap * l, zc(0));
     if (R.Vi.n < vecl) R.Vi.alloc(vecl);
     HIP_CHECK(hipMemcpyAsync(R.Vi.p, Vinter, vecl * sizeof(cplx), hipMemcpyDeviceToDevice, h->stream));
+    R.vi_valid = true;
     if (R.hb.n < (size_t)4 * (cap + 4) * l) R.hb.alloc((size_t)4 * (cap + 4) * l);
     if (R.alpha.n < (size_t)l) R.alpha.alloc(l);
     if (R.alpha2.n < (size_t)cap * l) R.alpha2.alloc((size_t)cap * l);
@@ -1438,7 +1440,7 @@ int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const doub
                         double tol, int32_t maxit, int32_t mode, int32_t nbasis, int32_t slot0, uint64_t Q_dev, double *A_out, uint64_t out_dev,
                         int32_t accumulate, int32_t l_total, int32_t col0, wae_solve_info *info) {
     return guarded([&]() {
-        WAE_REQUIRE(h && npts >= 0 && (npts == 0 || (z && w && coeff_table)) && V && l > 0 && K > 0, "bad argument");
+        WAE_REQUIRE(h && npts >= 0 && (npts == 0 || (z && w && coeff_table)) && (V || mode == 2) && l > 0 && K > 0, "bad argument");
         WAE_REQUIRE(A_out || out_dev, "no output buffer");
         WAE_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (take snapshots), 1 (rebuild the basis from the store, use it) or 2 (use it)");
         WAE_REQUIRE(nbasis >= 0 && slot0 >= 0 && (mode == 2 || slot0 + (mode == 0 ? npts : 0) <= nbasis), "snapshot slots out of range");
@@ -1469,7 +1471,12 @@ int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const doub
             Q = h->rbQ.p;
         }
         ensure(h->io_a, vecl);
-        HIP_CHECK(hipMemcpyAsync(h->io_a.p, V, vecl * sizeof(cplx), hipMemcpyHostToDevice, st));
+        if (V) {
+            HIP_CHECK(hipMemcpyAsync(h->io_a.p, V, vecl * sizeof(cplx), hipMemcpyHostToDevice, st));
+        } else {                                     // mode 2 on the basis this handle started: its probe matrix is still in HBM
+            WAE_REQUIRE(mode == 2 && R.vi_valid && R.l == l && R.Vi.n >= vecl, "V may be NULL only in mode 2 after a mode 0/1 call with the same l on this handle");
+            launch_inter_to_colmajor(R.Vi.p, l, d, l, h->io_a.p, st);
+        }
         const int spc = std::max(1, h->NB / l);   // systems per chunk
         ensure(h->zw_dev, (size_t)2 * spc);
         if (R.ycoef.n < (size_t)std::max(nbasis, 1) * h->NB) R.ycoef.alloc((size_t)std::max(nbasis, 1) * h->NB);
@@ -1580,6 +1587,7 @@ int wae_rb_import(wae_family *h, int32_t S, int32_t l, uint64_t Q_dev, int32_t n
         WAE_REQUIRE(h && S > 0 && l > 0 && Q_dev && nk >= 0 && (nk == 0 || kact) && Hk && g, "bad argument");
         RbState &R = h->rb;
         R.Q = (cplx *)(uintptr_t)Q_dev; R.cap = S; R.l = l; R.S = S;
+        R.vi_valid = false;
         R.kact.assign(kact, kact + nk);
         R.Hk.resize((size_t)nk * S * S * l);
         for (size_t i = 0; i < R.Hk.size(); ++i) R.Hk[i] = zc(Hk[2 * i], Hk[2 * i + 1]);     // cap == S: same dense layout

@@ -108,7 +108,8 @@ def compute_moment_matrices(L, G, V=None, l=5, K=1, N=16, points=None, out_dev=0
     cap = len(idx) + getattr(L, "rb_extra", 0)              # room for adaptive enrichment (WAE_RB_ENRICH)
     A0 = fam.beyn_moments_rb(zs[idx], ws[idx], ct[idx], V, 0, cap, **kw)
     i0 = dict(fam.last_info)
-    A1 = fam.beyn_moments_rb(zs[rest], ws[rest], ct[rest], V, 2, cap, accumulate=bool(out_dev), **kw)
+    # V=None: the probe matrix uploaded by the snapshot call is still on the device
+    A1 = fam.beyn_moments_rb(zs[rest], ws[rest], ct[rest], None, 2, cap, accumulate=bool(out_dev), l_total=np.shape(V)[1], **kw)
     i1 = fam.last_info
     fam.last_info = {"iters_max": max(i0["iters_max"], i1["iters_max"]), "iters_total": i0["iters_total"] + i1["iters_total"],
                      "n_unconverged": i0["n_unconverged"] + i1["n_unconverged"], "levels": i1["levels"],

@@ -89,7 +89,8 @@ def beyn_moments_distributed_rb(L, G, V, K, N, S, timings=None, extra=None):
 
     import torch
     rank, world = rank_world()
-    d, l = V.shape
+    V = np.asfortranarray(np.asarray(V, dtype=np.complex128))   # once: the library takes column-major (a C-ordered d x l
+    d, l = V.shape                                              # matrix costs a 10-ms strided copy per call at d = 2e5)
     dev = torch.device("cuda", L.device_id)
     zs, ws = gauss_points(G, N)
     from .beyn import coefficient_table, snapshot_split, spread_order
@@ -129,7 +130,10 @@ def beyn_moments_distributed_rb(L, G, V, K, N, S, timings=None, extra=None):
             store = local
         t2 = time.perf_counter()
         mine2 = rest[rank::world]
-        fam.beyn_moments_rb(zs[mine2], ws[mine2], ct[mine2], V, 2, S if world > 1 else cap, Q_dev=store.data_ptr(), accumulate=True, **kw)
+        if world > 1:
+            fam.beyn_moments_rb(zs[mine2], ws[mine2], ct[mine2], V, 2, S, Q_dev=store.data_ptr(), accumulate=True, **kw)
+        else:        # same handle, same probe matrix: it is still in HBM
+            fam.beyn_moments_rb(zs[mine2], ws[mine2], ct[mine2], None, 2, cap, Q_dev=store.data_ptr(), accumulate=True, l_total=l, **kw)
     else:
         S = min(int(S), len(zs))
         S = max(world, (S // world) * world)                      # equal snapshot shares (all_gather wants equal sizes)

@@ -190,18 +190,23 @@ class DeviceFamily:
     def beyn_moments_rb(self, z, w, coeff_table, V, mode, nbasis, slot0=0, Q_dev=0, K=1, tol=1e-10, maxit=300, out_dev=0,
                         accumulate=False, l_total=0, col0=0):
         """wae_beyn_moments_rb: mode 0 solves the points and stores their solutions as snapshots, mode 1 starts every
-        system from the Galerkin projection on the snapshot basis (include/waehip.h)."""
+        system from the Galerkin projection on the snapshot basis (include/waehip.h).  V=None (mode 2 only, with
+        l_total = number of probe columns): reuse the probe matrix of the call that started the basis."""
         z = np.ascontiguousarray(z, dtype=np.complex128)
         w = np.ascontiguousarray(w, dtype=np.complex128)
         ct = np.ascontiguousarray(coeff_table, dtype=np.complex128).reshape(len(z), self.T)
-        Vf = np.asfortranarray(np.asarray(V, dtype=np.complex128))
-        l = Vf.shape[1]
+        if V is None:                      # mode 2: the probe matrix of the call that started the basis, still on the device
+            Vf, l = None, int(l_total)
+            l_total = 0
+        else:
+            Vf = np.asfortranarray(np.asarray(V, dtype=np.complex128))
+            l = Vf.shape[1]
         info = SolveInfo()
         A, aptr = None, None
         if not out_dev:
             A = np.zeros((self.d, l_total if l_total > 0 else l, 2 * K), dtype=np.complex128, order="F")
             aptr = zptr(A)
-        code = check(_lib.lib().wae_beyn_moments_rb(self.handle, len(z), zptr(z), zptr(w), zptr(ct), zptr(Vf), l, K, tol, maxit,
+        code = check(_lib.lib().wae_beyn_moments_rb(self.handle, len(z), zptr(z), zptr(w), zptr(ct), None if Vf is None else zptr(Vf), l, K, tol, maxit,
                                                     int(mode), int(nbasis), int(slot0), int(Q_dev), aptr, int(out_dev),
                                                     1 if accumulate else 0, int(l_total), int(col0), C.byref(info)))
         self.last_info = info.as_dict()
