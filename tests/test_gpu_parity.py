@@ -499,8 +499,10 @@ def test_generate_subspace_and_project_match_oracle():
     Lp._drop_device()
 
 
-def test_projected_guesses_column_split_exchange():
-    """The multi-GPU snapshot phase in one process: "rank r" takes ALL snapshot points for its half of the probe columns
+@pytest.mark.parametrize("l,nranks", [(16, 2), (8, 8)])
+def test_projected_guesses_column_split_exchange(l, nranks):
+    """The multi-GPU snapshot phase in one process: "rank r" takes ALL snapshot points for its share of the probe columns
+    (two ranks with 8 columns each; eight ranks with ONE column each = 64 systems per lock-step chunk, the 8-GPU run of C3)
     (wae_beyn_moments_rb mode 0 with l_total/col0), the finished bases are exported, concatenated as the all-gather would,
     imported, and the remaining points run in mode 2.  Same moments as the plain path."""
     import json
@@ -513,7 +515,7 @@ def test_projected_guesses_column_split_exchange():
     Lp.solver_tol = 1e-11
     Lp.solver_ref = 2 * np.pi * 500.0
     Gam = np.array([150 - 150j, 1000 - 150j, 1000 + 150j, 150 + 150j]) * 2 * np.pi
-    d, l, ls, S = pb["d"], 16, 8, 24
+    d, ls, S = pb["d"], l // nranks, 24
     V = np.random.default_rng(5).standard_normal((d, l)) + 0j
     A0 = compute_moment_matrices(Lp, Gam, V, K=1, N=32, rb=0)
     fam = Lp.device()
@@ -525,7 +527,7 @@ def test_projected_guesses_column_split_exchange():
     buf = torch.zeros(d * l * 2 * 2, dtype=torch.float64, device="cuda:0")
     kw = dict(K=1, tol=Lp.solver_tol, maxit=Lp.solver_maxit, out_dev=buf.data_ptr())
     slabs, parts = [], []
-    for r in range(2):
+    for r in range(nranks):
         local = torch.empty(S * d * ls * 2, dtype=torch.float64, device="cuda:0")
         fam.beyn_moments_rb(zs[idx], ws[idx], ct[idx], V[:, r * ls:(r + 1) * ls], 0, S, Q_dev=local.data_ptr(),
                             accumulate=(r > 0), l_total=l, col0=r * ls, **kw)
@@ -533,7 +535,7 @@ def test_projected_guesses_column_split_exchange():
         parts.append(fam.rb_export())
     kact = parts[0][0]
     assert np.array_equal(kact, parts[1][0]) and parts[0][1].shape == (len(kact), S, S, ls)
-    store = torch.stack(slabs).view(2, S, d, ls, 2).permute(1, 2, 0, 3, 4).contiguous()
+    store = torch.stack(slabs).view(nranks, S, d, ls, 2).permute(1, 2, 0, 3, 4).contiguous()
     fam.rb_import(store.data_ptr(), kact, np.concatenate([p[1] for p in parts], axis=3), np.concatenate([p[2] for p in parts], axis=1))
     with pytest.raises(_lib.WaeError):          # an imported basis carries no probe matrix: V=None is refused, nothing is touched
         fam.beyn_moments_rb(zs[rest], ws[rest], ct[rest], None, 2, S, Q_dev=store.data_ptr(), accumulate=True, l_total=l, **kw)

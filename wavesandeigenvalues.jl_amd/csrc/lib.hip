@@ -1505,8 +1505,18 @@ int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const doub
             return std::async(std::launch::async, [h, coeff_table, q0, nq, T]() { return rb_guess_coeffs(h, coeff_table + (size_t)q0 * 2 * T, nq); });
         };
         if (fixed_basis && npts > 0 && R.S > 0) next_Y = launch_coeffs(0);
-        for (int p0 = 0; p0 < npts; p0 += spc) {
-            const int ns = std::min(spc, npts - p0);
+        // Mode 0 is progressive, so the first chunks should be small: a chunk never takes more points than the basis already
+        // holds, starting with 16 columns' worth (1, 1, 2, 4, 4, ... points for l = 16; 16, 16, 32 for l = 1).  Measured on
+        // the snapshot phase: C2 0.695 -> 0.668 s, C3 2.71 -> 2.56 s; one rank's share of C3 when the probe columns are split
+        // over 8 / 4 / 2 GPUs (1 / 2 / 4 columns x 64 points): 0.97 -> 0.63, 1.19 -> 0.97, 1.79 -> 1.69 s (dev/c3_rank_share.py).
+        // WAE_RB_DOUBLING=0 restores full chunks, WAE_RB_C0COLS sets the starting width (4, 8, 32 measured: slower).
+        static const int doubling = getenv("WAE_RB_DOUBLING") ? atoi(getenv("WAE_RB_DOUBLING")) : 1;
+        static const int c0cols = getenv("WAE_RB_C0COLS") ? std::max(1, atoi(getenv("WAE_RB_C0COLS"))) : 16;
+        const int c0 = doubling ? std::max(1, c0cols / l) : spc;
+        int ns_next = 0;
+        for (int p0 = 0; p0 < npts; p0 += ns_next) {
+            const int ns = (mode == 0) ? std::min(std::min(spc, npts - p0), std::max(c0, R.S)) : std::min(spc, npts - p0);
+            ns_next = ns;
             Batch bt;
             bt.nb = ns * l; bt.cps = l; bt.nsys = ns; bt.op = WAE_OP_N;
             std::vector<std::vector<zc>> pcs(ns);
