@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
 """Benchmark of the NLEVP hot path on MI355X:  eigenpairs/sec of a Beyn contour solve on the synthetic annular
-combustor (BASELINE.json configs[1]: ~200k DoF Helmholtz NLEVP with n·exp(-iωτ) flame term, Beyn N=32 per edge).
+combustor at 1M DoF -- the configuration BASELINE.json quotes its metric on ("1M-DoF Helmholtz NLEVP", configs[2]:
+995 328 DoF, n·exp(-iωτ) flame term, Beyn N=64 per edge, l=8); it fits one GPU (72 GB of HBM).  BASELINE configs[1]
+(200k DoF, N=32) is `--preset C2 --N 32 --l 16`.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-One "step" = one complete pass of the hot path: all quadrature points of the contour (4 edges x 32 Gauss-Legendre
-nodes = 128 shifted systems x l=16 probe columns), each solved on the device by multigrid-GMRES whose operator
-application is the fused multi-term CSR SpMV; moment accumulation in HBM.  By default (--rb 40) 40 snapshot points are
-solved first and every other system starts from the Galerkin projection of its solution on them: same
-moments to the inner tolerance, same stopping test; --rb 0 solves every system from a zero guess.  N>1: snapshot and
-remaining points are dealt round-robin to the ranks, the snapshot solutions are all-gathered and the partial moment
-tensors summed with one RCCL all-reduce over xGMI.  Then QR+SVD of the moments on the GPU, small eigenproblem,
-position test and the residual check of every eigenpair (on the device) on rank 0.  Inputs (all term matrices,
-the multigrid hierarchy, the probe matrix) are resident in HBM before the timed region.
+One "step" = one complete pass of the hot path: all quadrature points of the contour (4 edges x 64 Gauss-Legendre
+nodes = 256 shifted systems x l=8 probe columns), each solved on the device by multigrid-GMRES whose operator
+application is the fused multi-term CSR SpMV; moment accumulation in HBM.  By default (--rb -1 = the package's
+automatic rule, 64 of the 256 points) snapshot points are solved first and every other system starts from the Galerkin
+projection of its solution on them: same moments to the inner tolerance, same stopping test; --rb 0
+solves every system from a zero guess.  N>1: every rank solves all snapshot points for its l/N probe columns, the
+per-column bases are all-gathered, the remaining points are dealt round-robin and the partial moment tensors summed
+with one RCCL all-reduce over xGMI.  Then QR+SVD of the moments on the GPU, small eigenproblem, position test and the
+residual check of every eigenpair (on the device) on rank 0.  Inputs (all term matrices, the multigrid hierarchy) are
+resident in HBM before the timed region.
 
 The printed JSON line carries, besides the driver's contract fields,
   roofline     : the dominant kernel (spmv_kernel, the fused multi-term SpMV at the solver's batch width) --
@@ -54,30 +57,35 @@ def cpu_baseline(preset, l, N, n_in):
     return {"value": n_in / (npts * t_point), "unit": "eigenpairs/sec", "cores": 1, "kind": "port",
             "sample": f"1 of {npts} quadrature points (assemble L(z) + SuperLU + {l} solves = the reference's per-point work, "
                       f"beyn.jl:62-71) on the {pb['d']}-DoF annulus preset '{preset}': {t_point:.1f} s; value = {n_in} eigenpairs / "
-                      f"({npts} x t_point).  The C2 operator itself needs 579 s per LU on 1 host core (measured offline, DESIGN.md), "
-                      f"i.e. ~1.1e-4 eigenpairs/sec, too long for an in-run sample.",
+                      f"({npts} x t_point).  The benchmark operator itself is out of reach of an in-run sample: one LU of the 200k-DoF "
+                      f"operator takes 579 s and 9.4 GB of fill on 1 host core (measured offline, DESIGN.md), i.e. ~1.1e-4 "
+                      f"eigenpairs/sec for its 128-point contour; at 1M DoF the fill no longer fits the build container's memory.",
             "seconds_per_point": t_point, "d_sample": int(pb["d"]), "c2_offline_estimate": 8 / (128 * 587.0)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--preset", default="C2")
-    ap.add_argument("--l", type=int, default=16)
-    ap.add_argument("--N", type=int, default=32)
+    ap.add_argument("--preset", default="C3")
+    ap.add_argument("--l", type=int, default=8)
+    ap.add_argument("--N", type=int, default=64)
     ap.add_argument("--tol", type=float, default=1e-10)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--restart", type=int, default=40)
     ap.add_argument("--sweeps", type=int, default=1)
     ap.add_argument("--n", type=float, default=1.0)
     ap.add_argument("--tau", type=float, default=2e-4)
-    ap.add_argument("--rb", type=int, default=40,
-                    help="snapshot points for projected initial guesses (wae_beyn_moments_rb); 0 = every system from a zero guess")
+    ap.add_argument("--rb", type=int, default=-1,
+                    help="snapshot points for projected initial guesses (wae_beyn_moments_rb); -1 = the package's automatic "
+                         "rule min(max(40, points/4), points/2); 0 = every system from a zero guess")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-preset", default="20k")
     args = ap.parse_args()
+    if args.rb < 0:
+        npts = 4 * args.N
+        args.rb = min(max(40, npts // 4), npts // 2)      # nlevp/beyn.py compute_moment_matrices, automatic rule
 
     import torch
     import torch.distributed as dist
@@ -192,7 +200,7 @@ def main():
         tri = _C.c_double(0.0)                 # device triad a = b + s*c over 2^27 doubles: the streaming rate this GPU attains
         _wl.check(_wl.lib().wae_bench_triad(int(os.environ.get("LOCAL_RANK", 0)), 1 << 27, 20, _C.byref(tri)))
         traffic = None       # HBM bytes per launch from the PMC passes committed under profiles/ (not collectable in-run)
-        tfile = os.path.join(ROOT, "profiles", "r01_spmv_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", f"r01_spmv_traffic_{args.preset}.json")
         if os.path.exists(tfile):
             tj = json.load(open(tfile))
             if tj.get("preset") == args.preset and tj.get("r") == rb:
