@@ -97,6 +97,7 @@ def beyn_moments_distributed_rb(L, G, V, K, N, S, timings=None, extra=None):
     fam = L.ensure_solver()
     ct = coefficient_table(L, zs)
     buf = torch.zeros(d * l * 2 * K * 2, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize(dev)        # the library works on its own stream: torch's fill must have landed before it accumulates
     kw = dict(K=K, tol=L.solver_tol, maxit=L.solver_maxit, out_dev=buf.data_ptr())
     by_column = world > 1 and l % world == 0
     t0 = time.perf_counter()
