@@ -1,4 +1,4 @@
-"""GPU tests at BASELINE.json's full single-GPU size (configs[1], d = 199 680) through size-independent properties:
+"""GPU tests at BASELINE.json's full sizes (configs[1], d = 199 680; configs[2], d = 995 328; configs[3]) through size-independent properties:
 the oracle's direct factorisation needs ~10 minutes and 9 GB per quadrature point there, so parity at this size is
 checked by identities that hold for the exact operator (linearity, adjoint identity, solve round trip, additivity of
 sharded moments, eigenpair residuals and Newton refinement of the Beyn estimates).  Unpinned by any reference output
@@ -158,3 +158,45 @@ def test_projected_guesses_full_size(c2):
     S0 = moments2eigs(A0, return_sigma=True)[2]
     S1 = moments2eigs(A1, return_sigma=True)[2]
     assert np.allclose(S0[:8], S1[:8], rtol=1e-8) and S1[8] < 1e-8 * S1[0]
+
+
+def test_c3_one_million_dof_pass():
+    """BASELINE configs[2] = the bench default (995 328 DoF, 256 points x 8 columns, 64 snapshot points by the automatic
+    rule) through size-independent properties: a lock-step solve of 64 systems verified by the independent SpMV path, the
+    Beyn pass returning exactly the eight eigenpairs inside the contour with small backward errors, those eigenvalues within
+    the mesh-convergence distance of the 200k-DoF ones (same geometry, 1.7x finer mesh), and Newton refinement from a Beyn
+    estimate staying on it."""
+    L, pb = annulus_family("C3", tau=2e-4)
+    L.solver_tol = 1e-10
+    L.solver_ref = 2 * np.pi * 500.0
+    L.solver_opts = {"batch": 64, "restart": 40, "sweeps": 1}
+    d = pb["d"]
+    assert d == 995328
+    fam = L.ensure_solver()
+    zs, _ = gauss_points(GAMMA, 16)
+    B = _rand(d, 64)
+    ct = np.array([L.coefficients(z) for z in zs])
+    X = fam.solve(ct, B, tol=1e-10, maxit=300)
+    assert fam.last_info["n_unconverged"] == 0 and fam.last_info["relres_max"] <= 1e-10
+    R = B - fam.spmv(ct, X)
+    T = pb["terms"]
+    for j in (0, 31, 63):
+        dg = zs[j] * zs[j] * T["M"].diagonal() + T["K"].diagonal() + zs[j] * 1e15 * T["C"].diagonal()
+        assert np.linalg.norm(R[:, j] / dg) <= 1e-8 * np.linalg.norm(B[:, j] / dg)
+    del X, R, B
+    V = np.asfortranarray(np.random.default_rng(7).standard_normal((d, 8)) + 0j)
+    A = compute_moment_matrices(L, GAMMA, V, K=1, N=64)                 # rb=None: automatic, 64 snapshot points
+    info = fam.last_info
+    assert info["n_unconverged"] == 0 and info["snapshots"] == 64
+    assert info["iters_total"] < 256 * 8 * 10                           # < 10 Krylov iterations per system on average
+    Om, P, S = moments2eigs(A, return_sigma=True)
+    Om, P = pos_test(Om, P, GAMMA)
+    res = fam.eig_residuals(np.array([L.coefficients(w) for w in Om]), P=P)
+    assert len(Om) == 8 and res.max() <= 1e-7
+    f = np.sort_complex(Om / 2 / np.pi)
+    c2 = np.array([195.12 + 9.11j, 428.78 + 9.37j, 428.90 + 10.02j, 737.54 + 2.65j, 774.72 + 9.89j, 774.95 + 10.43j, 846.28 + 13.11j, 846.28 + 13.52j])
+    assert np.all(np.abs(f - c2) <= 0.01 * np.abs(c2))                  # mesh convergence: within 1 % of the 200k-DoF spectrum
+    k = int(np.argmin(np.abs(Om - 2 * np.pi * 735)))
+    sol, n, flag = householder(L, Om[k], maxiter=6, tol=1e-6, v0=P[:, k])
+    assert abs(sol.params["ω"] - Om[k]) <= 1e-6 * abs(Om[k]) and n <= 3
+    L._drop_device()
