@@ -164,7 +164,8 @@ function compute_moment_matrices(fam::DeviceFamily, Γ, V::Matrix{ComplexF64}; K
     # mode 0: the snapshot points (solutions kept in the handle's store); mode 2: all other points from the projection
     check(ccall((:wae_beyn_moments_rb, libwaehip), Cint, sig, fam.handle, length(idx), zs[idx], ws[idx], ct[:, idx], V, l, K,
                 fam.tol, fam.maxit, 0, length(idx), 0, 0, A, 0, 0, 0, 0, info))
-    check(ccall((:wae_beyn_moments_rb, libwaehip), Cint, sig, fam.handle, length(rest), zs[rest], ws[rest], ct[:, rest], V, l, K,
+    # V = C_NULL: the probe matrix uploaded by the mode-0 call is still on the device (include/waehip.h)
+    check(ccall((:wae_beyn_moments_rb, libwaehip), Cint, sig, fam.handle, length(rest), zs[rest], ws[rest], ct[:, rest], C_NULL, l, K,
                 fam.tol, fam.maxit, 2, length(idx), 0, 0, A1, 0, 0, 0, 0, info))
     return A .+ A1                                                  # the moments are a plain sum over quadrature points
 end
