@@ -11,7 +11,7 @@ combustor at 1M DoF -- the configuration BASELINE.json quotes its metric on ("1M
 One "step" = one complete pass of the hot path: all quadrature points of the contour (4 edges x 64 Gauss-Legendre
 nodes = 256 shifted systems x l=8 probe columns), each solved on the device by multigrid-GMRES whose operator
 application is the fused multi-term CSR SpMV; moment accumulation in HBM.  By default (--rb -1 = the package's
-automatic rule, 64 of the 256 points) snapshot points are solved first and every other system starts from the Galerkin
+automatic rule, 40 of the 256 points) snapshot points are solved first and every other system starts from the Galerkin
 projection of its solution on them: same moments to the inner tolerance, same stopping test; --rb 0
 solves every system from a zero guess.  N>1: every rank solves all snapshot points for its l/N probe columns, the
 per-column bases are all-gathered, the remaining points are dealt round-robin and the partial moment tensors summed
@@ -79,13 +79,13 @@ def main():
     ap.add_argument("--tau", type=float, default=2e-4)
     ap.add_argument("--rb", type=int, default=-1,
                     help="snapshot points for projected initial guesses (wae_beyn_moments_rb); -1 = the package's automatic "
-                         "rule min(max(40, points/4), points/2); 0 = every system from a zero guess")
+                         "rule min(40, points/2); 0 = every system from a zero guess")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-preset", default="20k")
     args = ap.parse_args()
     if args.rb < 0:
         npts = 4 * args.N
-        args.rb = min(max(40, npts // 4), npts // 2)      # nlevp/beyn.py compute_moment_matrices, automatic rule
+        args.rb = min(40, npts // 2)      # nlevp/beyn.py compute_moment_matrices, automatic rule
 
     import torch
     import torch.distributed as dist

@@ -16,7 +16,7 @@ L.solver_tol = 1e-10; L.solver_maxit = 400; L.solver_ref = 2 * np.pi * 500.0
 L.solver_opts = {"batch": 64, "restart": 40, "sweeps": 1}
 fam = L.ensure_solver()
 G = np.array([150 - 150j, 1000 - 150j, 1000 + 150j, 150 + 150j]) * 2 * np.pi
-N, l, S = (64, 8, 64) if preset == "C3" else (32, 16, 40)
+N, l, S = (64, 8, 40) if preset == "C3" else (32, 16, 40)
 zs, ws = gauss_points(G, N)
 ct = coefficient_table(L, zs)
 idx, rest = snapshot_split(len(zs), S)

@@ -131,7 +131,7 @@ function _snapshot_split(n::Int, rb::Int)
 end
 
 "moments of beyn.jl:62-74 / compute_moment_matrices (beyn.jl:251-268) on the device; `rb` = number of snapshot points
-for projected initial guesses (wae_beyn_moments_rb; default max(40, npts/4) for contours of at least 64 points)"
+for projected initial guesses (wae_beyn_moments_rb; default 40 for contours of at least 64 points)"
 function compute_moment_matrices(fam::DeviceFamily, Γ, V::Matrix{ComplexF64}; K=1, N=16, rb=nothing)
     ensure_solver!(fam)
     L = fam.L
@@ -149,7 +149,7 @@ function compute_moment_matrices(fam::DeviceFamily, Γ, V::Matrix{ComplexF64}; K
     d, l = size(V)
     A = zeros(ComplexF64, d, l, 2K); info = Ref{SolveInfo}()
     npts = length(zs)
-    rb === nothing && (rb = (npts >= 64 && d >= 1000) ? min(max(40, div(npts, 4)), div(npts, 2)) : 0)
+    rb === nothing && (rb = (npts >= 64 && d >= 1000) ? min(40, div(npts, 2)) : 0)
     if rb == 0 || npts < 2rb
         check(ccall((:wae_beyn_moments, libwaehip), Cint,
                     (Ptr{Cvoid}, Int32, Ptr{ComplexF64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Int32, Int32, Float64, Int32,

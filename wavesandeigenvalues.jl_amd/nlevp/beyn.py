@@ -86,8 +86,9 @@ def spread_order(idx):
 def compute_moment_matrices(L, G, V=None, l=5, K=1, N=16, points=None, out_dev=0, rb=None):
     """beyn.jl:233-268.  ``points=(z, w)`` overrides the contour (used to shard the quadrature over GPUs).
 
-    ``rb`` = number of snapshot points (default ``L.rb_snapshots``; None = max(40, a quarter of the points), at most
-    half of them, when there are at least 64 points and d >= 1000 -- measured optima: 40 of 128 at C2, 64 of 256 at C3; 0 = every system from a zero guess): the solutions
+    ``rb`` = number of snapshot points (default ``L.rb_snapshots``; None = 40, at most half of the points, when there are
+    at least 64 points and d >= 1000 -- the measured optimum both for 128 points at C2 (of 32/40/48/56) and for 256 points at
+    C3 (of 24...72: the count follows the solution manifold, not the quadrature); 0 = every system from a zero guess): the solutions
     at ``rb`` points spread along the contour are kept in HBM, all other points start from their Galerkin projection on
     those (wae_beyn_moments_rb); same moments to the inner tolerance, several times fewer Krylov iterations."""
     d = L.size()
@@ -99,7 +100,7 @@ def compute_moment_matrices(L, G, V=None, l=5, K=1, N=16, points=None, out_dev=0
     ct = coefficient_table(L, zs) if len(zs) else np.zeros((0, len(L.terms)), dtype=np.complex128)
     rb = getattr(L, "rb_snapshots", None) if rb is None else rb
     if rb is None:                                   # automatic, for contours worth the set-up
-        rb = min(max(40, len(zs) // 4), len(zs) // 2) if (len(zs) >= 64 and d >= 1000) else 0
+        rb = min(40, len(zs) // 2) if (len(zs) >= 64 and d >= 1000) else 0
     if not rb or len(zs) < 2 * rb:
         return fam.beyn_moments(zs, ws, ct, V, K=K, tol=L.solver_tol, maxit=L.solver_maxit, out_dev=out_dev)
     idx, rest = snapshot_split(len(zs), rb)
