@@ -1010,6 +1010,9 @@ void launch_axpy_neg_norm(const cplx *V, size_t stride, int nv, const cplx *h, c
 void launch_lincomb(const cplx *V, size_t stride, int nv, const cplx *y, cplx *Y, int64_t n, int nb, hipStream_t st) {
     axpy_impl(V, stride, nv, y, Y, n, nb, 1.0, nullptr, st, nullptr);
 }
+void launch_lincomb_add(const cplx *V, size_t stride, int nv, const cplx *y, cplx *X, int64_t n, int nb, hipStream_t st) {
+    axpy_impl(V, stride, nv, y, X, n, nb, 1.0, X, st, nullptr);      // X += sum_i y_i V_i
+}
 
 // ---------------------------------------------------------------------------------------------------
 // snapshot-basis helpers (Galerkin initial guesses for the shifted systems of a contour, lib.hip: beyn_moments_rb)

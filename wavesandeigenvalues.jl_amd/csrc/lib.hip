@@ -95,6 +95,8 @@ struct wae_family {
     int64_t n_penalty = 0;
     LevelOp pen_op;
     std::vector<int> pen_slot;
+    LevelOp pen_row_op;              // the penalty ROWS of the operator (n_penalty x d): their residual without a full SpMV
+    std::vector<int> pen_row_slot;
     DevBuf<int> pen_rows;
     DevBuf<cplx> pen_b, pen_x, pen_t;
     cplx *h_pinned = nullptr;        // (restart+2)*NB
@@ -276,10 +278,10 @@ static void upload_pc(wae_family *h, const std::vector<std::vector<zc>> &pcs) {
     const int nsys = (int)pcs.size();
     const int nl = (int)h->ops.size();
     const size_t per_level = (size_t)nsys * h->nplanes;
-    std::vector<cplx> tab(per_level * (nl + 1));
-    for (int l = 0; l <= nl; ++l) {                      // block nl: the penalty-row operator (own slot order)
-        if (l == nl && h->n_penalty == 0) break;
-        const std::vector<int> &sp = l < nl ? h->slot_plane[l] : h->pen_slot;
+    std::vector<cplx> tab(per_level * (nl + 2));
+    for (int l = 0; l <= nl + 1; ++l) {                  // blocks nl, nl+1: the penalty block and the penalty rows (own slot orders)
+        if (l >= nl && h->n_penalty == 0) break;
+        const std::vector<int> &sp = l < nl ? h->slot_plane[l] : (l == nl ? h->pen_slot : h->pen_row_slot);
         for (int s = 0; s < nsys; ++s)
             for (int q = 0; q < h->nplanes; ++q) {
                 const zc c = pcs[s][sp[q]];
@@ -375,8 +377,15 @@ static void penalty_polish(wae_family *h, const Batch &bt, const cplx *B, cplx *
     const OpDev A = h->ops[0].dev(bt.op);
     const OpDev Ab = h->pen_op.dev(bt.op);
     const cplx *pcb = pc_level(h, (int)h->ops.size());
-    launch_spmv(A, pc_level(h, 0), bt.cps, X, h->W.p, B, 0.0, nb, MODE_RES, st);
-    launch_gather_rows(h->W.p, h->pen_rows.p, nbk, nb, h->pen_b.p, st);
+    if (bt.op == WAE_OP_N && h->pen_row_op.n == nbk) {
+        // residual on the penalty rows only: their rows of the operator as a small (n_b x d) operator of its own -- the full
+        // fine-level SpMV this replaces cost as much as a Krylov step's operator product per chunk
+        launch_gather_rows(B, h->pen_rows.p, nbk, nb, h->pen_t.p, st);
+        launch_spmv(h->pen_row_op.dev(WAE_OP_N), pc_level(h, (int)h->ops.size() + 1), bt.cps, X, h->pen_b.p, h->pen_t.p, 0.0, nb, MODE_RES, st);
+    } else {
+        launch_spmv(A, pc_level(h, 0), bt.cps, X, h->W.p, B, 0.0, nb, MODE_RES, st);
+        launch_gather_rows(h->W.p, h->pen_rows.p, nbk, nb, h->pen_b.p, st);
+    }
     launch_norms(h->pen_b.p, nbk, nb, h->partial.p, h->hdev.p, st);
     cplx *x = h->pen_x.p, *t = h->pen_t.p;
     launch_jacobi0(Ab, pcb, bt.cps, h->pen_b.p, x, 0.8, nb, st);
@@ -659,8 +668,7 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
         }
         if (ju > 0) {
             h->ydev.upload(y.data(), (size_t)ju * nb, st);
-            launch_lincomb(h->V.p + (size_t)off * vec, vec, ju, h->ydev.p, h->U.p, n, nb, st);
-            launch_add(h->U.p, X, vec, st);
+            launch_lincomb_add(h->V.p + (size_t)off * vec, vec, ju, h->ydev.p, X, n, nb, st);      // x += V y in one pass over x
             HIP_CHECK(hipStreamSynchronize(st));       // y is a stack vector
         }
         if (deflate) {                                    // x += alpha g: cancels the u^ component of the residual
@@ -1251,6 +1259,20 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
                     }
                 }
                 h->pen_slot = build_levelop(h->pen_op, sub, st);
+                for (size_t q = 0; q < h->planes0.size(); ++q) {      // the same rows with ALL their columns (global numbering)
+                    const CsrZ &A = h->planes0[q];
+                    CsrZ &B = sub[q];
+                    B = CsrZ();
+                    B.n = (int64_t)rows.size();
+                    B.m = A.m;
+                    B.ptr.assign(rows.size() + 1, 0);
+                    for (size_t i = 0; i < rows.size(); ++i) {
+                        B.col.insert(B.col.end(), A.col.begin() + A.ptr[rows[i]], A.col.begin() + A.ptr[rows[i] + 1]);
+                        B.val.insert(B.val.end(), A.val.begin() + A.ptr[rows[i]], A.val.begin() + A.ptr[rows[i] + 1]);
+                        B.ptr[i + 1] = (int)B.col.size();
+                    }
+                }
+                h->pen_row_slot = build_levelop(h->pen_row_op, sub, st);
                 h->pen_rows.upload(rows.data(), rows.size(), st);
                 const size_t cnt = rows.size() * (size_t)h->NB;
                 h->pen_b.alloc(cnt); h->pen_x.alloc(cnt); h->pen_t.alloc(cnt);

@@ -161,6 +161,7 @@ void launch_axpy_neg(const cplx *V, size_t stride, int nv, const cplx *h, cplx *
 void launch_axpy_neg_norm(const cplx *V, size_t stride, int nv, const cplx *h, cplx *W, int64_t n, int nb, cplx *partial, cplx *norms,
                           hipStream_t s, const unsigned char *cmask = nullptr);
 void launch_lincomb(const cplx *V, size_t stride, int nv, const cplx *y, cplx *Y, int64_t n, int nb, hipStream_t s);
+void launch_lincomb_add(const cplx *V, size_t stride, int nv, const cplx *y, cplx *X, int64_t n, int nb, hipStream_t s);   // X += V y
 // norms: out[b] = ||X[:,b]||_2  (real part of out[b], imag 0)
 void launch_norms(const cplx *X, int64_t n, int nb, cplx *partial, cplx *out, hipStream_t s, const unsigned char *cmask = nullptr);
 // Y[:,b] = X[:,b] * (1/alpha[b].x)  (0 if alpha tiny)
