@@ -773,7 +773,8 @@ __global__ __launch_bounds__(256) void dots_kernel(const cplx *__restrict__ V, s
 // EPB outputs per workgroup, 256/EPB slices of the nblk partials each: with 32 outputs per workgroup the norms of one batch
 // (64 outputs, 768-1024 partials) ran on 2 workgroups, ~100 dependent-latency loads per lane (31 us per call, 3.7 % of a pass)
 template <int EPB>
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const cplx *__restrict__ partial, int nblk, int count, cplx *__restrict__ out, int do_sqrt) {
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const cplx *__restrict__ partial, int nblk, int count, cplx *__restrict__ out, int do_sqrt,
+                                                              const cplx *__restrict__ scale, cplx *__restrict__ inv_out) {
     __shared__ cplx sm[256];
     constexpr int NS = 256 / EPB;
     const int lane_e = threadIdx.x % EPB, slice = threadIdx.x / EPB;
@@ -790,18 +791,23 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const cplx *__rest
     }
     if (slice == 0 && e < count) {
         acc = sm[threadIdx.x];
-        if (do_sqrt) acc = cplx{sqrt(acc.x), 0.0};
+        if (scale) { const double sc = scale[e].x; acc.x *= sc; acc.y *= sc; }        // dots against unnormalised vectors (lazy GMRES basis)
+        if (do_sqrt) {
+            if (inv_out) inv_out[e] = cplx{acc.x > 0.0 ? 1.0 / acc.x : 0.0, 0.0};     // 1/||.||^2 of the vector just measured
+            acc = cplx{sqrt(acc.x), 0.0};
+        }
         out[e] = acc;
     }
 }
-static void launch_reduce_partials(const cplx *partial, int nblk, int count, cplx *out, int do_sqrt, hipStream_t st) {
-    if (count <= 256) hipLaunchKernelGGL(reduce_partials_kernel<2>, dim3((count + 1) / 2), dim3(256), 0, st, partial, nblk, count, out, do_sqrt);
-    else hipLaunchKernelGGL(reduce_partials_kernel<8>, dim3((count + 7) / 8), dim3(256), 0, st, partial, nblk, count, out, do_sqrt);
+static void launch_reduce_partials(const cplx *partial, int nblk, int count, cplx *out, int do_sqrt, hipStream_t st,
+                                   const cplx *scale = nullptr, cplx *inv_out = nullptr) {
+    if (count <= 256) hipLaunchKernelGGL(reduce_partials_kernel<2>, dim3((count + 1) / 2), dim3(256), 0, st, partial, nblk, count, out, do_sqrt, scale, inv_out);
+    else hipLaunchKernelGGL(reduce_partials_kernel<8>, dim3((count + 7) / 8), dim3(256), 0, st, partial, nblk, count, out, do_sqrt, scale, inv_out);
     HIP_CHECK(hipGetLastError());
 }
 
 static void dots_impl(const cplx *V, size_t stride, int nv, const cplx *W, int64_t n, int nb, cplx *partial, cplx *out, int do_sqrt, hipStream_t st,
-                      const unsigned char *cmask) {
+                      const unsigned char *cmask, const cplx *scale = nullptr) {
     if (nb < 1 || nb > 256) throw WaeError(WAE_ERR_INVALID, "dots: nb must be in 1..256");
     int done = 0;
     while (done < nv) {
@@ -821,7 +827,7 @@ static void dots_impl(const cplx *V, size_t stride, int nv, const cplx *W, int64
 #undef WAE_DOTS
         HIP_CHECK(hipGetLastError());
         int count = chunk * nb;
-        launch_reduce_partials(partial, nblk, count, out + (size_t)done * nb, do_sqrt, st);
+        launch_reduce_partials(partial, nblk, count, out + (size_t)done * nb, do_sqrt, st, scale ? scale + (size_t)done * nb : nullptr);
         done += chunk;
     }
 }
@@ -894,6 +900,10 @@ void launch_dots_multi(const cplx *V, size_t sv, int nv, const cplx *W, size_t s
 void launch_dots(const cplx *V, size_t stride, int nv, const cplx *W, int64_t n, int nb, cplx *partial, cplx *out, hipStream_t st,
                  const unsigned char *cmask) {
     dots_impl(V, stride, nv, W, n, nb, partial, out, 0, st, cmask);
+}
+void launch_dots_scaled(const cplx *V, size_t stride, int nv, const cplx *W, int64_t n, int nb, cplx *partial, cplx *out, const cplx *scale,
+                        hipStream_t st, const unsigned char *cmask) {
+    dots_impl(V, stride, nv, W, n, nb, partial, out, 0, st, cmask, scale);
 }
 void launch_norms(const cplx *X, int64_t n, int nb, cplx *partial, cplx *out, hipStream_t st, const unsigned char *cmask) {
     dots_impl(X, 0, 1, X, n, nb, partial, out, 1, st, cmask);
@@ -990,12 +1000,16 @@ void launch_axpy_neg(const cplx *V, size_t stride, int nv, const cplx *h, cplx *
     axpy_impl(V, stride, nv, h, W, n, nb, -1.0, W, st, cmask);
 }
 // w -= V h and norms[b] = ||w[:,b]|| in one pass over w (falls back to two kernels when the coefficients do not fit one launch)
+// base (optional): W = base - V h instead of the in-place update; inv_out (optional): 1/||W[:,b]||^2 beside the norms.  Both are
+// what a Krylov basis kept UNNORMALISED needs (lib.hip gmres): the new vector goes straight into its basis slot.
 void launch_axpy_neg_norm(const cplx *V, size_t stride, int nv, const cplx *h, cplx *W, int64_t n, int nb, cplx *partial, cplx *norms,
-                          hipStream_t st, const unsigned char *cmask) {
+                          hipStream_t st, const unsigned char *cmask, const cplx *base, cplx *inv_out) {
     if (!n || nb < 1) return;
     if (nb > 256) throw WaeError(WAE_ERR_INVALID, "axpy: nb must be in 1..256");
+    if (!base) base = W;
     if (nv < 1 || nv > AX_MAXC / nb) {
-        axpy_impl(V, stride, nv, h, W, n, nb, -1.0, W, st, cmask);
+        if (inv_out) throw WaeError(WAE_ERR_INVALID, "axpy_neg_norm: inverse norms need the single-launch form");
+        axpy_impl(V, stride, nv, h, W, n, nb, -1.0, base, st, cmask);
         launch_norms(W, n, nb, partial, norms, st, cmask);
         return;
     }
@@ -1003,9 +1017,9 @@ void launch_axpy_neg_norm(const cplx *V, size_t stride, int nv, const cplx *h, c
     const int64_t steps = (n + R - 1) / R;
     const unsigned grid = (unsigned)std::min<int64_t>(steps, 1024);
     const size_t shm = std::max((size_t)nv * nb * sizeof(cplx), (size_t)256 * sizeof(double));
-    hipLaunchKernelGGL(axpy_neg_kernel<true>, dim3(grid), dim3(256), shm, st, V, stride, nv, h, W, n, nb, -1.0, (const cplx *)W, cmask, partial);
+    hipLaunchKernelGGL(axpy_neg_kernel<true>, dim3(grid), dim3(256), shm, st, V, stride, nv, h, W, n, nb, -1.0, base, cmask, partial);
     HIP_CHECK(hipGetLastError());
-    launch_reduce_partials(partial, (int)grid, nb, norms, 1, st);
+    launch_reduce_partials(partial, (int)grid, nb, norms, 1, st, nullptr, inv_out);
 }
 void launch_lincomb(const cplx *V, size_t stride, int nv, const cplx *y, cplx *Y, int64_t n, int nb, hipStream_t st) {
     axpy_impl(V, stride, nv, y, Y, n, nb, 1.0, nullptr, st, nullptr);

@@ -87,6 +87,7 @@ struct wae_family {
     // workspaces
     std::vector<DevBuf<cplx>> lx, lb, lt;
     DevBuf<cplx> V, W, Z, Xs, Bs, U, partial, hdev, ydev, pcdev, one_dev, io_a, io_b, zw_dev;
+    DevBuf<cplx> vsq;                // 1/||v_i||^2 per basis slot and column: the wide-batch GMRES keeps its basis unnormalised
     DevBuf<cplx> rbQ;                // library-owned snapshot store of wae_beyn_moments_rb
     RbState rb;                      // the snapshot basis and its projected terms
     DevBuf<int> plane_col_dev;
@@ -431,6 +432,11 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
     const int m = (int)std::min<size_t>(150, h->V.n / vec - 1) - off;
     static const char *env_re = getenv("WAE_REORTH");
     const bool reorth = env_re ? atoi(env_re) != 0 : nb <= 8;
+    // wide batches, single Gram-Schmidt pass: unnormalised basis (see the inner loop); WAE_LAZY=0 restores the normalisation pass
+    static const bool lazy_on = !(getenv("WAE_LAZY") && atoi(getenv("WAE_LAZY")) == 0);
+    const size_t nslots = (size_t)m + off + 2;             // basis slots incl. the deflation vector and the newest vector
+    const bool lazy = lazy_on && !reorth && nslots * nb <= 4096 && nslots * nb <= h->vsq.n;   // 4096: coefficients of one axpy launch
+    std::vector<std::vector<double>> sv(lazy ? nslots : 0, std::vector<double>(nb, 1.0));
     const OpDev A = h->ops[0].dev(bt.op);
     const cplx *pc = pc_level(h, 0);
     cplx *hp = h->h_pinned;
@@ -571,6 +577,12 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
             break;
         }
         launch_scale_inv(z0, h->hdev.p, h->V.p + (size_t)off * vec, n, nb, st);     // V0 = M^-1 r / beta
+        if (lazy) {                                      // slots 0..off hold unit vectors
+            for (int i = 0; i <= off; ++i) std::fill(sv[i].begin(), sv[i].end(), 1.0);
+            std::vector<cplx> ones((size_t)(off + 1) * nb, cplx{1.0, 0.0});
+            h->vsq.upload(ones.data(), ones.size(), st);
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
         if (use_mask && nb >= 8) {
             for (int k = 0; k < nch; ++k) cm[k] = 0;
             for (int b = 0; b < nb; ++b) if (!done[b]) cm[b >> 3] = 1;
@@ -595,6 +607,15 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
             const bool fuse0 = h->ops.size() > 1;                // A v_j and the V-cycle's first sweep on it in one kernel
             launch_spmv(A, pc, bt.cps, vj, h->W.p, fuse0 ? h->lx[0].p : nullptr, fuse0 ? h->jac_w : 0.0, nb, fuse0 ? MODE_AX_J0 : MODE_AX, st, mk);
             cplx *w = vcycle(h, bt, 0, h->W.p, mk, fuse0);       // w = M^-1 A v_j  (lives in a V-cycle buffer)
+            if (lazy) {
+                // The basis is kept UNNORMALISED (v_i = s_i V^_i, s_i = 1/||V^_i||): M^-1 A is linear, so w^ = M^-1 A V^_j = w/s_j,
+                // the update coefficients of w^ against V^_i are s_i^2 (V^_i^H w^) -- s_j cancels -- and the new vector goes
+                // straight into its slot; the host rescales what it reads (h_ij = s_j c_i / s_i, h_{j+1,j} = s_j ||w^'||).
+                // Saves the normalisation pass (read + write of one multivector) of every iteration.
+                launch_dots_scaled(h->V.p, vec, nvj, w, n, nb, h->partial.p, h->hdev.p, h->vsq.p, st, mk);
+                launch_axpy_neg_norm(h->V.p, vec, nvj, h->hdev.p, h->V.p + (size_t)nvj * vec, n, nb, h->partial.p, h->hdev.p + (size_t)nvj * nb, st, mk,
+                                     w, h->vsq.p + (size_t)nvj * nb);
+            } else {
             launch_dots(h->V.p, vec, nvj, w, n, nb, h->partial.p, h->hdev.p, st, mk);
             if (reorth) {   // CGS2: h += V^H w', w' -= V (V^H w')
                 launch_axpy_neg(h->V.p, vec, nvj, h->hdev.p, w, n, nb, st, mk);
@@ -606,8 +627,22 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
                 launch_axpy_neg_norm(h->V.p, vec, nvj, h->hdev.p, w, n, nb, h->partial.p, h->hdev.p + (size_t)nvj * nb, st, mk);
             }
             launch_scale_inv(w, h->hdev.p + (size_t)nvj * nb, h->V.p + (size_t)nvj * vec, n, nb, st, mk);
+            }
             HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, (size_t)(nvj + 1) * nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
+            if (lazy) {                                  // back to the coefficients of the normalised recurrence
+                for (int b = 0; b < nb; ++b) {
+                    const double sj = sv[nvj - 1][b];
+                    for (int i = 0; i < nvj; ++i) {
+                        const double f = sv[i][b] > 0.0 ? sj / sv[i][b] : 0.0;
+                        hp[(size_t)i * nb + b].x *= f;
+                        hp[(size_t)i * nb + b].y *= f;
+                    }
+                    const double r = hp[(size_t)nvj * nb + b].x;
+                    sv[nvj][b] = r > 0.0 ? 1.0 / r : 0.0;
+                    hp[(size_t)nvj * nb + b].x = sj * r;
+                }
+            }
             ++total_it;
             bool all_conv = true;
             for (int b = 0; b < nb; ++b) {
@@ -664,7 +699,10 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
                 const zc dgi = c.H[(size_t)i * (m + 1) + i];
                 yy[i] = (dgi != zc(0)) ? s / dgi : zc(0);
             }
-            for (int i = 0; i < k; ++i) y[(size_t)i * nb + b] = cplx{yy[i].real(), yy[i].imag()};
+            for (int i = 0; i < k; ++i) {
+                const double f = lazy ? sv[off + i][b] : 1.0;                // x += sum_i y_i s_i V^_i
+                y[(size_t)i * nb + b] = cplx{f * yy[i].real(), f * yy[i].imag()};
+            }
         }
         if (ju > 0) {
             h->ydev.upload(y.data(), (size_t)ju * nb, st);
@@ -1336,6 +1374,7 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
         HIP_CHECK(hipStreamSynchronize(st));
         h->partial.alloc((size_t)1024 * 32 * NB);   // DOT_BLOCKS x 32 vectors x NB columns
         h->hdev.alloc((size_t)2 * (m + 3) * NB);     // second half: scratch for the re-orthogonalisation pass
+        h->vsq.alloc((size_t)(m + 3) * NB);
         h->ydev.alloc((size_t)(m + 1) * NB);
         if (h->h_pinned) { (void)hipHostFree(h->h_pinned); h->h_pinned = nullptr; }
         HIP_CHECK(hipHostMalloc((void **)&h->h_pinned, (size_t)(m + 2) * NB * sizeof(cplx)));

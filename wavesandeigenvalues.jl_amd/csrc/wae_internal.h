@@ -159,7 +159,10 @@ void launch_axpy_neg(const cplx *V, size_t stride, int nv, const cplx *h, cplx *
                      const unsigned char *cmask = nullptr);
 // Y = sum_i y[i][b] V_i
 void launch_axpy_neg_norm(const cplx *V, size_t stride, int nv, const cplx *h, cplx *W, int64_t n, int nb, cplx *partial, cplx *norms,
-                          hipStream_t s, const unsigned char *cmask = nullptr);
+                          hipStream_t s, const unsigned char *cmask = nullptr, const cplx *base = nullptr, cplx *inv_out = nullptr);
+// launch_dots with every output (i, b) multiplied by scale[i][b].x
+void launch_dots_scaled(const cplx *V, size_t stride, int nv, const cplx *W, int64_t n, int nb, cplx *partial, cplx *out, const cplx *scale,
+                        hipStream_t s, const unsigned char *cmask = nullptr);
 void launch_lincomb(const cplx *V, size_t stride, int nv, const cplx *y, cplx *Y, int64_t n, int nb, hipStream_t s);
 void launch_lincomb_add(const cplx *V, size_t stride, int nv, const cplx *y, cplx *X, int64_t n, int nb, hipStream_t s);   // X += V y
 // norms: out[b] = ||X[:,b]||_2  (real part of out[b], imag 0)
