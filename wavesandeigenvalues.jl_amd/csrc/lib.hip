@@ -642,6 +642,18 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
                     sv[nvj][b] = r > 0.0 ? 1.0 / r : 0.0;
                     hp[(size_t)nvj * nb + b].x = sj * r;
                 }
+                // the stored norms are the running products of the sub-diagonal entries: long recurrences could carry them
+                // out of range (their squares are used) -- normalise this one vector in place and start over from 1
+                bool rescale = false;
+                static const double lim = getenv("WAE_LAZY_LIMIT") ? atof(getenv("WAE_LAZY_LIMIT")) : 1e100;   // (small values exercise this branch in tests)
+                for (int b = 0; b < nb; ++b) rescale = rescale || sv[nvj][b] > lim || (sv[nvj][b] > 0.0 && sv[nvj][b] < 1.0 / lim);
+                if (rescale) {
+                    launch_scale_inv(h->V.p + (size_t)nvj * vec, h->hdev.p + (size_t)nvj * nb, h->V.p + (size_t)nvj * vec, n, nb, st, mk);
+                    std::vector<cplx> ones(nb, cplx{1.0, 0.0});
+                    for (int b = 0; b < nb; ++b) if (sv[nvj][b] > 0.0) sv[nvj][b] = 1.0; else ones[b] = cplx{0.0, 0.0};
+                    HIP_CHECK(hipMemcpyAsync(h->vsq.p + (size_t)nvj * nb, ones.data(), (size_t)nb * sizeof(cplx), hipMemcpyHostToDevice, st));
+                    HIP_CHECK(hipStreamSynchronize(st));
+                }
             }
             ++total_it;
             bool all_conv = true;
