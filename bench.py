@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the NLEVP hot path on MI355X:  eigenpairs/sec of a Beyn contour solve on the synthetic annular
 combustor at 1M DoF -- the configuration BASELINE.json quotes its metric on ("1M-DoF Helmholtz NLEVP", configs[2]:
-995 328 DoF, n·exp(-iωτ) flame term, Beyn N=64 per edge, l=8); it fits one GPU (about 60 GB of HBM).  BASELINE configs[1]
+995 328 DoF, n·exp(-iωτ) flame term, Beyn N=64 per edge, l=8); it fits one GPU (about 77 GB of HBM).  BASELINE configs[1]
 (200k DoF, N=32) is `--preset C2 --N 32 --l 16`.
 
     python bench.py --gpus 1 --steps K --warmup W
