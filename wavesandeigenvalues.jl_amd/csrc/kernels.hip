@@ -1163,29 +1163,66 @@ void launch_replicate(const cplx *Vc, int64_t d, int l, cplx *Xi, int nb, hipStr
     HIP_CHECK(hipGetLastError());
 }
 
-// A[(p*l+c)*d + row] += sum_s w[s] z[s]^p X[row][s*l+c]
+// A[(p*lA + c0 + c)*d + row] += sum_s w[s] z[s]^p X[row][s*l+c]
+// X is interleaved [row][nb] and A column-major [row fastest]: a workgroup stages TR rows of X in LDS (coalesced 16-B reads),
+// then every thread owns one (row, c) of the tile, sums over the systems in registers and touches each moment entry once
+// (coalesced along the rows).  The first version read X with a 1-KB lane stride and re-read/re-wrote A once per system:
+// 1.5 ms per chunk at 1M DoF against 0.4 ms of traffic.
+constexpr int ACC_MAXP = 8;         // moments (2K) accumulated in registers per pass over the systems
 __global__ __launch_bounds__(256) void beyn_accum_kernel(const cplx *__restrict__ Xi, int nb, int64_t d, int l, int nsys,
                                                          const cplx *__restrict__ w, const cplx *__restrict__ z, int npow, cplx *__restrict__ A,
-                                                         int lA, int c0) {
-    const size_t total = (size_t)d * l;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const size_t c = e / d, row = e - c * d;
-        for (int s = 0; s < nsys; ++s) {
-            cplx t = cmul(w[s], Xi[row * nb + (size_t)s * l + c]);
-            const cplx zs = z[s];
-            for (int p = 0; p < npow; ++p) {
-                cplx *dst = A + ((size_t)p * lA + c0 + c) * d + row;
-                cplx a = *dst;
-                *dst = cplx{a.x + t.x, a.y + t.y};
-                t = cmul(t, zs);
+                                                         int lA, int c0, int TR) {
+    extern __shared__ cplx tile[];                           // TR x (nb + 1): the pad keeps the column reads off one bank
+    const int ld = nb + 1;
+    const int tid = threadIdx.x;
+    for (int64_t row0 = (int64_t)blockIdx.x * TR; row0 < d; row0 += (int64_t)gridDim.x * TR) {
+        for (int e = tid; e < TR * nb; e += 256) {
+            const int r = e / nb, col = e - r * nb;
+            tile[r * ld + col] = (row0 + r < d) ? Xi[(size_t)(row0 + r) * nb + col] : cplx{0.0, 0.0};
+        }
+        __syncthreads();
+        for (int idx = tid; idx < TR * l; idx += 256) {
+            const int c = idx / TR, r = idx - c * TR;
+            const int64_t row = row0 + r;
+            if (row >= d) continue;
+            for (int p0 = 0; p0 < npow; p0 += ACC_MAXP) {
+                const int np = npow - p0 < ACC_MAXP ? npow - p0 : ACC_MAXP;
+                cplx acc[ACC_MAXP];
+#pragma unroll
+                for (int p = 0; p < ACC_MAXP; ++p) acc[p] = cplx{0.0, 0.0};
+                for (int s = 0; s < nsys; ++s) {
+                    cplx t = cmul(w[s], tile[r * ld + s * l + c]);
+                    const cplx zs = z[s];
+                    for (int q = 0; q < p0; ++q) t = cmul(t, zs);
+#pragma unroll
+                    for (int p = 0; p < ACC_MAXP; ++p) {
+                        if (p < np) { acc[p].x += t.x; acc[p].y += t.y; t = cmul(t, zs); }
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < ACC_MAXP; ++p) {
+                    if (p < np) {
+                        cplx *dst = A + ((size_t)(p0 + p) * lA + c0 + c) * d + row;
+                        const cplx a = *dst;
+                        *dst = cplx{a.x + acc[p].x, a.y + acc[p].y};
+                    }
+                }
             }
         }
+        __syncthreads();
     }
 }
 void launch_beyn_accum(const cplx *Xi, int nb, int64_t d, int l, int nsys, const cplx *w, const cplx *z, int npow, cplx *A, hipStream_t st,
                        int lA, int c0) {
     if (lA <= 0) lA = l;
-    hipLaunchKernelGGL(beyn_accum_kernel, dim3(grid_for((size_t)d * l)), dim3(256), 0, st, Xi, nb, d, l, nsys, w, z, npow, A, lA, c0);
+    if (!d || nb < 1) return;
+    if (nb > 256) throw WaeError(WAE_ERR_INVALID, "beyn_accum: nb must be in 1..256");
+    int TR = 2048 / (nb + 1);                                // <= 32 KB of LDS
+    if (TR > 32) TR = 32;
+    if (TR < 1) TR = 1;
+    const int64_t tiles = (d + TR - 1) / TR;
+    const unsigned grid = (unsigned)std::min<int64_t>(tiles, 4096);
+    hipLaunchKernelGGL(beyn_accum_kernel, dim3(grid), dim3(256), (size_t)TR * (nb + 1) * sizeof(cplx), st, Xi, nb, d, l, nsys, w, z, npow, A, lA, c0, TR);
     HIP_CHECK(hipGetLastError());
 }
 
