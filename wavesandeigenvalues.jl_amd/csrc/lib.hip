@@ -1482,6 +1482,7 @@ int wae_beyn_moments(wae_family *h, int32_t npts, const double *z, const double 
         HIP_CHECK(hipMemcpyAsync(h->io_a.p, V, (size_t)d * l * sizeof(cplx), hipMemcpyHostToDevice, st));
         const int spc = std::max(1, h->NB / l);   // systems per chunk
         ensure(h->zw_dev, (size_t)2 * spc);
+        int rep_nb = -1;
         for (int p0 = 0; p0 < npts; p0 += spc) {
             const int ns = std::min(spc, npts - p0);
             Batch bt;
@@ -1495,7 +1496,7 @@ int wae_beyn_moments(wae_family *h, int32_t npts, const double *z, const double 
             }
             h->zw_dev.upload(zw.data(), zw.size(), st);
             HIP_CHECK(hipStreamSynchronize(st));
-            launch_replicate(h->io_a.p, d, l, h->Bs.p, bt.nb, st);
+            if (bt.nb != rep_nb) { launch_replicate(h->io_a.p, d, l, h->Bs.p, bt.nb, st); rep_nb = bt.nb; }   // same right-hand sides for every chunk
             solve_chunk(h, bt, pcs, h->Bs.p, h->Xs.p, tol, maxit, &li);
             launch_beyn_accum(h->Xs.p, bt.nb, d, l, ns, h->zw_dev.p, h->zw_dev.p + ns, npow, Ad, st);
         }
@@ -1586,7 +1587,7 @@ int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const doub
         static const int doubling = getenv("WAE_RB_DOUBLING") ? atoi(getenv("WAE_RB_DOUBLING")) : 1;
         static const int c0cols = getenv("WAE_RB_C0COLS") ? std::max(1, atoi(getenv("WAE_RB_C0COLS"))) : 16;
         const int c0 = doubling ? std::max(1, c0cols / l) : spc;
-        int ns_next = 0;
+        int ns_next = 0, rep_nb = -1;
         for (int p0 = 0; p0 < npts; p0 += ns_next) {
             const int ns = (mode == 0) ? std::min(std::min(spc, npts - p0), std::max(c0, R.S)) : std::min(spc, npts - p0);
             ns_next = ns;
@@ -1601,7 +1602,7 @@ int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const doub
             }
             h->zw_dev.upload(zw.data(), zw.size(), st);
             HIP_CHECK(hipStreamSynchronize(st));
-            launch_replicate(h->io_a.p, d, l, h->Bs.p, bt.nb, st);
+            if (bt.nb != rep_nb) { launch_replicate(h->io_a.p, d, l, h->Bs.p, bt.nb, st); rep_nb = bt.nb; }   // same right-hand sides for every chunk
             const bool guess = R.S > 0;            // mode 0 is progressive: later snapshot chunks start from the earlier ones
             const double ta = now_s();
             if (guess) {
