@@ -674,3 +674,41 @@ def test_finite_difference_shape_sensitivity_confirms_the_adjoint_gradient():
     assert np.all(scale > 1.0)
     assert np.all(np.abs(fd - adj).max(axis=0) <= 2e-3 * scale), (fd, adj)
     Lp._drop_device()
+
+
+def test_unnormalised_basis_range_guard_branch():
+    """The wide-batch GMRES keeps its basis unnormalised and re-normalises a vector only when its stored norm leaves
+    [1e-100, 1e100] -- a branch ordinary problems never reach.  WAE_LAZY_LIMIT=3 (read once per process, hence the child
+    process) makes nearly every iteration take it; WAE_LAZY=0 is the explicit normalisation pass.  All three must give the
+    same solutions and iteration counts as the default."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import json, numpy as np
+from wae_amd.helmholtz.family import annulus_family
+from wae_amd.nlevp import gauss_points
+L, pb = annulus_family("small", tau=2e-4)
+L.solver_tol = 1e-11; L.solver_ref = 2 * np.pi * 500.0
+fam = L.ensure_solver()
+G = np.array([150 - 150j, 1000 - 150j, 1000 + 150j, 150 + 150j]) * 2 * np.pi
+zs, _ = gauss_points(G, 16)
+rng = np.random.default_rng(11)
+B = rng.standard_normal((pb["d"], 64)) + 1j * rng.standard_normal((pb["d"], 64))
+ct = np.array([L.coefficients(z) for z in zs])
+X = fam.solve(ct, B, tol=1e-11, maxit=300)
+i = fam.last_info
+print(json.dumps({"its": i["iters_total"], "unconv": i["n_unconverged"], "sum": [float(np.abs(X).sum()), float(np.abs(X[::7]).sum())]}))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for name, extra in (("default", {}), ("guard", {"WAE_LAZY_LIMIT": "3"}), ("explicit", {"WAE_LAZY": "0"})):
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), **extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        import json
+        out[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    for name in ("guard", "explicit"):
+        assert out[name]["unconv"] == 0 and out["default"]["unconv"] == 0
+        assert abs(out[name]["its"] - out["default"]["its"]) <= 0.02 * out["default"]["its"]
+        assert np.allclose(out[name]["sum"], out["default"]["sum"], rtol=1e-8)
