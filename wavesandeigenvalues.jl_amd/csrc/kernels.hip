@@ -1081,9 +1081,71 @@ __global__ __launch_bounds__(256) void lincomb_rep_kernel(const cplx *__restrict
         X[(size_t)row * nb + b] = acc;
     }
 }
+// The same for batches of at most 8 systems (l >= 8 probe columns at the default width): one thread per (row, probe column)
+// loads every basis entry ONCE and feeds the accumulators of all systems -- in the kernel above the lanes of the nsys systems
+// load the same 16 bytes each (8 x the L1 requests: 2.55 TB/s of unique reads at 1M DoF).
+constexpr int LRS = 8;
+__global__ __launch_bounds__(256) void lincomb_rep8_kernel(const cplx *__restrict__ Q, size_t stride, int nv, const cplx *__restrict__ y,
+                                                           cplx *__restrict__ X, int64_t n, int nb, int l, int nsys, int accumulate) {
+    extern __shared__ cplx hs[];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < nv * nb; k += 256) hs[k] = y[k];
+    __syncthreads();
+    const int R = 256 / l;
+    const int c = tid % l, rl = tid / l;
+    if (rl >= R) return;
+    for (int64_t row = (int64_t)blockIdx.x * R + rl; row < n; row += (int64_t)gridDim.x * R) {
+        const size_t eq = (size_t)row * l + c;
+        cplx acc[LRS];
+#pragma unroll
+        for (int s = 0; s < LRS; ++s) acc[s] = (accumulate && s < nsys) ? X[(size_t)row * nb + s * l + c] : cplx{0.0, 0.0};
+        int i = 0;
+        for (; i + 4 <= nv; i += 4) {
+            cplx v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = Q[(size_t)(i + u) * stride + eq];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int s = 0; s < LRS; ++s)
+                    if (s < nsys) {
+                        const cplx cf = hs[(i + u) * nb + s * l + c];
+                        acc[s].x += cf.x * v[u].x - cf.y * v[u].y;
+                        acc[s].y += cf.x * v[u].y + cf.y * v[u].x;
+                    }
+        }
+        for (; i < nv; ++i) {
+            const cplx v = Q[(size_t)i * stride + eq];
+#pragma unroll
+            for (int s = 0; s < LRS; ++s)
+                if (s < nsys) {
+                    const cplx cf = hs[i * nb + s * l + c];
+                    acc[s].x += cf.x * v.x - cf.y * v.y;
+                    acc[s].y += cf.x * v.y + cf.y * v.x;
+                }
+        }
+#pragma unroll
+        for (int s = 0; s < LRS; ++s)
+            if (s < nsys) X[(size_t)row * nb + s * l + c] = acc[s];
+    }
+}
 void launch_lincomb_rep(const cplx *Q, size_t stride, int nv, const cplx *y, cplx *X, int64_t n, int nb, int l, hipStream_t st) {
     if (!n || nb < 1) return;
     if (nb > 256) throw WaeError(WAE_ERR_INVALID, "lincomb_rep: nb must be in 1..256");
+    if (l >= 4 && l <= 256 && nb % l == 0 && nb / l <= LRS) {
+        const int R = 256 / l, nsys = nb / l;
+        const unsigned grid = (unsigned)std::min<int64_t>((n + R - 1) / R, 4096);
+        const int maxv = std::max(1, AX_MAXC / nb);
+        int done = 0;
+        do {
+            const int chunk = std::min(nv - done, maxv);
+            hipLaunchKernelGGL(lincomb_rep8_kernel, dim3(grid), dim3(256), (size_t)std::max(chunk, 1) * nb * sizeof(cplx), st,
+                               Q + (size_t)done * stride, stride, chunk, y + (size_t)done * nb, X, n, nb, l, nsys, done ? 1 : 0);
+            HIP_CHECK(hipGetLastError());
+            done += chunk;
+        } while (done < nv);
+        return;
+    }
     const int R = 256 / nb;
     const unsigned grid = (unsigned)std::min<int64_t>((n + R - 1) / R, 2048);
     const int maxv = std::max(1, AX_MAXC / nb);
