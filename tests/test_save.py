@@ -39,6 +39,11 @@ def test_julia_literals():
     assert np.isnan(v.real) and np.isnan(v.imag)
     assert parse_julia("UInt32[0x00000001, 0x0000000a]") == [1, 10]
     assert parse_julia("Complex{Float64}[1.0+0.0im,0.5-2.0im,]") == [1 + 0j, 0.5 - 2j]
+    # negative zero: the reference prints "+" whenever imag(v) >= 0, which holds for -0.0 (save.jl:73-78, LinOpFam.jl:283-287),
+    # so negated terms (-M, -Q) and conj'd real vectors routinely produce "+-0.0im"
+    v = parse_julia("1.0+-0.0im")
+    assert v == 1 + 0j and np.signbit(v.imag)
+    assert parse_julia("Complex{Float64}[-1.0+-0.0im,0.0+-2.5im,2.0+0.0im,]") == [-1 + 0j, -2.5j, 2 + 0j]
     assert parse_julia("((:ω,), (:ω, :τ))") == (("ω",), ("ω", "τ"))
     assert parse_julia("()") == ()
     assert parse_julia('"n*exp(-iωτ)"') == "n*exp(-iωτ)"
@@ -189,3 +194,22 @@ def test_binary_container_as_the_julia_writer_lays_it_out(tmp_path):
     assert np.isinf(L.params["λ"].real) and np.isnan(L.params["τ"].real) and L.eigval == "ω"
     assert abs(L.terms[0].coeff - A).max() == 0 and abs(L.terms[1].coeff + 2 * A).max() == 0
     assert L.coefficients(2.0) [0] == 4.0
+
+
+def test_solution_file_with_negative_zero_imaginary_parts_loads(tmp_path):
+    """a Solution file as save.jl:2-20,71-82 writes it for a conj'd real vector: every entry reads ``x+-0.0im``"""
+    txt = """# Solution version 0
+#2021-03-01T10:00:00.000
+params=[(:ω,1700.0 + 35.5im),
+(:λ,0.0 + 0.0im),
+]
+eigval=:ω
+v=[1.0+-0.0im,-2.0+-0.0im,0.5+0.25im,]
+]
+v_adj=[1.0+0.0im,-2.0+0.0im,0.5-0.25im,]
+"""
+    p = tmp_path / "neg0.toml"
+    p.write_text(txt, encoding="utf-8")
+    sol = read_sol(str(p))
+    assert np.array_equal(sol.v, np.array([1, -2, 0.5 + 0.25j])) and np.all(np.signbit(sol.v.imag[:2]))
+    assert np.array_equal(sol.v_adj, np.array([1, -2, 0.5 - 0.25j]))

@@ -102,22 +102,8 @@ struct wae_family {
     DevBuf<cplx> pen_b, pen_x, pen_t;
     cplx *h_pinned = nullptr;        // (restart+2)*NB
     size_t pc_stride_level = 0;      // elements per level in pcdev
-    ~wae_family() {
-        for (auto *b : {&dense_planes, &Ainv, &V, &W, &Z, &Xs, &Bs, &U, &partial, &hdev, &ydev, &pcdev, &one_dev, &io_a, &io_b, &zw_dev, &rbQ, &rb.W, &rb.Vi, &rb.hb, &rb.alpha, &rb.alpha2, &rb.ycoef}) b->release();
-        dstatus.release();
-        plane_col_dev.release();
-        cmask.release();
-        pen_rows.release(); pen_b.release(); pen_x.release(); pen_t.release();
-        pen_op.diag.release();
-        for (auto &G : pen_op.groups) { G.rowptr.release(); G.col.release(); G.rowptr_t.release(); G.col_t.release(); G.vals.release(); G.vals_t.release(); }
-        for (auto &b : lx) b.release();
-        for (auto &b : lb) b.release();
-        for (auto &b : lt) b.release();
-        for (auto &L : ops) {
-            L.diag.release();
-            for (auto &G : L.groups) { G.rowptr.release(); G.col.release(); G.rowptr_t.release(); G.col_t.release(); G.vals.release(); G.vals_t.release(); }
-        }
-        for (auto &X : xfer) { X.p_ptr.release(); X.p_col.release(); X.r_ptr.release(); X.r_col.release(); X.p_val.release(); X.r_val.release(); }
+    ~wae_family() {                  // every DevBuf member frees itself
+        if (stream) (void)hipStreamSynchronize(stream);
         if (h_pinned) (void)hipHostFree(h_pinned);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -1465,7 +1451,6 @@ int wae_beyn_moments(wae_family *h, int32_t npts, const double *z, const double 
         WAE_REQUIRE(h && npts >= 0 && (npts == 0 || (z && w && coeff_table)) && V && l > 0 && K > 0, "bad argument");
         WAE_REQUIRE(A_out || out_dev, "no output buffer");
         require_solver(h);
-        WAE_REQUIRE(l <= h->NB, "l exceeds the solver batch width");
         HIP_CHECK(hipSetDevice(h->device));
         hipStream_t st = h->stream;
         wae_solve_info li;
@@ -1480,25 +1465,29 @@ int wae_beyn_moments(wae_family *h, int32_t npts, const double *z, const double 
         launch_fill_zero(Ad, acnt, st);
         ensure(h->io_a, (size_t)d * l);
         HIP_CHECK(hipMemcpyAsync(h->io_a.p, V, (size_t)d * l * sizeof(cplx), hipMemcpyHostToDevice, st));
-        const int spc = std::max(1, h->NB / l);   // systems per chunk
-        ensure(h->zw_dev, (size_t)2 * spc);
-        int rep_nb = -1;
-        for (int p0 = 0; p0 < npts; p0 += spc) {
-            const int ns = std::min(spc, npts - p0);
-            Batch bt;
-            bt.nb = ns * l; bt.cps = l; bt.nsys = ns; bt.op = WAE_OP_N;
-            std::vector<std::vector<zc>> pcs(ns);
-            std::vector<cplx> zw(2 * ns);
-            for (int s = 0; s < ns; ++s) {
-                plane_coeffs(h, coeff_table + (size_t)(p0 + s) * 2 * h->T, WAE_OP_N, pcs[s]);
-                zw[s] = cplx{w[2 * (p0 + s)], w[2 * (p0 + s) + 1]};
-                zw[ns + s] = cplx{z[2 * (p0 + s)], z[2 * (p0 + s) + 1]};
+        // the reference accepts any l (beyn.jl:39-57): probe columns beyond the batch width are handled in groups of <= NB
+        for (int cg = 0; cg < l; cg += h->NB) {
+            const int lg = std::min(h->NB, l - cg);
+            const int spc = std::max(1, h->NB / lg);   // systems per chunk
+            ensure(h->zw_dev, (size_t)2 * spc);
+            int rep_nb = -1;
+            for (int p0 = 0; p0 < npts; p0 += spc) {
+                const int ns = std::min(spc, npts - p0);
+                Batch bt;
+                bt.nb = ns * lg; bt.cps = lg; bt.nsys = ns; bt.op = WAE_OP_N;
+                std::vector<std::vector<zc>> pcs(ns);
+                std::vector<cplx> zw(2 * ns);
+                for (int s = 0; s < ns; ++s) {
+                    plane_coeffs(h, coeff_table + (size_t)(p0 + s) * 2 * h->T, WAE_OP_N, pcs[s]);
+                    zw[s] = cplx{w[2 * (p0 + s)], w[2 * (p0 + s) + 1]};
+                    zw[ns + s] = cplx{z[2 * (p0 + s)], z[2 * (p0 + s) + 1]};
+                }
+                h->zw_dev.upload(zw.data(), zw.size(), st);
+                HIP_CHECK(hipStreamSynchronize(st));
+                if (bt.nb != rep_nb) { launch_replicate(h->io_a.p + (size_t)cg * d, d, lg, h->Bs.p, bt.nb, st); rep_nb = bt.nb; }   // same right-hand sides for every chunk
+                solve_chunk(h, bt, pcs, h->Bs.p, h->Xs.p, tol, maxit, &li);
+                launch_beyn_accum(h->Xs.p, bt.nb, d, lg, ns, h->zw_dev.p, h->zw_dev.p + ns, npow, Ad, st, l, cg);
             }
-            h->zw_dev.upload(zw.data(), zw.size(), st);
-            HIP_CHECK(hipStreamSynchronize(st));
-            if (bt.nb != rep_nb) { launch_replicate(h->io_a.p, d, l, h->Bs.p, bt.nb, st); rep_nb = bt.nb; }   // same right-hand sides for every chunk
-            solve_chunk(h, bt, pcs, h->Bs.p, h->Xs.p, tol, maxit, &li);
-            launch_beyn_accum(h->Xs.p, bt.nb, d, l, ns, h->zw_dev.p, h->zw_dev.p + ns, npow, Ad, st);
         }
         if (A_out) HIP_CHECK(hipMemcpyAsync(A_out, Ad, acnt * sizeof(cplx), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));

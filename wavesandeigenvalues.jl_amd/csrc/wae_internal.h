@@ -76,10 +76,20 @@ struct OpDev {
     int conj_diag;                  // op = C: use conj(diag) (coefficients arrive already conjugated)
 };
 
-// device buffer with RAII-less explicit free (owned by the family)
+// device buffer: owns its allocation (freed on destruction, so an exception that leaves a C-ABI entry through guarded()
+// releases every function-local buffer); movable, not copyable
 template <class T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
     void alloc(size_t count) {
         release();
         n = count;

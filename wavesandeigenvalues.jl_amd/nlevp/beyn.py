@@ -107,16 +107,32 @@ def compute_moment_matrices(L, G, V=None, l=5, K=1, N=16, points=None, out_dev=0
     idx = spread_order(idx)
     kw = dict(K=K, tol=L.solver_tol, maxit=L.solver_maxit, out_dev=out_dev)
     cap = len(idx) + getattr(L, "rb_extra", 0)              # room for adaptive enrichment (WAE_RB_ENRICH)
-    A0 = fam.beyn_moments_rb(zs[idx], ws[idx], ct[idx], V, 0, cap, **kw)
-    i0 = dict(fam.last_info)
-    # V=None: the probe matrix uploaded by the snapshot call is still on the device
-    A1 = fam.beyn_moments_rb(zs[rest], ws[rest], ct[rest], None, 2, cap, accumulate=bool(out_dev), l_total=np.shape(V)[1], **kw)
-    i1 = fam.last_info
-    fam.last_info = {"iters_max": max(i0["iters_max"], i1["iters_max"]), "iters_total": i0["iters_total"] + i1["iters_total"],
-                     "n_unconverged": i0["n_unconverged"] + i1["n_unconverged"], "levels": i1["levels"],
-                     "relres_max": max(i0["relres_max"], i1["relres_max"]), "seconds": i0["seconds"] + i1["seconds"],
-                     "snapshot_iters": i0["iters_total"], "projected_iters": i1["iters_total"], "snapshots": len(idx)}
-    return None if out_dev else A0 + A1
+    V = np.asarray(V)
+    l = V.shape[1]
+    NB = int(getattr(fam, "batch", 64))
+    infos, A = [], None
+    # the per-column snapshot bases are independent: probe columns beyond the solver's batch width are handled in slices
+    # of <= NB columns (the reference accepts any l, beyn.jl:39-57), each slice = snapshot phase + projected phase
+    for c0 in range(0, l, NB):
+        Vs = V[:, c0:c0 + NB]
+        sl = dict(l_total=l, col0=c0) if l > NB else {}
+        A0 = fam.beyn_moments_rb(zs[idx], ws[idx], ct[idx], Vs, 0, cap, accumulate=bool(out_dev) and c0 > 0, **sl, **kw)
+        i0 = dict(fam.last_info)
+        if l > NB:
+            A1 = fam.beyn_moments_rb(zs[rest], ws[rest], ct[rest], Vs, 2, cap, accumulate=bool(out_dev), **sl, **kw)
+        else:   # V=None: the probe matrix uploaded by the snapshot call is still on the device
+            A1 = fam.beyn_moments_rb(zs[rest], ws[rest], ct[rest], None, 2, cap, accumulate=bool(out_dev), l_total=l, **kw)
+        infos.append((i0, dict(fam.last_info)))
+        if not out_dev:
+            A = A0 + A1 if A is None else A + A0 + A1
+    fam.last_info = {"iters_max": max(max(a["iters_max"], b["iters_max"]) for a, b in infos),
+                     "iters_total": sum(a["iters_total"] + b["iters_total"] for a, b in infos),
+                     "n_unconverged": sum(a["n_unconverged"] + b["n_unconverged"] for a, b in infos), "levels": infos[-1][1]["levels"],
+                     "relres_max": max(max(a["relres_max"], b["relres_max"]) for a, b in infos),
+                     "seconds": sum(a["seconds"] + b["seconds"] for a, b in infos),
+                     "snapshot_iters": sum(a["iters_total"] for a, _ in infos), "projected_iters": sum(b["iters_total"] for _, b in infos),
+                     "snapshots": len(idx)}
+    return None if out_dev else A
 
 
 def moments2eigs(A_list, tol_sigma=0.0, return_sigma=False):

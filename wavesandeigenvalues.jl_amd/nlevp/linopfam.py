@@ -73,8 +73,18 @@ class Solution:
         return eigval, polyval(list(A), de) / polyval(list(B), de)
 
 
+class UnconvergedWarning(RuntimeWarning):
+    """an inner multigrid-GMRES solve stopped at its iteration limit or stagnated above the requested tolerance"""
+
+
 class DeviceFamily:
-    """Owner of a ``wae_family`` handle: all term matrices resident in HBM (include/waehip.h)."""
+    """Owner of a ``wae_family`` handle: all term matrices resident in HBM (include/waehip.h).
+
+    ``strict`` (default True): the reference's ``\\`` is a direct LU that either solves or throws, so an inner solve that
+    did not reach its tolerance must not pass silently.  Contour integrals (``beyn_moments*``) raise ``WaeError`` -- a
+    stalled quadrature point corrupts every eigenpair; single solves, Arnoldi processes and the perturbation recurrence
+    emit an ``UnconvergedWarning`` (the Newton-type solvers run them on numerically singular operators by design and
+    judge the outcome themselves: they pass ``quiet=True``).  ``strict=False`` restores the silent behaviour."""
 
     def __init__(self, mats, device=0):
         lib = _lib.lib()
@@ -97,6 +107,23 @@ class DeviceFamily:
         self.device = device
         self.solver_ready = False
         self.last_info = None
+        self.last_code = 0
+        self.strict = True
+
+    def _report(self, code, info, what, fatal=False, quiet=False):
+        """record the outcome of a library call that solved linear systems; see the class docstring"""
+        self.last_info = info.as_dict() if hasattr(info, "as_dict") else dict(info)
+        self.last_code = code
+        n = self.last_info.get("n_unconverged", 0)
+        if n > 0 and self.strict and not quiet:
+            msg = (f"{what}: {n} inner solve(s) did not reach the tolerance (largest relative residual "
+                   f"{self.last_info.get('relres_max', float('nan')):.2e}, "
+                   f"{'stagnation' if code == _lib.WAE_WARN_STAGNATION else 'iteration limit'})")
+            if fatal:
+                raise _lib.WaeError(code, msg)
+            import warnings
+            warnings.warn(msg, UnconvergedWarning, stacklevel=3)
+        return code
 
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle:
@@ -148,7 +175,7 @@ class DeviceFamily:
         self.solver_ready = True
         self.batch = batch
 
-    def solve(self, coeffs, B, op=OP_N, tol=1e-12, maxit=300, strict=False, guess=None):
+    def solve(self, coeffs, B, op=OP_N, tol=1e-12, maxit=300, strict=False, guess=None, quiet=False):
         c = np.ascontiguousarray(coeffs, dtype=np.complex128)
         B = np.asarray(B, dtype=np.complex128)
         one = B.ndim == 1
@@ -165,8 +192,7 @@ class DeviceFamily:
             assert Gf.shape == Bf.shape
             code = check(_lib.lib().wae_solve_guess(self.handle, zptr(c), ncoef, zptr(Bf), zptr(Gf), zptr(X), r, op, tol, maxit,
                                                     C.byref(info)), warn_ok=not strict)
-        self.last_info = info.as_dict()
-        self.last_code = code
+        self._report(code, info, "solve", quiet=quiet)
         return X[:, 0].copy() if one else X
 
     def beyn_moments(self, z, w, coeff_table, V, K=1, tol=1e-10, maxit=300, out_dev=0):
@@ -183,8 +209,7 @@ class DeviceFamily:
             aptr = zptr(A)
         code = check(_lib.lib().wae_beyn_moments(self.handle, len(z), zptr(z), zptr(w), zptr(ct), zptr(Vf), l, K, tol, maxit,
                                                  aptr, int(out_dev), C.byref(info)))
-        self.last_info = info.as_dict()
-        self.last_code = code
+        self._report(code, info, "beyn_moments", fatal=True)
         return A
 
     def beyn_moments_rb(self, z, w, coeff_table, V, mode, nbasis, slot0=0, Q_dev=0, K=1, tol=1e-10, maxit=300, out_dev=0,
@@ -209,8 +234,7 @@ class DeviceFamily:
         code = check(_lib.lib().wae_beyn_moments_rb(self.handle, len(z), zptr(z), zptr(w), zptr(ct), None if Vf is None else zptr(Vf), l, K, tol, maxit,
                                                     int(mode), int(nbasis), int(slot0), int(Q_dev), aptr, int(out_dev),
                                                     1 if accumulate else 0, int(l_total), int(col0), C.byref(info)))
-        self.last_info = info.as_dict()
-        self.last_code = code
+        self._report(code, info, "beyn_moments_rb", fatal=True)
         return A
 
     def rb_export(self):
@@ -244,7 +268,7 @@ class DeviceFamily:
                                            out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
 
-    def arnoldi(self, coeffsA, coeffsM, m, v0, op=OP_N, tol=1e-12, maxit=300):
+    def arnoldi(self, coeffsA, coeffsM, m, v0, op=OP_N, tol=1e-12, maxit=300, quiet=False):
         cA = np.ascontiguousarray(coeffsA, dtype=np.complex128)
         cM = np.ascontiguousarray(coeffsM, dtype=np.complex128)
         v0 = np.ascontiguousarray(v0, dtype=np.complex128)
@@ -253,11 +277,10 @@ class DeviceFamily:
         info = SolveInfo()
         code = check(_lib.lib().wae_arnoldi_shiftinvert(self.handle, zptr(cA), zptr(cM), m, zptr(v0), op, tol, maxit, zptr(H), zptr(V),
                                                         C.byref(info)))
-        self.last_info = info.as_dict()
-        self.last_code = code
+        self._report(code, info, "arnoldi", quiet=quiet)
         return H, V
 
-    def arnoldi_batch(self, coeffsA, coeffsM, m, V0, op=OP_N, tol=1e-12, maxit=300, ritz_tol=0.0):
+    def arnoldi_batch(self, coeffsA, coeffsM, m, V0, op=OP_N, tol=1e-12, maxit=300, ritz_tol=0.0, quiet=False):
         """wae_arnoldi_shiftinvert_batch: nsys Arnoldi processes in lock-step.  coeffsA, coeffsM: (nsys, T); V0: (d, nsys).
         Returns H (nsys, m+1, m) and V (nsys, d, m+1)."""
         cA = np.ascontiguousarray(coeffsA, dtype=np.complex128).reshape(-1, self.T)
@@ -269,11 +292,10 @@ class DeviceFamily:
         info = SolveInfo()
         code = check(_lib.lib().wae_arnoldi_shiftinvert_batch(self.handle, nsys, zptr(cA), zptr(cM), m, zptr(V0), op, tol, maxit,
                                                               float(ritz_tol), zptr(H), zptr(V), C.byref(info)))
-        self.last_info = info.as_dict()
-        self.last_code = code
+        self._report(code, info, "arnoldi_batch", quiet=quiet)
         return H.transpose(0, 2, 1), V.transpose(0, 2, 1)
 
-    def perturb(self, coeff_table, N, v0, v0adj, norm_mode=1, coeffsY=None, tol=1e-12, maxit=400):
+    def perturb(self, coeff_table, N, v0, v0adj, norm_mode=1, coeffsY=None, tol=1e-12, maxit=400, quiet=False):
         """wae_perturb: the whole recurrence on the device. coeff_table[(m,n)] = T coefficients of L(m,n)."""
         ct = np.ascontiguousarray(coeff_table, dtype=np.complex128).reshape((N + 1) * (N + 1), self.T)
         v0 = np.ascontiguousarray(v0, dtype=np.complex128)
@@ -284,8 +306,7 @@ class DeviceFamily:
         info = SolveInfo()
         code = check(_lib.lib().wae_perturb(self.handle, zptr(ct), N, zptr(v0), zptr(va), norm_mode, None if cy is None else zptr(cy),
                                             tol, maxit, zptr(lam), zptr(V), C.byref(info)))
-        self.last_info = info.as_dict()
-        self.last_code = code
+        self._report(code, info, f"perturb (order {N})", quiet=quiet)
         return lam, V
 
     def bench_spmv(self, coeffs, r=1, reps=20):
@@ -315,14 +336,14 @@ class Operator:
 
     dot = __matmul__
 
-    def solve(self, b, tol=None, maxit=None, guess=None):
+    def solve(self, b, tol=None, maxit=None, guess=None, quiet=False):
         """Julia ``A \\ b`` (beyn.jl:65; iterative_solvers.jl:307,397-398)"""
         own = self.owner
         if own is not None:
             own.ensure_solver()
         tol = tol if tol is not None else (own.solver_tol if own is not None else 1e-12)
         maxit = maxit if maxit is not None else (own.solver_maxit if own is not None else 300)
-        return self.fam.solve(self.coeffs, b, self.op, tol, maxit, guess=guess)
+        return self.fam.solve(self.coeffs, b, self.op, tol, maxit, guess=guess, quiet=quiet)
 
     def __neg__(self):
         return Operator(self.fam, -self.coeffs, self.op, self.owner)

@@ -84,10 +84,10 @@ def eigs(A, M, nev=1, v0=None, ncv=None, tol=1e-12, maxiter=300, sigma=0.0, retu
     while total < maxiter:
         if nev == 1:
             # one wanted pair: the device stops the factorisation as soon as its Ritz residual is below tol
-            Hb, Vb = fam.arnoldi_batch(cA[None, :], cM, step, v[:, None], op=A.op, tol=stol, maxit=smax, ritz_tol=tol)
+            Hb, Vb = fam.arnoldi_batch(cA[None, :], cM, step, v[:, None], op=A.op, tol=stol, maxit=smax, ritz_tol=tol, quiet=True)
             H, V = Hb[0], Vb[0]
         else:
-            H, V = fam.arnoldi(cA, cM, step, v, op=A.op, tol=stol, maxit=smax)
+            H, V = fam.arnoldi(cA, cM, step, v, op=A.op, tol=stol, maxit=smax, quiet=True)
         total += step
         # inner solves that did not even reach 1e-4 (far outside the range the multigrid hierarchy was built for, or
         # beyond what the mesh resolves) cannot produce Ritz pairs: give up like ARPACK does instead of restarting
@@ -349,7 +349,7 @@ def inveriter(L, z, maxiter=10, tol=0.0, relax=1.0, x0=None, v=None, output=Fals
             if output:
                 print(n, "\t\t", abs(z - z0), "\t", z)
             z0 = z
-            u = L(z, 0).solve(L(z, 1) @ x0, guess=x0)        # the solution is x0/(ω*-z) to first order
+            u = L(z, 0).solve(L(z, 1) @ x0, guess=x0, quiet=True)        # the solution is x0/(ω*-z) to first order
             z = z0 - np.vdot(v, x0) / np.vdot(v, u)
             x0 = u / np.vdot(v, u)
             n += 1
@@ -372,8 +372,8 @@ def lancaster(L, z, maxiter=10, tol=0.0, relax=1.0, x0=None, y0=None, output=Fal
         while abs(z - z0) > tol and n < maxiter:
             z0 = z
             A = L(z)
-            xi = A.solve(x0)
-            eta = A.H.solve(y0)
+            xi = A.solve(x0, quiet=True)          # (numerically singular by design close to convergence: direction matters)
+            eta = A.H.solve(y0, quiet=True)
             z = z0 - np.vdot(eta, L(z, 0) @ xi) / np.vdot(eta, L(z, 1) @ xi)
             n += 1
     except WaeError:
@@ -400,8 +400,8 @@ def rf2s(L, z, maxiter=10, tol=0.0, relax=1.0, x0=None, y0=None, output=False):
             z0 = z
             A = L(z)
             L1 = L(z, 1)
-            x0 = A.solve(L1 @ x0, guess=x0)
-            y0 = A.H.solve(L1.H @ y0, guess=y0)
+            x0 = A.solve(L1 @ x0, guess=x0, quiet=True)
+            y0 = A.H.solve(L1.H @ y0, guess=y0, quiet=True)
             x0 = x0 / np.sqrt(np.vdot(x0, x0)); y0 = y0 / np.sqrt(np.vdot(y0, y0))
             idx = 0
             z00 = complex(np.inf)
@@ -471,7 +471,7 @@ def eigs_many(fam, cA, cM, v0s, op, sigmas, nev=1, tol=1e-12, maxiter=300, stol=
     total = 0
     while pending and total < maxiter:
         H, V = fam.arnoldi_batch(cAs[pending], cM, step, V0[:, pending], op=op, tol=stol, maxit=smax,
-                                 ritz_tol=tol if nev == 1 else 0.0)
+                                 ritz_tol=tol if nev == 1 else 0.0, quiet=True)
         total += step
         failed = fam.last_info["n_unconverged"] > 0 and fam.last_info["relres_max"] > 1e-4
         still = []

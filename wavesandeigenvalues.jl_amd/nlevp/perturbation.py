@@ -90,7 +90,7 @@ def _recurrence(L, N, v0, v0Adj, normalize, Y=None, skip_last_solve=False):
             table[m, n] = L.coefficients(m, n)
     mode = (2 if Y is not None else (1 if normalize else 0)) + (16 if skip_last_solve else 0)
     lam, V = fam.perturb(table, N, v0, v0Adj, norm_mode=mode, coeffsY=None if Y is None else Y.coeffs,
-                         tol=L.solver_tol, maxit=L.solver_maxit)
+                         tol=L.solver_tol, maxit=L.solver_maxit, quiet=skip_last_solve)   # (inside a Newton step: the caller judges)
     return lam, [V[:, i].copy() for i in range(N + 1)]
 
 

@@ -91,7 +91,7 @@ class Call(tuple):
     """(name, args) of a constructor call in a file"""
 
 
-_REAL = re.compile(r"[+-]?\s*(?:0x[0-9a-fA-F]+|Inf|NaN|(?:\d+\.?\d*|\.\d+)(?:[eE][+-]?\d+)?)")
+_REAL = re.compile(r"[+-]?\s*[+-]?\s*(?:0x[0-9a-fA-F]+|Inf|NaN|(?:\d+\.?\d*|\.\d+)(?:[eE][+-]?\d+)?)")
 _IDENT = re.compile(r"[^\W\d][\w!]*", re.UNICODE)
 
 
@@ -133,8 +133,10 @@ class _Parser:
                 break
             tok = m.group(0).replace(" ", "")
             j = m.end()
-            sign = -1.0 if tok.startswith("-") else 1.0
             body = tok.lstrip("+-")
+            # the reference's writers print ``$(real)+$(imag)im`` whenever imag(v) >= 0, which is true for -0.0 as well
+            # (save.jl:73-78, LinOpFam.jl:283-287): "1.0+-0.0im" -- a binary sign followed by the number's own sign
+            sign = -1.0 if tok[:len(tok) - len(body)].count("-") % 2 else 1.0
             if body.startswith("0x"):
                 val = float(int(body, 16))
             elif body == "Inf":
@@ -148,7 +150,7 @@ class _Parser:
             if self.s.startswith("*", k):
                 k += 1
             if self.s.startswith("im", k) and not (k + 2 < len(self.s) and (self.s[k + 2].isalnum() or self.s[k + 2] == "_")):
-                total_im += sign * val
+                total_im = sign * val if not is_c else total_im + sign * val     # (keeps the sign of a lone -0.0)
                 is_c = True
                 j = k + 2
             else:
