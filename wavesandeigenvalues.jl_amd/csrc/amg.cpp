@@ -5,6 +5,8 @@
 #include <numeric>
 
 #include "amg.h"
+#include <chrono>
+#include <cstdlib>
 #include <future>
 
 template <class V> static void transpose_impl(int64_t n, int64_t m, const std::vector<int> &ptr, const std::vector<int> &col,
@@ -261,7 +263,12 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
 void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, const AmgOptions &opt, std::vector<AmgLevel> &levels,
                std::vector<char> *penalty_rows, const std::vector<zc> *pc_shape) {
     levels.clear();
+    const bool dbg = getenv("WAE_SETUP_DEBUG") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tq = now();
+    auto lap = [&](const char *what) { if (dbg) { const double t = now(); fprintf(stderr, "[amg] %-28s %.3f s\n", what, t - tq); tq = t; } };
     const CsrZ Afull = csr_lincomb(planes, pc_ref);
+    lap("lincomb");
     const CsrZ Ashape = pc_shape ? csr_lincomb(planes, *pc_shape) : CsrZ();
     const CsrZ &Aref = pc_shape ? Ashape : Afull;          // the shape matrix comes from here, the penalty test from Afull
     const int64_t n0 = Afull.n;
@@ -306,10 +313,12 @@ void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, c
         for (int64_t i = 0; i < n0; ++i) skip[i] = dabs[i] > opt.penalty_ratio * med;
     }
     if (penalty_rows) *penalty_rows = skip;
+    lap("shape matrix + penalty rows");
     std::vector<CsrZ> cur(planes);
     int64_t n = n0;
     while (n > opt.max_coarse && (int)levels.size() < opt.max_levels) {
         CsrD P = build_prolongator(S, skip, opt.theta, true);
+        lap("prolongator");
         if (P.m >= (int64_t)(0.9 * n) || P.m == 0) break;
         CsrD R = csr_transpose(P);
         AmgLevel L;
@@ -324,6 +333,7 @@ void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, c
             for (auto &j : jobs) j.get();
             S = std::move(Snext);
         }
+        lap("galerkin products");
         L.coarse_planes = next;
         levels.push_back(std::move(L));
         n = S.n;

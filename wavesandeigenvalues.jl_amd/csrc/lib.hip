@@ -1264,8 +1264,11 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
                 if (excl >> k & 1) cs[2 * k] = cs[2 * k + 1] = 0.0;
             plane_coeffs(h, cs.data(), WAE_OP_N, pc_shape);
         }
+        const double t_amg0 = now_s();
         amg_setup(h->planes0, pc, ao, lv, &pen, excl ? &pc_shape : nullptr);
+        const double t_amg1 = now_s();
         if (getenv("WAE_SETUP_DEBUG")) {
+            fprintf(stderr, "[setup] amg_setup (host) %.3f s\n", t_amg1 - t_amg0);
             fprintf(stderr, "[setup] level 0: n=%lld nnz/plane:", (long long)h->planes0[0].n);
             for (const CsrZ &A : h->planes0) fprintf(stderr, " %lld", (long long)A.nnz());
             fprintf(stderr, "\n");
@@ -1377,6 +1380,7 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
         if (h->h_pinned) { (void)hipHostFree(h->h_pinned); h->h_pinned = nullptr; }
         HIP_CHECK(hipHostMalloc((void **)&h->h_pinned, (size_t)(m + 2) * NB * sizeof(cplx)));
         h->solver_ready = true;
+        if (getenv("WAE_SETUP_DEBUG")) fprintf(stderr, "[setup] uploads + workspaces %.3f s\n", now_s() - t_amg1);
         return WAE_OK;
     });
 }
