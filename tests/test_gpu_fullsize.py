@@ -232,7 +232,11 @@ def test_c5_adjoint_perturbation_order_30_half_million_dof():
     fam = L.ensure_solver()
     sol, n, flag = householder(L, 2 * np.pi * (195 + 9j), maxiter=12, tol=1e-11)
     w0 = sol.params["ω"]
-    assert flag in (0, 1) and n <= 10 and 150 < w0.real / 2 / np.pi < 250
+    # tol = 1e-11 is an ABSOLUTE step size (Householder.jl:94), 8e-15 of |ω| here: whether the last iterates dip below it is
+    # rounding noise (flag -1 = the iteration limit), so the convergence history is pinned instead of the final count
+    assert flag in (-1, 0, 1) and 150 < w0.real / 2 / np.pi < 250
+    first = next(i for i, zk in enumerate(sol.history) if abs(zk - w0) < 1e-12 * abs(w0))
+    assert first <= 8, sol.history
     perturb_fast_(sol, L, "τ", 30)
     info = dict(fam.last_info)
     assert info["n_unconverged"] == 0

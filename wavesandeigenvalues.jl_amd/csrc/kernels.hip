@@ -342,6 +342,183 @@ __global__ __launch_bounds__(256, 4) void spmv_lds_kernel(OpDev op, const cplx *
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Tile kernel for batch widths >= 8 on a reordered fine-level operator (tiles.h).
+//
+// One workgroup = one tile (<= 256 consecutive rows forming a compact brick of the mesh graph) x one chunk of 8 batch
+// columns.  Phase 1 loads the tile's window -- the ~2x256 distinct X rows its rows touch, 128 B each for this chunk --
+// into LDS, coalesced, ONCE; phase 2 is lane = row: every lane walks its own row in the tile-local storage (entries of a
+// 64-row slice interleaved so that the loads of a wavefront are contiguous; 16-bit window positions) and reads its
+// operands from LDS; phase 3 transposes the 256 x 8 results through LDS so that B / Y are touched as 128-B row segments.
+// Against spmv_lds_kernel: ~2 window rows loaded per matrix row instead of ~15 gathered (L2 -> L1 traffic / 7), no
+// cross-lane traffic for the matrix entries, one coefficient product per nonzero instead of one per nonzero and column.
+// LDS reads: lane l reads the columns in the rotated order (s + l) mod 8, s = 0..7, so that the 16 lanes a ds_read_b128
+// serves per cycle spread over all bank groups (two lanes share a group only if their window rows have equal parity).
+// UNI: the 8 columns of a chunk belong to one system (columns per system a multiple of 8): one coefficient set per chunk.
+// ---------------------------------------------------------------------------------------------------
+template <bool UNI>
+__global__ __launch_bounds__(256, 2) void spmv_tile_kernel(OpDev op, TileDev td, const cplx *__restrict__ pc, int cps,
+                                                          const cplx *__restrict__ X, cplx *Y, const cplx *B, double jac_w,
+                                                          int nb, int mode, const unsigned char *__restrict__ cmask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
+    const int tid = threadIdx.x;
+    const int nch = (nb + 7) >> 3;
+    const int tpx = (td.ntiles + 7) >> 3;                   // tiles per XCD: workgroup ids are dealt round-robin over the 8 XCDs, so
+    const int jx = blockIdx.x >> 3;                         // XCD k takes the k-th contiguous eighth of the tiles and runs the
+    const int tl = jx / nch, ch = jx - tl * nch;            // column chunks of a tile back to back (its matrix tile stays in that L2)
+    const int tile = (int)(blockIdx.x & 7u) * tpx + tl;
+    if (tile >= td.ntiles) return;
+    if (cmask && !cmask[ch]) return;
+    const int npl = op.nplanes_total;
+    cplx *win = (cplx *)tile_smem;                          // [window slot][8 columns]
+    cplx *spc = win + (size_t)(td.wmax > 256 ? td.wmax : 256) * 8;   // [8][npl] coefficients of the chunk's columns
+    const int col0 = ch * 8;
+    for (int i = tid; i < 8 * npl; i += 256) {
+        const int cc = i / npl, q = i - cc * npl;
+        int bb = col0 + cc;
+        if (bb >= nb) bb = nb - 1;
+        spc[i] = pc[(size_t)(bb / cps) * npl + q];
+    }
+    {   // phase 1: window -> LDS (thread = (window slot, column); 8 lanes fetch one 128-B segment of an X row)
+        const int w0 = td.win_ptr[tile], W = td.win_ptr[tile + 1] - w0;
+        const int c = tid & 7;
+        int bc = col0 + c;
+        if (bc >= nb) bc = nb - 1;
+        const cplx *Xc = X + bc;
+        const int *wl = td.win_cols + w0;
+        constexpr int U = 4;
+        for (int i0 = tid >> 3; i0 < W; i0 += 32 * U) {
+            int gr[U];
+            cplx x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int i = i0 + 32 * u; gr[u] = wl[i < W ? i : W - 1]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = Xc[(size_t)gr[u] * nb];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int i = i0 + 32 * u; if (i < W) win[i * 8 + c] = x[u]; }
+        }
+    }
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+    const int rot = lane & 7;
+    cplx acc[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc[s] = cplx{0.0, 0.0};
+#pragma unroll 1
+    for (int g = 0; g < op.ngroups; ++g) {
+        const TileGroupDev TG = td.g[g];
+        const int s0 = TG.sptr[tile * 4 + wv], s1 = TG.sptr[tile * 4 + wv + 1];
+        if (s0 == s1) continue;                              // (uniform per wavefront)
+        const GroupDev G = op.g[g];
+        const int np = G.nplanes;
+        if (G.is_real && np == 2) {                          // the hot case: mass + stiffness on one pattern, 16 B + 2 B per nonzero
+            const double2 *__restrict__ v2 = (const double2 *)TG.svals;
+            const unsigned short *__restrict__ si = TG.sidx;
+            cplx c0 = spc[G.plane0], c1 = spc[G.plane0 + 1];
+            int e = s0 + lane;
+            unsigned ix = si[e];
+            double2 a = v2[e];
+            for (; e < s1; e += 64) {
+                const int en = e + 64 < s1 ? e + 64 : e;     // next entry of this lane (prefetched)
+                const unsigned ixn = si[en];
+                const double2 an = v2[en];
+                const cplx *wr = win + ix * 8;
+                cplx m = {fma(c0.x, a.x, c1.x * a.y), fma(c0.y, a.x, c1.y * a.y)};
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const int cs = (s + rot) & 7;
+                    if (!UNI) {
+                        c0 = spc[cs * npl + G.plane0]; c1 = spc[cs * npl + G.plane0 + 1];
+                        m = cplx{fma(c0.x, a.x, c1.x * a.y), fma(c0.y, a.x, c1.y * a.y)};
+                    }
+                    cfma(acc[s], m, wr[cs]);
+                }
+                ix = ixn; a = an;
+            }
+        } else {
+            const double *__restrict__ vr = (const double *)TG.svals;
+            const cplx *__restrict__ vc = (const cplx *)TG.svals;
+            const double sg = G.conj_vals ? -1.0 : 1.0;
+            for (int e = s0 + lane; e < s1; e += 64) {
+                const cplx *wr = win + (unsigned)TG.sidx[e] * 8;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const int cs = (s + rot) & 7;
+                    const cplx *gpc = spc + (UNI ? 0 : cs * npl) + G.plane0;
+                    cplx m = {0.0, 0.0};
+                    if (G.is_real) {
+                        for (int q = 0; q < np; ++q) { const double av = vr[(size_t)e * np + q]; m.x = fma(gpc[q].x, av, m.x); m.y = fma(gpc[q].y, av, m.y); }
+                    } else {
+                        for (int q = 0; q < np; ++q) { cplx av = vc[(size_t)e * np + q]; av.y *= sg; cfma(m, gpc[q], av); }
+                    }
+                    cfma(acc[s], m, wr[cs]);
+                }
+            }
+        }
+    }
+    __syncthreads();                                         // every wavefront is done with the window: reuse it as the staging tile
+#pragma unroll
+    for (int s = 0; s < 8; ++s) win[tid * 8 + ((s + rot) & 7)] = acc[s];
+    __syncthreads();
+    // phase 3: thread = (row, column) -> 8 lanes write one 128-B row segment
+    const int r0 = td.row_ptr[tile], nrows = td.row_ptr[tile + 1] - r0;
+    const int c = tid & 7;
+    const int b = col0 + c;
+    if (b >= nb) return;
+    const cplx *mypc = spc + c * npl;
+    for (int rr = tid >> 3; rr < nrows; rr += 32) {
+        const cplx av = win[rr * 8 + c];
+        const int64_t row = r0 + rr;
+        const size_t e = (size_t)row * nb + b;
+        cplx out;
+        if (mode == MODE_AX) {
+            out = av;
+        } else if (mode == MODE_RES) {
+            const cplx bv = B[e];
+            out = cplx{bv.x - av.x, bv.y - av.y};
+        } else if (mode == MODE_ADD) {
+            const cplx bv = B[e];
+            out = cplx{bv.x + av.x, bv.y + av.y};
+        } else {
+            cplx dg = {0.0, 0.0};
+            const double dsg = op.conj_diag ? -1.0 : 1.0;
+            for (int q = 0; q < npl; ++q) { cplx dq = op.diag[(size_t)row * npl + q]; dq.y *= dsg; cfma(dg, mypc[q], dq); }
+            if (mode == MODE_AX_J0) {
+                out = av;
+                const cplx r = cdiv(av, dg);
+                const_cast<cplx *>(B)[e] = cplx{jac_w * r.x, jac_w * r.y};
+            } else if (mode == MODE_AX_DS) {
+                out = cdiv(av, dg);
+            } else if (mode == MODE_RES_DS) {
+                const cplx bv = B[e];
+                out = cdiv(cplx{bv.x - av.x, bv.y - av.y}, dg);
+            } else {
+                const cplx bv = B[e], xv = X[e];
+                const cplx r = cdiv(cplx{bv.x - av.x, bv.y - av.y}, dg);
+                out = cplx{xv.x + jac_w * r.x, xv.y + jac_w * r.y};
+            }
+        }
+        Y[e] = out;
+    }
+}
+
+static void launch_spmv_tile(const OpDev &op, const TileDev &td, const cplx *pc, int cps, const cplx *X, cplx *Y, const cplx *B, double jac_w,
+                             int nb, int mode, hipStream_t st, const unsigned char *cmask) {
+    static bool attr_set = false;
+    const size_t shm = (size_t)(td.wmax > 256 ? td.wmax : 256) * 8 * sizeof(cplx) + (size_t)8 * op.nplanes_total * sizeof(cplx);
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        attr_set = true;
+    }
+    const int nch = (nb + 7) / 8;
+    const unsigned tpx = (unsigned)((td.ntiles + 7) / 8);
+    const dim3 grid(8u * tpx * (unsigned)nch);
+    if (cps % 8 == 0) hipLaunchKernelGGL(spmv_tile_kernel<true>, grid, dim3(256), shm, st, op, td, pc, cps, X, Y, B, jac_w, nb, mode, cmask);
+    else hipLaunchKernelGGL(spmv_tile_kernel<false>, grid, dim3(256), shm, st, op, td, pc, cps, X, Y, B, jac_w, nb, mode, cmask);
+    HIP_CHECK(hipGetLastError());
+}
+
 typedef void (*spmv_fn)(OpDev, const cplx *, int, const cplx *, cplx *, const cplx *, double, int, int, const unsigned char *);
 template <int C, int S> static spmv_fn spmv_ptr() { return spmv_kernel<C, S>; }
 
@@ -373,6 +550,10 @@ void launch_spmv(const OpDev &op, const cplx *pc, int cps, const cplx *X, cplx *
     if (envC > 0 && envC <= nb) C = envC;
     if (envS > 0) S = envS;
     if (op.n <= 0) return;
+    if (op.tiles && nb >= 8 && envC == 0 && envS == 0 && env_int("WAE_SPMV_TILE", 1)) {
+        launch_spmv_tile(op, *op.tiles, pc, cps, X, Y, B, jac_w, nb, mode, st, cmask);
+        return;
+    }
     if (mode == MODE_AX_J0 && !(C == 8 && S == 1 && env_int("WAE_SPMV_LDS", 1))) {   // only the wide fine-level kernel fuses the sweep
         launch_spmv(op, pc, cps, X, Y, nullptr, 0.0, nb, MODE_AX, st, cmask);
         launch_jacobi0(op, pc, cps, Y, const_cast<cplx *>(B), jac_w, nb, st, cmask);
@@ -1188,40 +1369,48 @@ void launch_scale_inv(const cplx *X, const cplx *alpha, cplx *Y, int64_t n, int 
     HIP_CHECK(hipGetLastError());
 }
 
-__global__ __launch_bounds__(256) void colmajor_to_inter_kernel(const cplx *__restrict__ Xc, int64_t d, int r, cplx *__restrict__ Xi, int nb) {
+// The column-major side of these three is in the CALLER's row numbering, the interleaved side in the library's (tiles.h):
+// perm[i] = caller's row of internal row i (null: same numbering).
+__global__ __launch_bounds__(256) void colmajor_to_inter_kernel(const cplx *__restrict__ Xc, int64_t d, int r, cplx *__restrict__ Xi, int nb,
+                                                                const int *__restrict__ perm) {
     const size_t total = (size_t)d * nb;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const size_t row = e / nb;
         const int b = (int)(e - row * nb);
-        Xi[e] = (b < r) ? Xc[(size_t)b * d + row] : cplx{0.0, 0.0};
+        const size_t src = perm ? (size_t)perm[row] : row;
+        Xi[e] = (b < r) ? Xc[(size_t)b * d + src] : cplx{0.0, 0.0};
     }
 }
-void launch_colmajor_to_inter(const cplx *Xc, int64_t d, int r, cplx *Xi, int nb, hipStream_t st) {
-    hipLaunchKernelGGL(colmajor_to_inter_kernel, dim3(grid_for((size_t)d * nb)), dim3(256), 0, st, Xc, d, r, Xi, nb);
+void launch_colmajor_to_inter(const cplx *Xc, int64_t d, int r, cplx *Xi, int nb, hipStream_t st, const int *perm) {
+    hipLaunchKernelGGL(colmajor_to_inter_kernel, dim3(grid_for((size_t)d * nb)), dim3(256), 0, st, Xc, d, r, Xi, nb, perm);
     HIP_CHECK(hipGetLastError());
 }
-__global__ __launch_bounds__(256) void inter_to_colmajor_kernel(const cplx *__restrict__ Xi, int nb, int64_t d, int r, cplx *__restrict__ Xc) {
+__global__ __launch_bounds__(256) void inter_to_colmajor_kernel(const cplx *__restrict__ Xi, int nb, int64_t d, int r, cplx *__restrict__ Xc,
+                                                                const int *__restrict__ perm) {
     const size_t total = (size_t)d * r;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const size_t b = e / d, row = e - b * d;
-        Xc[e] = Xi[row * nb + b];
+        const size_t dst = perm ? (size_t)perm[row] : row;
+        Xc[b * d + dst] = Xi[row * nb + b];
     }
 }
-void launch_inter_to_colmajor(const cplx *Xi, int nb, int64_t d, int r, cplx *Xc, hipStream_t st) {
+void launch_inter_to_colmajor(const cplx *Xi, int nb, int64_t d, int r, cplx *Xc, hipStream_t st, const int *perm) {
     if (!d || !r) return;
-    hipLaunchKernelGGL(inter_to_colmajor_kernel, dim3(grid_for((size_t)d * r)), dim3(256), 0, st, Xi, nb, d, r, Xc);
+    hipLaunchKernelGGL(inter_to_colmajor_kernel, dim3(grid_for((size_t)d * r)), dim3(256), 0, st, Xi, nb, d, r, Xc, perm);
     HIP_CHECK(hipGetLastError());
 }
-__global__ __launch_bounds__(256) void replicate_kernel(const cplx *__restrict__ Vc, int64_t d, int l, cplx *__restrict__ Xi, int nb) {
+__global__ __launch_bounds__(256) void replicate_kernel(const cplx *__restrict__ Vc, int64_t d, int l, cplx *__restrict__ Xi, int nb,
+                                                        const int *__restrict__ perm) {
     const size_t total = (size_t)d * nb;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const size_t row = e / nb;
         const int b = (int)(e - row * nb);
-        Xi[e] = Vc[(size_t)(b % l) * d + row];
+        const size_t src = perm ? (size_t)perm[row] : row;
+        Xi[e] = Vc[(size_t)(b % l) * d + src];
     }
 }
-void launch_replicate(const cplx *Vc, int64_t d, int l, cplx *Xi, int nb, hipStream_t st) {
-    hipLaunchKernelGGL(replicate_kernel, dim3(grid_for((size_t)d * nb)), dim3(256), 0, st, Vc, d, l, Xi, nb);
+void launch_replicate(const cplx *Vc, int64_t d, int l, cplx *Xi, int nb, hipStream_t st, const int *perm) {
+    hipLaunchKernelGGL(replicate_kernel, dim3(grid_for((size_t)d * nb)), dim3(256), 0, st, Vc, d, l, Xi, nb, perm);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1233,7 +1422,7 @@ void launch_replicate(const cplx *Vc, int64_t d, int l, cplx *Xi, int nb, hipStr
 constexpr int ACC_MAXP = 8;         // moments (2K) accumulated in registers per pass over the systems
 __global__ __launch_bounds__(256) void beyn_accum_kernel(const cplx *__restrict__ Xi, int nb, int64_t d, int l, int nsys,
                                                          const cplx *__restrict__ w, const cplx *__restrict__ z, int npow, cplx *__restrict__ A,
-                                                         int lA, int c0, int TR) {
+                                                         int lA, int c0, int TR, const int *__restrict__ perm) {
     extern __shared__ cplx tile[];                           // TR x (nb + 1): the pad keeps the column reads off one bank
     const int ld = nb + 1;
     const int tid = threadIdx.x;
@@ -1264,7 +1453,7 @@ __global__ __launch_bounds__(256) void beyn_accum_kernel(const cplx *__restrict_
 #pragma unroll
                 for (int p = 0; p < ACC_MAXP; ++p) {
                     if (p < np) {
-                        cplx *dst = A + ((size_t)(p0 + p) * lA + c0 + c) * d + row;
+                        cplx *dst = A + ((size_t)(p0 + p) * lA + c0 + c) * d + (perm ? (int64_t)perm[row] : row);   // the moments are the caller's
                         const cplx a = *dst;
                         *dst = cplx{a.x + acc[p].x, a.y + acc[p].y};
                     }
@@ -1275,7 +1464,7 @@ __global__ __launch_bounds__(256) void beyn_accum_kernel(const cplx *__restrict_
     }
 }
 void launch_beyn_accum(const cplx *Xi, int nb, int64_t d, int l, int nsys, const cplx *w, const cplx *z, int npow, cplx *A, hipStream_t st,
-                       int lA, int c0) {
+                       int lA, int c0, const int *perm) {
     if (lA <= 0) lA = l;
     if (!d || nb < 1) return;
     if (nb > 256) throw WaeError(WAE_ERR_INVALID, "beyn_accum: nb must be in 1..256");
@@ -1284,7 +1473,7 @@ void launch_beyn_accum(const cplx *Xi, int nb, int64_t d, int l, int nsys, const
     if (TR < 1) TR = 1;
     const int64_t tiles = (d + TR - 1) / TR;
     const unsigned grid = (unsigned)std::min<int64_t>(tiles, 4096);
-    hipLaunchKernelGGL(beyn_accum_kernel, dim3(grid), dim3(256), (size_t)TR * (nb + 1) * sizeof(cplx), st, Xi, nb, d, l, nsys, w, z, npow, A, lA, c0, TR);
+    hipLaunchKernelGGL(beyn_accum_kernel, dim3(grid), dim3(256), (size_t)TR * (nb + 1) * sizeof(cplx), st, Xi, nb, d, l, nsys, w, z, npow, A, lA, c0, TR, perm);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -8,6 +8,7 @@
 #include <memory>
 
 #include "amg.h"
+#include "tiles.h"
 #include "wae_internal.h"
 
 static thread_local std::string g_last_error;
@@ -24,6 +25,7 @@ OpDev LevelOp::dev(int op) const {
     o.n = n;
     o.diag = diag.p;
     o.conj_diag = (op == WAE_OP_C) ? 1 : 0;
+    o.tiles = (tiles.ready && (op == WAE_OP_N || tiles.all_symmetric)) ? &tiles.dev : nullptr;
     for (size_t g = 0; g < groups.size(); ++g) {
         const GroupHost &G = groups[g];
         GroupDev &D = o.g[g];
@@ -49,6 +51,7 @@ static OpDev transfer_dev(const DevBuf<int> &ptr, const DevBuf<int> &col, const 
     o.g[0].vals = val.p;
     o.g[0].nplanes = 1;
     o.g[0].is_real = 1;
+    o.tiles = nullptr;
     return o;
 }
 OpDev Transfer::devP() const { return transfer_dev(p_ptr, p_col, p_val, nf); }
@@ -73,7 +76,13 @@ struct wae_family {
     std::vector<zc> term_scale;      // term k = scale * plane
     std::vector<int64_t> term_nnz;
     int nplanes = 0;
-    std::vector<CsrZ> planes0;       // host copies of the fine planes (set-up input)
+    std::vector<CsrZ> planes0;       // host copies of the fine planes (set-up input), in the library's row numbering
+    // Row renumbering (tiles.h): internal row i is the caller's row perm[i].  Applied to the term matrices at create, to
+    // every vector at the ABI boundary (layout kernels), never visible outside.
+    std::vector<int> perm_h;
+    DevBuf<int> perm_dev;
+    std::vector<int> tile_row_ptr;   // tiles of the fine level (empty: no tiling)
+    const int *perm() const { return perm_dev.p; }
     std::vector<LevelOp> ops;        // ops[0] = fine level
     std::vector<std::vector<int>> slot_plane;   // per level: slot -> plane
     std::vector<Transfer> xfer;
@@ -191,6 +200,48 @@ static std::vector<int> build_levelop(LevelOp &L, const std::vector<CsrZ> &plane
     L.diag.upload(dg.data(), dg.size(), st);
     HIP_CHECK(hipStreamSynchronize(st));
     return slot_plane;
+}
+
+// tile-local storage of a level operator whose rows have been renumbered into tiles (tiles.h); planes in the level's numbering
+static void build_level_tiles(LevelOp &L, const std::vector<CsrZ> &planes, const std::vector<int> &slot_plane, const std::vector<int> &row_ptr,
+                              hipStream_t st) {
+    TileStore &T = L.tiles;
+    T = TileStore();
+    if (row_ptr.size() < 2) return;
+    const Pattern U = union_pattern(planes);
+    const TileWindows W = build_windows(U, row_ptr);
+    const int nt = (int)row_ptr.size() - 1;
+    int wmax = 0;
+    for (int t = 0; t < nt; ++t) wmax = std::max(wmax, W.win_ptr[t + 1] - W.win_ptr[t]);
+    if (wmax > 65535) return;
+    T.row_ptr.upload(row_ptr.data(), row_ptr.size(), st);
+    T.win_ptr.upload(W.win_ptr.data(), W.win_ptr.size(), st);
+    T.win_cols.upload(W.win_cols.data(), W.win_cols.size(), st);
+    const size_t ng = L.groups.size();
+    T.sptr.resize(ng); T.sidx.resize(ng); T.svals.resize(ng);
+    memset(&T.dev, 0, sizeof(T.dev));
+    T.all_symmetric = true;
+    for (size_t g = 0; g < ng; ++g) {
+        const GroupHost &G = L.groups[g];
+        std::vector<const CsrZ *> mats;
+        for (int q = 0; q < G.nplanes; ++q) mats.push_back(&planes[slot_plane[G.plane0 + q]]);
+        const TileGroupHost H = build_tile_group(mats, G.is_real, row_ptr, W);
+        T.sptr[g].upload(H.sptr.data(), H.sptr.size(), st);
+        T.sidx[g].upload(H.sidx.data(), H.sidx.size(), st);
+        T.svals[g].upload(H.svals.data(), H.svals.size(), st);
+        HIP_CHECK(hipStreamSynchronize(st));                 // H dies at the end of this iteration
+        T.dev.g[g].sptr = T.sptr[g].p;
+        T.dev.g[g].sidx = T.sidx[g].p;
+        T.dev.g[g].svals = T.svals[g].p;
+        T.all_symmetric = T.all_symmetric && G.symmetric;
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    T.dev.ntiles = nt;
+    T.dev.wmax = wmax;
+    T.dev.row_ptr = T.row_ptr.p;
+    T.dev.win_ptr = T.win_ptr.p;
+    T.dev.win_cols = T.win_cols.p;
+    T.ready = true;
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -1055,9 +1106,31 @@ int wae_family_create(wae_family **out, int64_t d, int32_t T, int32_t index_byte
             }
         }
         h->nplanes = (int)h->planes0.size();
+        // renumber the rows into compact tiles (tiles.h); WAE_REORDER=0 keeps the caller's numbering (A/B measurements)
+        static const bool reorder_on = !(getenv("WAE_REORDER") && atoi(getenv("WAE_REORDER")) == 0);
+        if (reorder_on) {
+            static const int wcap = getenv("WAE_TILE_WCAP") ? atoi(getenv("WAE_TILE_WCAP")) : 608;      // 2 workgroups x 78 KB of LDS per CU
+            static const int thick = getenv("WAE_TILE_THICK") ? atoi(getenv("WAE_TILE_THICK")) : 6;
+            const double tq0 = now_s();
+            TilePlan plan = plan_tiles(union_pattern(h->planes0), 256, wcap, thick);
+            const double tq1 = now_s();
+            if (!plan.perm.empty()) {
+                std::vector<std::future<CsrZ>> jobs;
+                for (size_t q = 0; q < h->planes0.size(); ++q)
+                    jobs.push_back(std::async(std::launch::async, [&, q]() { return permute_symmetric(h->planes0[q], plan.perm, plan.iperm); }));
+                for (size_t q = 0; q < h->planes0.size(); ++q) h->planes0[q] = jobs[q].get();
+                h->perm_h = plan.perm;
+                h->perm_dev.upload(h->perm_h.data(), h->perm_h.size(), h->stream);
+                h->tile_row_ptr = plan.row_ptr;
+            }
+            if (getenv("WAE_SETUP_DEBUG"))
+                fprintf(stderr, "[create] tile plan %.3f s (%zu tiles, largest window %d), permutation of the planes %.3f s\n", tq1 - tq0,
+                        plan.row_ptr.empty() ? (size_t)0 : plan.row_ptr.size() - 1, plan.wmax, now_s() - tq1);
+        }
         h->ops.resize(1);
         h->slot_plane.resize(1);
         h->slot_plane[0] = build_levelop(h->ops[0], h->planes0, h->stream);
+        if (!h->tile_row_ptr.empty()) build_level_tiles(h->ops[0], h->planes0, h->slot_plane[0], h->tile_row_ptr, h->stream);
         cplx one = {1.0, 0.0};
         h->one_dev.upload(&one, 1, h->stream);
         HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -1116,9 +1189,9 @@ int wae_spmv_sum_cols(wae_family *h, const double *coeffs, int32_t ncoef, const 
         DevBuf<cplx> pcd;
         pcd.upload(tab.data(), tab.size(), st);
         HIP_CHECK(hipMemcpyAsync(h->io_a.p, X, cnt * sizeof(cplx), hipMemcpyHostToDevice, st));
-        launch_colmajor_to_inter(h->io_a.p, h->d, r, xi.p, r, st);
+        launch_colmajor_to_inter(h->io_a.p, h->d, r, xi.p, r, st, h->perm());
         launch_spmv(h->ops[0].dev(op), pcd.p, ncoef == 1 ? (1 << 30) : 1, xi.p, yi.p, nullptr, 0.0, r, MODE_AX, st);
-        launch_inter_to_colmajor(yi.p, r, h->d, r, h->io_b.p, st);
+        launch_inter_to_colmajor(yi.p, r, h->d, r, h->io_b.p, st, h->perm());
         HIP_CHECK(hipMemcpyAsync(Y, h->io_b.p, cnt * sizeof(cplx), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         xi.release(); yi.release(); pcd.release();
@@ -1141,7 +1214,7 @@ int wae_eig_residuals(wae_family *h, int32_t n, const double *coeff_table, const
             HIP_CHECK(hipMemcpyAsync(h->io_a.p, P, cnt * sizeof(cplx), hipMemcpyHostToDevice, st));
             src = h->io_a.p;
         }
-        launch_colmajor_to_inter(src, h->d, n, xi.p, n, st);
+        launch_colmajor_to_inter(src, h->d, n, xi.p, n, st, h->perm());
         std::vector<cplx> tab((size_t)n * h->nplanes), hn(n);
         std::vector<zc> pc;
         auto pass = [&](int only_term, std::vector<double> &out) {     // norms of (sum_k c_jk A_k v_j), k = all or one term
@@ -1195,7 +1268,7 @@ int wae_spmv_sum_multi(wae_family *h, const double *coeffs, const double *X, dou
         DevBuf<cplx> xi, yi, acc, pcd;
         xi.alloc(cnt); yi.alloc((size_t)h->d); acc.alloc((size_t)h->d);
         HIP_CHECK(hipMemcpyAsync(h->io_a.p, X, cnt * sizeof(cplx), hipMemcpyHostToDevice, st));
-        launch_colmajor_to_inter(h->io_a.p, h->d, T, xi.p, T, st);
+        launch_colmajor_to_inter(h->io_a.p, h->d, T, xi.p, T, st, h->perm());
         launch_fill_zero(acc.p, (size_t)h->d, st);
         // passes: in pass t every plane takes the t-th term mapped to it (if any)
         std::vector<std::vector<int>> plane_terms(h->nplanes);
@@ -1220,7 +1293,8 @@ int wae_spmv_sum_multi(wae_family *h, const double *coeffs, const double *X, dou
             launch_add(yi.p, acc.p, (size_t)h->d, st);
             HIP_CHECK(hipStreamSynchronize(st));
         }
-        HIP_CHECK(hipMemcpyAsync(Y, acc.p, (size_t)h->d * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        launch_inter_to_colmajor(acc.p, 1, h->d, 1, h->io_b.p, st, h->perm());      // back to the caller's row numbering
+        HIP_CHECK(hipMemcpyAsync(Y, h->io_b.p, (size_t)h->d * sizeof(cplx), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         xi.release(); yi.release(); acc.release(); pcd.release();
         return WAE_OK;
@@ -1429,10 +1503,10 @@ int wae_solve_guess(wae_family *h, const double *coeffs, int32_t ncoef, const do
                 pcs.resize(nb);
                 for (int b = 0; b < nb; ++b) plane_coeffs(h, coeffs + (size_t)(c0 + b) * 2 * h->T, op, pcs[b]);
             }
-            launch_colmajor_to_inter(h->io_a.p + (size_t)c0 * d, d, nb, h->Bs.p, nb, st);
-            if (Gd) launch_colmajor_to_inter(gcol.p + (size_t)c0 * d, d, nb, gint.p, nb, st);
+            launch_colmajor_to_inter(h->io_a.p + (size_t)c0 * d, d, nb, h->Bs.p, nb, st, h->perm());
+            if (Gd) launch_colmajor_to_inter(gcol.p + (size_t)c0 * d, d, nb, gint.p, nb, st, h->perm());
             solve_chunk(h, bt, pcs, h->Bs.p, h->Xs.p, tol, maxit, &li, Gd ? gint.p : nullptr);
-            launch_inter_to_colmajor(h->Xs.p, nb, d, nb, h->io_b.p + (size_t)c0 * d, st);
+            launch_inter_to_colmajor(h->Xs.p, nb, d, nb, h->io_b.p + (size_t)c0 * d, st, h->perm());
         }
         HIP_CHECK(hipMemcpyAsync(X, h->io_b.p, cnt * sizeof(cplx), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
@@ -1488,9 +1562,9 @@ int wae_beyn_moments(wae_family *h, int32_t npts, const double *z, const double 
                 }
                 h->zw_dev.upload(zw.data(), zw.size(), st);
                 HIP_CHECK(hipStreamSynchronize(st));
-                if (bt.nb != rep_nb) { launch_replicate(h->io_a.p + (size_t)cg * d, d, lg, h->Bs.p, bt.nb, st); rep_nb = bt.nb; }   // same right-hand sides for every chunk
+                if (bt.nb != rep_nb) { launch_replicate(h->io_a.p + (size_t)cg * d, d, lg, h->Bs.p, bt.nb, st, h->perm()); rep_nb = bt.nb; }   // same right-hand sides for every chunk
                 solve_chunk(h, bt, pcs, h->Bs.p, h->Xs.p, tol, maxit, &li);
-                launch_beyn_accum(h->Xs.p, bt.nb, d, lg, ns, h->zw_dev.p, h->zw_dev.p + ns, npow, Ad, st, l, cg);
+                launch_beyn_accum(h->Xs.p, bt.nb, d, lg, ns, h->zw_dev.p, h->zw_dev.p + ns, npow, Ad, st, l, cg, h->perm());
             }
         }
         if (A_out) HIP_CHECK(hipMemcpyAsync(A_out, Ad, acnt * sizeof(cplx), hipMemcpyDeviceToHost, st));
@@ -1542,7 +1616,7 @@ int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const doub
             HIP_CHECK(hipMemcpyAsync(h->io_a.p, V, vecl * sizeof(cplx), hipMemcpyHostToDevice, st));
         } else {                                     // mode 2 on the basis this handle started: its probe matrix is still in HBM
             WAE_REQUIRE(mode == 2 && R.vi_valid && R.l == l && R.Vi.n >= vecl, "V may be NULL only in mode 2 after a mode 0/1 call with the same l on this handle");
-            launch_inter_to_colmajor(R.Vi.p, l, d, l, h->io_a.p, st);
+            launch_inter_to_colmajor(R.Vi.p, l, d, l, h->io_a.p, st, h->perm());      // (io_a holds the caller's numbering, like an uploaded V)
         }
         const int spc = std::max(1, h->NB / l);   // systems per chunk
         ensure(h->zw_dev, (size_t)2 * spc);
@@ -1554,7 +1628,7 @@ int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const doub
         static const int enrich_its = getenv("WAE_RB_ENRICH") ? atoi(getenv("WAE_RB_ENRICH")) : (1 << 30);
         double t_guess = 0.0, t_solve = 0.0, t_append = 0.0;
         if ((mode == 0 && slot0 == 0) || mode == 1) {
-            launch_colmajor_to_inter(h->io_a.p, d, l, h->W.p, l, st);
+            launch_colmajor_to_inter(h->io_a.p, d, l, h->W.p, l, st, h->perm());
             rb_reset(h, Q, nbasis, l, coeff_table, npts, h->W.p);
             if (mode == 1) rb_append(h, slot0);    // the store holds slot0 raw snapshots (e.g. all-gathered)
         } else {
@@ -1595,7 +1669,7 @@ int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const doub
             }
             h->zw_dev.upload(zw.data(), zw.size(), st);
             HIP_CHECK(hipStreamSynchronize(st));
-            if (bt.nb != rep_nb) { launch_replicate(h->io_a.p, d, l, h->Bs.p, bt.nb, st); rep_nb = bt.nb; }   // same right-hand sides for every chunk
+            if (bt.nb != rep_nb) { launch_replicate(h->io_a.p, d, l, h->Bs.p, bt.nb, st, h->perm()); rep_nb = bt.nb; }   // same right-hand sides for every chunk
             const bool guess = R.S > 0;            // mode 0 is progressive: later snapshot chunks start from the earlier ones
             const double ta = now_s();
             if (guess) {
@@ -1610,7 +1684,7 @@ int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const doub
             }
             const double tb = now_s();
             const int its = solve_chunk(h, bt, pcs, h->Bs.p, h->Xs.p, tol, maxit, &li, nullptr, guess);
-            launch_beyn_accum(h->Xs.p, bt.nb, d, l, ns, h->zw_dev.p, h->zw_dev.p + ns, npow, Ad, st, l_total, col0);
+            launch_beyn_accum(h->Xs.p, bt.nb, d, l, ns, h->zw_dev.p, h->zw_dev.p + ns, npow, Ad, st, l_total, col0, h->perm());
             if (rbdbg) HIP_CHECK(hipStreamSynchronize(st));
             const double tc = now_s();
             // mode 0 keeps every solution; modes 1/2 enrich the basis where the guesses were poor (a region of the
@@ -1739,7 +1813,7 @@ int wae_arnoldi_shiftinvert_batch(wae_family *h, int32_t nsys, const double *coe
         std::vector<char> dead(nsys, 0);
         // v_0 = v0 / ||v0||, column by column
         HIP_CHECK(hipMemcpyAsync(stage.p, v0, vec * sizeof(cplx), hipMemcpyHostToDevice, st));
-        launch_colmajor_to_inter(stage.p, d, nsys, t.p, nsys, st);
+        launch_colmajor_to_inter(stage.p, d, nsys, t.p, nsys, st, h->perm());
         launch_norms(t.p, d, nsys, h->partial.p, hcol.p, st);
         launch_scale_inv(t.p, hcol.p, EV.p, d, nsys, st);
         const OpDev Mop = h->ops[0].dev(op);
@@ -1790,7 +1864,7 @@ int wae_arnoldi_shiftinvert_batch(wae_family *h, int32_t nsys, const double *coe
         if (done < m) launch_fill_zero(EV.p + (size_t)(done + 1) * vec, (size_t)(m - done) * vec, st);
         // V_out[sys] = d x (m+1) column-major
         for (int j = 0; j <= m; ++j) {
-            launch_inter_to_colmajor(EV.p + (size_t)j * vec, nsys, d, nsys, stage.p, st);
+            launch_inter_to_colmajor(EV.p + (size_t)j * vec, nsys, d, nsys, stage.p, st, h->perm());
             for (int sy = 0; sy < nsys; ++sy)
                 HIP_CHECK(hipMemcpyAsync(V_out + ((size_t)sy * (m + 1) + j) * d * 2, stage.p + (size_t)sy * d, (size_t)d * sizeof(cplx),
                                          hipMemcpyDeviceToHost, st));
@@ -1872,8 +1946,11 @@ int wae_perturb(wae_family *h, const double *coeff_table, int32_t N, const doubl
         }
         // v[0] = v0 / sqrt(ip(v0,v0))
         cplx *V0 = PV.p;
-        HIP_CHECK(hipMemcpyAsync(V0, v0, (size_t)d * sizeof(cplx), hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(wl.p, v0adj, (size_t)d * sizeof(cplx), hipMemcpyHostToDevice, st));
+        ensure(h->io_a, (size_t)2 * d);                                   // caller's row numbering -> the library's
+        HIP_CHECK(hipMemcpyAsync(h->io_a.p, v0, (size_t)d * sizeof(cplx), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(h->io_a.p + d, v0adj, (size_t)d * sizeof(cplx), hipMemcpyHostToDevice, st));
+        launch_colmajor_to_inter(h->io_a.p, d, 1, V0, 1, st, h->perm());
+        launch_colmajor_to_inter(h->io_a.p + d, d, 1, wl.p, 1, st, h->perm());
         {
             const zc nn = ipY(V0, V0);
             axpby(1.0 / std::sqrt(nn), V0, 0.0, V0, V0);
@@ -1969,7 +2046,9 @@ int wae_perturb(wae_family *h, const double *coeff_table, int32_t N, const doubl
                 }
             }
         }
-        HIP_CHECK(hipMemcpyAsync(v_out, PV.p, (size_t)d * (N + 1) * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        ensure(h->io_b, (size_t)d * (N + 1));
+        for (int k = 0; k <= N; ++k) launch_inter_to_colmajor(PV.p + (size_t)k * d, 1, d, 1, h->io_b.p + (size_t)k * d, st, h->perm());
+        HIP_CHECK(hipMemcpyAsync(v_out, h->io_b.p, (size_t)d * (N + 1) * sizeof(cplx), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         for (int k = 1; k <= N; ++k) { lambda_out[2 * k] = lam[k].real(); lambda_out[2 * k + 1] = lam[k].imag(); }
         for (auto *bf : {&PV, &Ub, &rb, &rhs, &u10, &wl, &tmp, &tmp2, &tmp3, &sc, &Gd, &pcd}) bf->release();

@@ -67,6 +67,21 @@ struct GroupDev {                   // one sparsity pattern shared by `nplanes` 
     int plane0;                     // first plane index in the per-system coefficient table
     int conj_vals;                  // conjugate complex values on the fly (op = C on a symmetric pattern)
 };
+// tile-local storage of an operator (tiles.h): rows renumbered so that <= 256 consecutive rows form a compact brick of the
+// mesh graph whose distinct columns (the "window") fit LDS
+struct TileGroupDev {
+    const int *sptr;                // 4*ntiles+1: entry offset of the slice of (tile, wavefront)
+    const unsigned short *sidx;     // window-local column of every entry ([k][lane] inside a slice)
+    const void *svals;              // [entry][nplanes] double or double2, same value layout as GroupDev::vals
+};
+struct TileDev {
+    int ntiles;
+    int wmax;                       // largest window
+    const int *row_ptr;             // ntiles+1
+    const int *win_ptr;             // ntiles+1
+    const int *win_cols;            // global (new) column of every window slot, ascending per tile
+    TileGroupDev g[WAE_MAXG];
+};
 struct OpDev {
     int ngroups;
     int nplanes_total;
@@ -74,6 +89,7 @@ struct OpDev {
     GroupDev g[WAE_MAXG];
     const cplx *diag;               // [n][nplanes_total] diagonal of every plane (for Jacobi), may be null
     int conj_diag;                  // op = C: use conj(diag) (coefficients arrive already conjugated)
+    const TileDev *tiles;           // HOST pointer (read by launch_spmv only): tile-local storage valid for this orientation, or null
 };
 
 // device buffer: owns its allocation (freed on destruction, so an exception that leaves a C-ABI entry through guarded()
@@ -116,11 +132,22 @@ struct GroupHost {                  // a pattern group held on device, N and T o
     DevBuf<double> vals, vals_t;    // raw storage (nnz*nplanes*(1 or 2) doubles)
 };
 
+struct TileStore {                  // device arrays behind a TileDev
+    DevBuf<int> row_ptr, win_ptr, win_cols;
+    std::vector<DevBuf<int>> sptr;
+    std::vector<DevBuf<unsigned short>> sidx;
+    std::vector<DevBuf<double>> svals;
+    TileDev dev;
+    bool ready = false;
+    bool all_symmetric = false;     // every group symmetric: the N-orientation tiles serve op = T/C as well
+};
+
 struct LevelOp {                    // sum_q pc[q] * plane_q  at one multigrid level
     int64_t n = 0;
     int nplanes = 0;
     std::vector<GroupHost> groups;
     DevBuf<cplx> diag;              // [n][nplanes]
+    TileStore tiles;
     OpDev dev(int op) const;        // op: WAE_OP_N / T / C
     // host copies of the planes (kept for Galerkin products and dense coarse assembly)
     std::vector<CsrZ> planes;
@@ -182,10 +209,11 @@ void launch_scale_inv(const cplx *X, const cplx *alpha, cplx *Y, int64_t n, int 
 // Y += X
 void launch_add(const cplx *X, cplx *Y, size_t count, hipStream_t s);
 // layout changes: column-major d x r  <->  interleaved [d][nb] (columns >= r zero-filled / ignored)
-void launch_colmajor_to_inter(const cplx *Xc, int64_t d, int r, cplx *Xi, int nb, hipStream_t s);
-void launch_inter_to_colmajor(const cplx *Xi, int nb, int64_t d, int r, cplx *Xc, hipStream_t s);
+// perm (optional, device): internal row i is the caller's row perm[i] (tiles.h) -- the column-major side is in the caller's numbering
+void launch_colmajor_to_inter(const cplx *Xc, int64_t d, int r, cplx *Xi, int nb, hipStream_t s, const int *perm = nullptr);
+void launch_inter_to_colmajor(const cplx *Xi, int nb, int64_t d, int r, cplx *Xc, hipStream_t s, const int *perm = nullptr);
 // replicate V (col-major d x l) into an interleaved block: column b -> V[:, b % l]
-void launch_replicate(const cplx *Vc, int64_t d, int l, cplx *Xi, int nb, hipStream_t s);
+void launch_replicate(const cplx *Vc, int64_t d, int l, cplx *Xi, int nb, hipStream_t s, const int *perm = nullptr);
 // snapshot-basis helpers: one system's l columns out of a batch; X = sum_i y[i][b] Q_i[row][b % l]; zero selected columns
 // V-cycle prolongation: X += P Xc (P real CSR, n fine rows)
 void launch_prolong_add(const int *ptr, const int *col, const double *val, int64_t n, const cplx *Xc, cplx *X, int nb, hipStream_t s,
@@ -200,7 +228,7 @@ void launch_lincomb_rep(const cplx *Q, size_t stride, int nv, const cplx *y, cpl
 void launch_mask_cols(cplx *X, const cplx *keep, int64_t n, int nb, hipStream_t s);
 // Beyn accumulation: A[(p*lA+c0+c)*d + row] += sum_s w[s] z[s]^p X[row][s*l+c], s < nsys, p < npow  (lA columns in A; 0 = l)
 void launch_beyn_accum(const cplx *Xi, int nb, int64_t d, int l, int nsys, const cplx *w, const cplx *z, int npow, cplx *A, hipStream_t s,
-                       int lA = 0, int c0 = 0);
+                       int lA = 0, int c0 = 0, const int *perm = nullptr);
 // X[row][t] = sum_i G[i][t] V_i[row], V_i = V + i*stride (single vectors), X interleaved with leading dimension T
 void launch_gemv_multi(const cplx *V, size_t stride, int k, const cplx *G, cplx *X, int64_t d, int T, hipStream_t s);
 // triad for bandwidth measurement
