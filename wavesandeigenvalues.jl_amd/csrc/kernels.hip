@@ -356,90 +356,156 @@ __global__ __launch_bounds__(256, 4) void spmv_lds_kernel(OpDev op, const cplx *
 // serves per cycle spread over all bank groups (two lanes share a group only if their window rows have equal parity).
 // UNI: the 8 columns of a chunk belong to one system (columns per system a multiple of 8): one coefficient set per chunk.
 // ---------------------------------------------------------------------------------------------------
+// Structure: one PERSISTENT workgroup of 8 wavefronts per tile walks the tile's column chunks.  The matrix slice of its rows
+// is loaded ONCE into registers and serves every chunk; two window buffers alternate, so the LDS-DMA gather of chunk c+1
+// (global_load_lds_dwordx4: the per-lane source address makes it a row gather, no VGPR round trip) runs under the LDS + FMA
+// work of chunk c, which issues no global load at all.  Wavefronts w and w+4 share the 64 rows of slice w and split their
+// entries by parity (partial sums meet in the staging tile): two wavefronts per SIMD, so one's LDS latency hides under the
+// other's FMAs -- with one wavefront per SIMD hipcc serialised every ds_read behind an s_waitcnt (15 k cycles per chunk).
+// (First version: one workgroup per (tile, chunk), two per CU, phases back to back -- the waves sat in s_waitcnt 80 % of the
+// time and the matrix tile crossed L2 -> L1 once per chunk: 1396 us at 1M DoF against 1175 us for spmv_lds_kernel.)
+#ifdef WAE_TILE_STAMPS
+__device__ unsigned long long wae_tile_stamps[8 * 64];     // diagnostic build only: s_memtime at the phase boundaries of one workgroup
+#define TILE_STAMP(k) do { if (blockIdx.x == 808 && tid == 0 && ch < 8) wae_tile_stamps[ch * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TILE_STAMP(k) do { } while (0)
+#endif
 template <bool UNI>
-__global__ __launch_bounds__(256, 2) void spmv_tile_kernel(OpDev op, TileDev td, const cplx *__restrict__ pc, int cps,
+__global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td, const cplx *__restrict__ pc, int cps,
                                                           const cplx *__restrict__ X, cplx *Y, const cplx *B, double jac_w,
                                                           int nb, int mode, const unsigned char *__restrict__ cmask) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
     const int tid = threadIdx.x;
     const int nch = (nb + 7) >> 3;
-    const int tpx = (td.ntiles + 7) >> 3;                   // tiles per XCD: workgroup ids are dealt round-robin over the 8 XCDs, so
-    const int jx = blockIdx.x >> 3;                         // XCD k takes the k-th contiguous eighth of the tiles and runs the
-    const int tl = jx / nch, ch = jx - tl * nch;            // column chunks of a tile back to back (its matrix tile stays in that L2)
-    const int tile = (int)(blockIdx.x & 7u) * tpx + tl;
+    const int tpx = (td.ntiles + 7) >> 3;                   // workgroup ids are dealt round-robin over the 8 XCDs: XCD k takes the
+    const int tile = (int)(blockIdx.x & 7u) * tpx + (int)(blockIdx.x >> 3);   // k-th contiguous eighth of the tiles (shared halos hit its L2)
     if (tile >= td.ntiles) return;
-    if (cmask && !cmask[ch]) return;
     const int npl = op.nplanes_total;
-    cplx *win = (cplx *)tile_smem;                          // [window slot][8 columns]
-    cplx *spc = win + (size_t)(td.wmax > 256 ? td.wmax : 256) * 8;   // [8][npl] coefficients of the chunk's columns
-    const int col0 = ch * 8;
-    for (int i = tid; i < 8 * npl; i += 256) {
-        const int cc = i / npl, q = i - cc * npl;
-        int bb = col0 + cc;
-        if (bb >= nb) bb = nb - 1;
-        spc[i] = pc[(size_t)(bb / cps) * npl + q];
-    }
-    {   // phase 1: window -> LDS (thread = (window slot, column); 8 lanes fetch one 128-B segment of an X row)
-        const int w0 = td.win_ptr[tile], W = td.win_ptr[tile + 1] - w0;
-        const int c = tid & 7;
-        int bc = col0 + c;
-        if (bc >= nb) bc = nb - 1;
-        const cplx *Xc = X + bc;
-        const int *wl = td.win_cols + w0;
-        constexpr int U = 4;
-        for (int i0 = tid >> 3; i0 < W; i0 += 32 * U) {
-            int gr[U];
-            cplx x[U];
+    const int wslots = ((td.wmax > 512 ? td.wmax : 512) + 7) & ~7;
+    cplx *const smem = (cplx *)tile_smem;                   // two window buffers [window slot][8 columns] (offsets, not a pointer
+    cplx *spc = smem + (size_t)wslots * 16;                 // table: the accesses must stay provably LDS), then [8][npl] coefficients
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: branches on it are uniform)
+    const int half = wv >> 2, sl = wv & 3;                   // this wavefront: entries of parity `half` of the rows of slice `sl`
+    auto next_active = [&](int c) { while (c < nch && cmask && !cmask[c]) ++c; return c; };
+    int ch = next_active(0);
+    if (ch >= nch) return;
+    // this lane's share of its row of the bulk group -> registers: entries half, half+2, ... (the first KR of them)
+    constexpr int KR = 8;
+    const GroupDev G0 = op.g[0];
+    const TileGroupDev T0 = td.g[0];
+    const bool fast0 = G0.is_real && G0.nplanes == 2;
+    const int s00 = T0.sptr[tile * 4 + sl];
+    const int n0 = (T0.sptr[tile * 4 + sl + 1] - s00) >> 6;
+    unsigned ixr[KR];
+    double2 avr[KR];
 #pragma unroll
-            for (int u = 0; u < U; ++u) { const int i = i0 + 32 * u; gr[u] = wl[i < W ? i : W - 1]; }
+    for (int u = 0; u < KR; ++u) { ixr[u] = 0; avr[u] = double2{0.0, 0.0}; }
+    if (fast0) {
+        const unsigned short *__restrict__ si = T0.sidx;
+        const double2 *__restrict__ v2 = (const double2 *)T0.svals;
 #pragma unroll
-            for (int u = 0; u < U; ++u) x[u] = Xc[(size_t)gr[u] * nb];
-#pragma unroll
-            for (int u = 0; u < U; ++u) { const int i = i0 + 32 * u; if (i < W) win[i * 8 + c] = x[u]; }
+        for (int u = 0; u < KR; ++u) {
+            const int k = 2 * u + half;
+            if (k < n0) { const int e = s00 + lane + 64 * k; ixr[u] = si[e]; avr[u] = v2[e]; }   // (uniform; absent entries stay (0, 0.0))
         }
     }
-    __syncthreads();
-    const int lane = tid & 63, wv = tid >> 6;
-    const int rot = lane & 7;
-    cplx acc[8];
+    // window row list: wave instruction u of wavefront wv moves the window rows wv*8 + 64*u .. +7
+    const int w0 = td.win_ptr[tile], W = td.win_ptr[tile + 1] - w0;
+    constexpr int NW = 10;                                   // 64 rows per workgroup step: windows up to 640 rows in one sweep
+    int gr[NW];
+    {
+        const int *wl = td.win_cols + w0;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) acc[s] = cplx{0.0, 0.0};
-#pragma unroll 1
-    for (int g = 0; g < op.ngroups; ++g) {
-        const TileGroupDev TG = td.g[g];
-        const int s0 = TG.sptr[tile * 4 + wv], s1 = TG.sptr[tile * 4 + wv + 1];
-        if (s0 == s1) continue;                              // (uniform per wavefront)
-        const GroupDev G = op.g[g];
-        const int np = G.nplanes;
-        if (G.is_real && np == 2) {                          // the hot case: mass + stiffness on one pattern, 16 B + 2 B per nonzero
-            const double2 *__restrict__ v2 = (const double2 *)TG.svals;
-            const unsigned short *__restrict__ si = TG.sidx;
-            cplx c0 = spc[G.plane0], c1 = spc[G.plane0 + 1];
-            int e = s0 + lane;
-            unsigned ix = si[e];
-            double2 a = v2[e];
-            for (; e < s1; e += 64) {
-                const int en = e + 64 < s1 ? e + 64 : e;     // next entry of this lane (prefetched)
-                const unsigned ixn = si[en];
-                const double2 an = v2[en];
+        for (int u = 0; u < NW; ++u) { const int i = wv * 8 + 64 * u + (lane >> 3); gr[u] = wl[i < W ? i : W - 1]; }
+    }
+    auto issue_window = [&](int c, cplx *dst) {              // LDS-DMA gather of chunk c's window (rows past W duplicate the last one
+        int bc = c * 8 + (lane & 7);                         // into the slack of the 8-row granule: no per-lane predicate)
+        if (bc >= nb) bc = nb - 1;
+        const cplx *Xc = X + bc;
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int r = wv * 8 + 64 * u;
+            if (r < W)                                       // (uniform)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Xc + (size_t)gr[u] * nb),
+                                                 (__attribute__((address_space(3))) void *)(dst + (size_t)r * 8), 16, 0, 0);
+        }
+        for (int rb = wv * 8 + 64 * NW; rb < W; rb += 64) {  // (windows beyond NW sweeps: only with WAE_TILE_WCAP > 640)
+            const int i = rb + (lane >> 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Xc + (size_t)td.win_cols[w0 + (i < W ? i : W - 1)] * nb),
+                                             (__attribute__((address_space(3))) void *)(dst + (size_t)rb * 8), 16, 0, 0);
+        }
+    };
+    const int r0 = td.row_ptr[tile], nrows = td.row_ptr[tile + 1] - r0;
+    const int rot = lane & 7;
+    const int lrow = sl * 64 + lane;                         // this lane's row inside the tile
+    int buf = 0;
+    issue_window(ch, smem);
+    while (ch < nch) {
+        const int chn = next_active(ch + 1);
+        const int col0 = ch * 8;
+        TILE_STAMP(0);
+        for (int i = tid; i < 8 * npl; i += 512) {
+            const int cc = i / npl, q = i - cc * npl;
+            int bb = col0 + cc;
+            if (bb >= nb) bb = nb - 1;
+            spc[i] = pc[(size_t)(bb / cps) * npl + q];
+        }
+        __syncthreads();                                     // window of chunk ch has landed (hipcc drains the LDS-DMA before a barrier);
+        cplx *win = smem + (size_t)buf * wslots * 8;         // the other buffer's last reader (previous epilogue) is done
+        TILE_STAMP(1);
+        if (chn < nch) issue_window(chn, smem + (size_t)(buf ^ 1) * wslots * 8);
+        TILE_STAMP(2);
+        cplx acc[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc[s] = cplx{0.0, 0.0};
+        if (fast0 && n0 > 0) {                               // the bulk group: mass + stiffness on one pattern, 16 B + 2 B per nonzero
+            const cplx c0 = spc[G0.plane0], c1 = spc[G0.plane0 + 1];
+            auto entry = [&](unsigned ix, double2 a) {
                 const cplx *wr = win + ix * 8;
                 cplx m = {fma(c0.x, a.x, c1.x * a.y), fma(c0.y, a.x, c1.y * a.y)};
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
                     const int cs = (s + rot) & 7;
                     if (!UNI) {
-                        c0 = spc[cs * npl + G.plane0]; c1 = spc[cs * npl + G.plane0 + 1];
-                        m = cplx{fma(c0.x, a.x, c1.x * a.y), fma(c0.y, a.x, c1.y * a.y)};
+                        const cplx d0 = spc[cs * npl + G0.plane0], d1 = spc[cs * npl + G0.plane0 + 1];
+                        m = cplx{fma(d0.x, a.x, d1.x * a.y), fma(d0.y, a.x, d1.y * a.y)};
                     }
+#if defined(TILE_ABL_NOLDS)
+                    cfma(acc[s], m, cplx{1.0 + cs, 2.0});
+#elif defined(TILE_ABL_NOFMA)
+                    { const cplx xx = wr[cs]; acc[s].x += xx.x; acc[s].y += xx.y; }
+#else
                     cfma(acc[s], m, wr[cs]);
+#endif
                 }
-                ix = ixn; a = an;
+            };
+            // register-resident part: straight-line code, absent entries are (slot 0, 0.0); the scheduling fences keep two
+            // entries' operands in flight (hipcc would otherwise hoist all 64 LDS reads and spill)
+#pragma unroll
+            for (int u = 0; u < KR; ++u) {
+                entry(ixr[u], avr[u]);
+                if (u & 1) __builtin_amdgcn_sched_barrier(0);
             }
-        } else {
+            const unsigned short *__restrict__ si = T0.sidx;
+            const double2 *__restrict__ v2 = (const double2 *)T0.svals;
+#pragma unroll 1
+            for (int k = 2 * KR + half; k < n0; k += 2) {    // rows longer than 2 KR entries: streamed
+                const int e = s00 + lane + 64 * k;
+                entry(si[e], v2[e]);
+            }
+        }
+#pragma unroll 1
+        for (int g = fast0 ? 1 : 0; g < op.ngroups; ++g) {   // the other groups (boundary, flame, ... : few entries, most tiles have none)
+            const TileGroupDev TG = td.g[g];
+            const int s0 = TG.sptr[tile * 4 + sl], s1 = TG.sptr[tile * 4 + sl + 1];
+            if (s0 == s1) continue;                          // (uniform per wavefront)
+            const GroupDev G = op.g[g];
+            const int np = G.nplanes;
             const double *__restrict__ vr = (const double *)TG.svals;
             const cplx *__restrict__ vc = (const cplx *)TG.svals;
             const double sg = G.conj_vals ? -1.0 : 1.0;
-            for (int e = s0 + lane; e < s1; e += 64) {
+#pragma unroll 1
+            for (int e = s0 + lane + 64 * half; e < s1; e += 128) {
                 const cplx *wr = win + (unsigned)TG.sidx[e] * 8;
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
@@ -455,67 +521,101 @@ __global__ __launch_bounds__(256, 2) void spmv_tile_kernel(OpDev op, TileDev td,
                 }
             }
         }
-    }
-    __syncthreads();                                         // every wavefront is done with the window: reuse it as the staging tile
+        TILE_STAMP(3);
+        __syncthreads();                                     // every wavefront is done with this window: reuse it as two staging tiles
+        TILE_STAMP(4);
+        {
+            cplx *stage = win + (size_t)half * 2048;         // [256 rows][8 columns] per half
 #pragma unroll
-    for (int s = 0; s < 8; ++s) win[tid * 8 + ((s + rot) & 7)] = acc[s];
-    __syncthreads();
-    // phase 3: thread = (row, column) -> 8 lanes write one 128-B row segment
-    const int r0 = td.row_ptr[tile], nrows = td.row_ptr[tile + 1] - r0;
-    const int c = tid & 7;
-    const int b = col0 + c;
-    if (b >= nb) return;
-    const cplx *mypc = spc + c * npl;
-    for (int rr = tid >> 3; rr < nrows; rr += 32) {
-        const cplx av = win[rr * 8 + c];
-        const int64_t row = r0 + rr;
-        const size_t e = (size_t)row * nb + b;
-        cplx out;
-        if (mode == MODE_AX) {
-            out = av;
-        } else if (mode == MODE_RES) {
-            const cplx bv = B[e];
-            out = cplx{bv.x - av.x, bv.y - av.y};
-        } else if (mode == MODE_ADD) {
-            const cplx bv = B[e];
-            out = cplx{bv.x + av.x, bv.y + av.y};
-        } else {
-            cplx dg = {0.0, 0.0};
-            const double dsg = op.conj_diag ? -1.0 : 1.0;
-            for (int q = 0; q < npl; ++q) { cplx dq = op.diag[(size_t)row * npl + q]; dq.y *= dsg; cfma(dg, mypc[q], dq); }
-            if (mode == MODE_AX_J0) {
-                out = av;
-                const cplx r = cdiv(av, dg);
-                const_cast<cplx *>(B)[e] = cplx{jac_w * r.x, jac_w * r.y};
-            } else if (mode == MODE_AX_DS) {
-                out = cdiv(av, dg);
-            } else if (mode == MODE_RES_DS) {
-                const cplx bv = B[e];
-                out = cdiv(cplx{bv.x - av.x, bv.y - av.y}, dg);
+            for (int s = 0; s < 8; ++s) stage[lrow * 8 + ((s + rot) & 7)] = acc[s];
+        }
+        __syncthreads();
+        TILE_STAMP(5);
+        // epilogue: thread = (row, column) -> 8 lanes write one 128-B row segment; the two halves' partial sums meet here
+        const int c = tid & 7;
+        const int b = col0 + c;
+        if (b < nb) {
+            const cplx *mypc = spc + c * npl;
+            const int rl = tid >> 3;
+            if (mode == MODE_AX) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int rr = rl + 64 * u;
+                    if (rr < nrows) {
+                        const cplx a0 = win[rr * 8 + c], a1 = win[2048 + rr * 8 + c];
+                        Y[(size_t)(r0 + rr) * nb + b] = cplx{a0.x + a1.x, a0.y + a1.y};
+                    }
+                }
             } else {
-                const cplx bv = B[e], xv = X[e];
-                const cplx r = cdiv(cplx{bv.x - av.x, bv.y - av.y}, dg);
-                out = cplx{xv.x + jac_w * r.x, xv.y + jac_w * r.y};
+                cplx bv[4], xv[4];
+                const bool need_b = mode == MODE_RES || mode == MODE_ADD || mode == MODE_RES_DS || mode == MODE_JAC;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int rr = rl + 64 * u;
+                    const size_t e = (size_t)(r0 + (rr < nrows ? rr : 0)) * nb + b;
+                    bv[u] = need_b ? B[e] : cplx{0.0, 0.0};
+                    xv[u] = mode == MODE_JAC ? X[e] : cplx{0.0, 0.0};
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int rr = rl + 64 * u;
+                    if (rr >= nrows) continue;
+                    const cplx a0 = win[rr * 8 + c], a1 = win[2048 + rr * 8 + c];
+                    const cplx av = {a0.x + a1.x, a0.y + a1.y};
+                    const int64_t row = r0 + rr;
+                    const size_t e = (size_t)row * nb + b;
+                    cplx out;
+                    if (mode == MODE_RES) {
+                        out = cplx{bv[u].x - av.x, bv[u].y - av.y};
+                    } else if (mode == MODE_ADD) {
+                        out = cplx{bv[u].x + av.x, bv[u].y + av.y};
+                    } else {
+                        cplx dg = {0.0, 0.0};
+                        const double dsg = op.conj_diag ? -1.0 : 1.0;
+                        for (int q = 0; q < npl; ++q) { cplx dq = op.diag[(size_t)row * npl + q]; dq.y *= dsg; cfma(dg, mypc[q], dq); }
+                        if (mode == MODE_AX_J0) {
+                            out = av;
+                            const cplx r = cdiv(av, dg);
+                            const_cast<cplx *>(B)[e] = cplx{jac_w * r.x, jac_w * r.y};
+                        } else if (mode == MODE_AX_DS) {
+                            out = cdiv(av, dg);
+                        } else if (mode == MODE_RES_DS) {
+                            out = cdiv(cplx{bv[u].x - av.x, bv[u].y - av.y}, dg);
+                        } else {
+                            const cplx r = cdiv(cplx{bv[u].x - av.x, bv[u].y - av.y}, dg);
+                            out = cplx{xv[u].x + jac_w * r.x, xv[u].y + jac_w * r.y};
+                        }
+                    }
+                    Y[e] = out;
+                }
             }
         }
-        Y[e] = out;
+        TILE_STAMP(6);
+        buf ^= 1;
+        ch = chn;
     }
 }
 
+#ifdef WAE_TILE_STAMPS
+extern "C" int wae_debug_tile_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wae_tile_stamps), sizeof(unsigned long long) * 8 * 64);
+}
+#endif
 static void launch_spmv_tile(const OpDev &op, const TileDev &td, const cplx *pc, int cps, const cplx *X, cplx *Y, const cplx *B, double jac_w,
                              int nb, int mode, hipStream_t st, const unsigned char *cmask) {
     static bool attr_set = false;
-    const size_t shm = (size_t)(td.wmax > 256 ? td.wmax : 256) * 8 * sizeof(cplx) + (size_t)8 * op.nplanes_total * sizeof(cplx);
+    const size_t wslots = (size_t)(((td.wmax > 512 ? td.wmax : 512) + 7) & ~7);
+    const size_t shm = 2 * wslots * 8 * sizeof(cplx) + (size_t)8 * op.nplanes_total * sizeof(cplx);
+    if (shm > 160 * 1024) throw WaeError(WAE_ERR_INVALID, "tile windows do not fit LDS (WAE_TILE_WCAP too large)");
     if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    const int nch = (nb + 7) / 8;
     const unsigned tpx = (unsigned)((td.ntiles + 7) / 8);
-    const dim3 grid(8u * tpx * (unsigned)nch);
-    if (cps % 8 == 0) hipLaunchKernelGGL(spmv_tile_kernel<true>, grid, dim3(256), shm, st, op, td, pc, cps, X, Y, B, jac_w, nb, mode, cmask);
-    else hipLaunchKernelGGL(spmv_tile_kernel<false>, grid, dim3(256), shm, st, op, td, pc, cps, X, Y, B, jac_w, nb, mode, cmask);
+    const dim3 grid(8u * tpx);
+    if (cps % 8 == 0) hipLaunchKernelGGL(spmv_tile_kernel<true>, grid, dim3(512), shm, st, op, td, pc, cps, X, Y, B, jac_w, nb, mode, cmask);
+    else hipLaunchKernelGGL(spmv_tile_kernel<false>, grid, dim3(512), shm, st, op, td, pc, cps, X, Y, B, jac_w, nb, mode, cmask);
     HIP_CHECK(hipGetLastError());
 }
 
