@@ -129,8 +129,12 @@ static double diag_of(const CsrD &S, int64_t i) {
 
 // Returns P (n x nc).  `skip[i]` != 0 marks penalty (Dirichlet-like) rows: they are neither aggregated nor
 // interpolated (empty P row), so coarse spaces satisfy the essential condition exactly.
-CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double theta, bool smooth) {
+CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double theta, bool smooth, const std::vector<int> *visit) {
     const int64_t n = S.n;
+    // visit (optional): the order in which the greedy passes take the nodes (default: index order).  The library renumbers the
+    // fine rows into tiles (tiles.h); visiting them in the CALLER's order keeps the aggregates -- and with them the whole
+    // hierarchy and the iteration counts -- what they were before the renumbering.
+    auto node = [&](int64_t k) -> int64_t { return visit ? (int64_t)(*visit)[k] : k; };
     std::vector<double> D(n);
     for (int64_t i = 0; i < n; ++i) D[i] = std::fabs(diag_of(S, i));
     // strength graph (symmetric criterion), restricted to non-skipped nodes
@@ -147,7 +151,8 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
     }
     std::vector<int> agg(n, -1);
     int na = 0;
-    for (int64_t i = 0; i < n; ++i) {   // pass 1: root nodes whose whole strong neighbourhood is free
+    for (int64_t k = 0; k < n; ++k) {   // pass 1: root nodes whose whole strong neighbourhood is free
+        const int64_t i = node(k);
         if (skip[i] || agg[i] >= 0 || gptr[i + 1] == gptr[i]) continue;
         bool free_nb = true;
         for (int p = gptr[i]; p < gptr[i + 1]; ++p)
@@ -158,13 +163,15 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
         ++na;
     }
     std::vector<int> agg2(agg);
-    for (int64_t i = 0; i < n; ++i) {   // pass 2: join a neighbouring aggregate
+    for (int64_t k = 0; k < n; ++k) {   // pass 2: join a neighbouring aggregate
+        const int64_t i = node(k);
         if (skip[i] || agg[i] >= 0) continue;
         for (int p = gptr[i]; p < gptr[i + 1]; ++p)
             if (agg[gcol[p]] >= 0) { agg2[i] = agg[gcol[p]]; break; }
     }
     agg.swap(agg2);
-    for (int64_t i = 0; i < n; ++i) {   // pass 3: leftovers form their own aggregates
+    for (int64_t k = 0; k < n; ++k) {   // pass 3: leftovers form their own aggregates
+        const int64_t i = node(k);
         if (skip[i] || agg[i] >= 0) continue;
         agg[i] = na;
         for (int p = gptr[i]; p < gptr[i + 1]; ++p)
@@ -261,7 +268,7 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
 }
 
 void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, const AmgOptions &opt, std::vector<AmgLevel> &levels,
-               std::vector<char> *penalty_rows, const std::vector<zc> *pc_shape) {
+               std::vector<char> *penalty_rows, const std::vector<zc> *pc_shape, const std::vector<int> *visit0) {
     levels.clear();
     const bool dbg = getenv("WAE_SETUP_DEBUG") != nullptr;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -317,7 +324,7 @@ void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, c
     std::vector<CsrZ> cur(planes);
     int64_t n = n0;
     while (n > opt.max_coarse && (int)levels.size() < opt.max_levels) {
-        CsrD P = build_prolongator(S, skip, opt.theta, true);
+        CsrD P = build_prolongator(S, skip, opt.theta, true, levels.empty() ? visit0 : nullptr);
         lap("prolongator");
         if (P.m >= (int64_t)(0.9 * n) || P.m == 0) break;
         CsrD R = csr_transpose(P);

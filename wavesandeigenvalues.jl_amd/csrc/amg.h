@@ -14,10 +14,11 @@ struct AmgLevel {
 };
 CsrZ csr_lincomb(const std::vector<CsrZ> &planes, const std::vector<zc> &coef);
 CsrD galerkin_real(const CsrD &R, const CsrD &A, const CsrD &P);
-CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double theta, bool smooth);
+CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double theta, bool smooth, const std::vector<int> *visit = nullptr);
 // penalty_rows (optional): receives the fine-level flags of the rows detected as penalty (Dirichlet-like) rows
 // pc_shape (optional): plane coefficients of the operator the strength graph / aggregates / prolongator smoothing are taken
 // from, when that should not be the full reference operator (Bloch families: without the seam couplings, so that no
 // aggregate spans the seam across which the solution jumps by exp(i b 2pi/N)).
+// visit0 (optional): order in which the fine-level aggregation visits the nodes (see build_prolongator).
 void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, const AmgOptions &opt, std::vector<AmgLevel> &levels,
-               std::vector<char> *penalty_rows = nullptr, const std::vector<zc> *pc_shape = nullptr);
+               std::vector<char> *penalty_rows = nullptr, const std::vector<zc> *pc_shape = nullptr, const std::vector<int> *visit0 = nullptr);

@@ -373,21 +373,26 @@ __device__ unsigned long long wae_tile_stamps[8 * 64];     // diagnostic build o
 template <bool UNI>
 __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td, const cplx *__restrict__ pc, int cps,
                                                           const cplx *__restrict__ X, cplx *Y, const cplx *B, double jac_w,
-                                                          int nb, int mode, const unsigned char *__restrict__ cmask) {
+                                                          int nb, int mode, const unsigned char *__restrict__ cmask, int spc_all, int csplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
     const int tid = threadIdx.x;
-    const int nch = (nb + 7) >> 3;
+    const int nch_all = (nb + 7) >> 3;
     const int tpx = (td.ntiles + 7) >> 3;                   // workgroup ids are dealt round-robin over the 8 XCDs: XCD k takes the
-    const int tile = (int)(blockIdx.x & 7u) * tpx + (int)(blockIdx.x >> 3);   // k-th contiguous eighth of the tiles (shared halos hit its L2)
+    const int jx = (int)(blockIdx.x >> 3);                  // k-th contiguous eighth of the tiles (shared halos hit its L2).
+    const int tile = (int)(blockIdx.x & 7u) * tpx + jx / csplit;    // csplit > 1 (few tiles per CU): a tile's chunks are shared out
+    const int part = jx - (jx / csplit) * csplit;           // between csplit workgroups that follow each other on the same XCD
     if (tile >= td.ntiles) return;
+    const int ch_begin = part * nch_all / csplit;
+    const int nch = (part + 1) * nch_all / csplit;          // (end of this workgroup's chunk range)
     const int npl = op.nplanes_total;
     const int wslots = ((td.wmax > 512 ? td.wmax : 512) + 7) & ~7;
     cplx *const smem = (cplx *)tile_smem;                   // two window buffers [window slot][8 columns] (offsets, not a pointer
-    cplx *spc = smem + (size_t)wslots * 16;                 // table: the accesses must stay provably LDS), then [8][npl] coefficients
+    cplx *spc0 = smem + (size_t)wslots * 16;                // table: the accesses must stay provably LDS), then the coefficients:
+                                                            // [8][npl] of the current chunk, or (spc_all) [nb][npl] staged once
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: branches on it are uniform)
     const int half = wv >> 2, sl = wv & 3;                   // this wavefront: entries of parity `half` of the rows of slice `sl`
     auto next_active = [&](int c) { while (c < nch && cmask && !cmask[c]) ++c; return c; };
-    int ch = next_active(0);
+    int ch = next_active(ch_begin);
     if (ch >= nch) return;
     // this lane's share of its row of the bulk group -> registers: entries half, half+2, ... (the first KR of them)
     constexpr int KR = 8;
@@ -440,20 +445,29 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
     const int lrow = sl * 64 + lane;                         // this lane's row inside the tile
     int buf = 0;
     issue_window(ch, smem);
+    if (spc_all)
+        for (int i = tid; i < nch_all * 8 * npl; i += 512) {
+            const int cc = i / npl, q = i - cc * npl;
+            spc0[i] = pc[(size_t)((cc < nb ? cc : nb - 1) / cps) * npl + q];
+        }
     while (ch < nch) {
         const int chn = next_active(ch + 1);
         const int col0 = ch * 8;
         TILE_STAMP(0);
-        for (int i = tid; i < 8 * npl; i += 512) {
-            const int cc = i / npl, q = i - cc * npl;
-            int bb = col0 + cc;
-            if (bb >= nb) bb = nb - 1;
-            spc[i] = pc[(size_t)(bb / cps) * npl + q];
-        }
+        cplx *spc = spc0 + (spc_all ? (size_t)col0 * npl : 0);
+        if (!spc_all)
+            for (int i = tid; i < 8 * npl; i += 512) {
+                const int cc = i / npl, q = i - cc * npl;
+                int bb = col0 + cc;
+                if (bb >= nb) bb = nb - 1;
+                spc[i] = pc[(size_t)(bb / cps) * npl + q];
+            }
         __syncthreads();                                     // window of chunk ch has landed (hipcc drains the LDS-DMA before a barrier);
         cplx *win = smem + (size_t)buf * wslots * 8;         // the other buffer's last reader (previous epilogue) is done
         TILE_STAMP(1);
-        if (chn < nch) issue_window(chn, smem + (size_t)(buf ^ 1) * wslots * 8);
+        // The gather of the next window costs ~200 issue cycles per wave instruction: the two wavefronts of a SIMD (w, w+4)
+        // issue theirs at different times -- one before its entries, the other half-way through -- so that one of them computes
+        if (chn < nch && half == 0) issue_window(chn, smem + (size_t)(buf ^ 1) * wslots * 8);
         TILE_STAMP(2);
         cplx acc[8];
 #pragma unroll
@@ -481,10 +495,14 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
             };
             // register-resident part: straight-line code, absent entries are (slot 0, 0.0); the scheduling fences keep two
             // entries' operands in flight (hipcc would otherwise hoist all 64 LDS reads and spill)
+#ifndef TILE_FENCE
+#define TILE_FENCE 4
+#endif
 #pragma unroll
             for (int u = 0; u < KR; ++u) {
                 entry(ixr[u], avr[u]);
-                if (u & 1) __builtin_amdgcn_sched_barrier(0);
+                if ((u + 1) % TILE_FENCE == 0) __builtin_amdgcn_sched_barrier(0);
+                if (u == KR / 2 - 1 && chn < nch && half == 1) issue_window(chn, smem + (size_t)(buf ^ 1) * wslots * 8);
             }
             const unsigned short *__restrict__ si = T0.sidx;
             const double2 *__restrict__ v2 = (const double2 *)T0.svals;
@@ -494,6 +512,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
                 entry(si[e], v2[e]);
             }
         }
+        if (!(fast0 && n0 > 0) && chn < nch && half == 1) issue_window(chn, smem + (size_t)(buf ^ 1) * wslots * 8);
 #pragma unroll 1
         for (int g = fast0 ? 1 : 0; g < op.ngroups; ++g) {   // the other groups (boundary, flame, ... : few entries, most tiles have none)
             const TileGroupDev TG = td.g[g];
@@ -605,7 +624,10 @@ static void launch_spmv_tile(const OpDev &op, const TileDev &td, const cplx *pc,
                              int nb, int mode, hipStream_t st, const unsigned char *cmask) {
     static bool attr_set = false;
     const size_t wslots = (size_t)(((td.wmax > 512 ? td.wmax : 512) + 7) & ~7);
-    const size_t shm = 2 * wslots * 8 * sizeof(cplx) + (size_t)8 * op.nplanes_total * sizeof(cplx);
+    const int nch8 = ((nb + 7) / 8) * 8;
+    size_t shm = 2 * wslots * 8 * sizeof(cplx) + (size_t)nch8 * op.nplanes_total * sizeof(cplx);   // coefficients of all chunks staged once ...
+    const int spc_all = shm <= 160 * 1024;
+    if (!spc_all) shm = 2 * wslots * 8 * sizeof(cplx) + (size_t)8 * op.nplanes_total * sizeof(cplx);   // ... or chunk by chunk
     if (shm > 160 * 1024) throw WaeError(WAE_ERR_INVALID, "tile windows do not fit LDS (WAE_TILE_WCAP too large)");
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -613,9 +635,16 @@ static void launch_spmv_tile(const OpDev &op, const TileDev &td, const cplx *pc,
         attr_set = true;
     }
     const unsigned tpx = (unsigned)((td.ntiles + 7) / 8);
-    const dim3 grid(8u * tpx);
-    if (cps % 8 == 0) hipLaunchKernelGGL(spmv_tile_kernel<true>, grid, dim3(512), shm, st, op, td, pc, cps, X, Y, B, jac_w, nb, mode, cmask);
-    else hipLaunchKernelGGL(spmv_tile_kernel<false>, grid, dim3(512), shm, st, op, td, pc, cps, X, Y, B, jac_w, nb, mode, cmask);
+    // one workgroup per tile unless there are fewer tiles than CUs: then the chunks of a tile are shared out.  (Sharing them
+    // out as soon as a CU had fewer than 8 tiles was measured and is slower -- 200k DoF, 780 tiles: 229 -> 259 us; 500k DoF:
+    // 519 -> 547 us: the matrix slice is re-loaded and the window pipeline restarts per workgroup.)
+    const int nchunks = (nb + 7) / 8;
+    int csplit = (int)((256 + td.ntiles - 1) / td.ntiles);
+    if (csplit > nchunks) csplit = nchunks;
+    if (csplit < 1) csplit = 1;
+    const dim3 grid(8u * tpx * (unsigned)csplit);
+    if (cps % 8 == 0) hipLaunchKernelGGL(spmv_tile_kernel<true>, grid, dim3(512), shm, st, op, td, pc, cps, X, Y, B, jac_w, nb, mode, cmask, spc_all, csplit);
+    else hipLaunchKernelGGL(spmv_tile_kernel<false>, grid, dim3(512), shm, st, op, td, pc, cps, X, Y, B, jac_w, nb, mode, cmask, spc_all, csplit);
     HIP_CHECK(hipGetLastError());
 }
 

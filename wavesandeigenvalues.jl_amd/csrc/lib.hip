@@ -1339,7 +1339,10 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
             plane_coeffs(h, cs.data(), WAE_OP_N, pc_shape);
         }
         const double t_amg0 = now_s();
-        amg_setup(h->planes0, pc, ao, lv, &pen, excl ? &pc_shape : nullptr);
+        // fine-level aggregation in the caller's node order (iperm[o] = internal index of the caller's node o)
+        std::vector<int> visit0;
+        if (!h->perm_h.empty()) { visit0.resize(h->perm_h.size()); for (size_t i = 0; i < h->perm_h.size(); ++i) visit0[h->perm_h[i]] = (int)i; }
+        amg_setup(h->planes0, pc, ao, lv, &pen, excl ? &pc_shape : nullptr, visit0.empty() ? nullptr : &visit0);
         const double t_amg1 = now_s();
         if (getenv("WAE_SETUP_DEBUG")) {
             fprintf(stderr, "[setup] amg_setup (host) %.3f s\n", t_amg1 - t_amg0);
