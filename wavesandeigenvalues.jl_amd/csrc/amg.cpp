@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <future>
+#include <thread>
 
 template <class V> static void transpose_impl(int64_t n, int64_t m, const std::vector<int> &ptr, const std::vector<int> &col,
                                               const std::vector<V> &val, std::vector<int> &tptr, std::vector<int> &tcol, std::vector<V> &tval) {
@@ -38,60 +39,103 @@ CsrD csr_transpose(const CsrD &A) {
 }
 bool csr_same_pattern(const CsrZ &A, const CsrZ &B) { return A.n == B.n && A.m == B.m && A.ptr == B.ptr && A.col == B.col; }
 
+// Host threads for the set-up (the set-up is part of the metric: one cold solver call = set-up + pass).  The row loops below are
+// cut into contiguous chunks, one per thread, each with its own marker / accumulator and output vectors, stitched afterwards:
+// the result is the serial one bit for bit (per row the same operations in the same order).
+static int setup_threads() {
+    static const int n = []() {
+        if (const char *e = getenv("WAE_SETUP_THREADS")) return std::max(1, atoi(e));
+        return (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    }();
+    return n;
+}
+// runs body(lo, hi, part) over nparts contiguous row ranges of [0, n) on as many threads
+template <class F> static void parallel_ranges(int64_t n, int nparts, F &&body) {
+    nparts = (int)std::max<int64_t>(1, std::min<int64_t>(nparts, n / 4096 + 1));
+    if (nparts == 1) { body((int64_t)0, n, 0); return; }
+    std::vector<std::future<void>> jobs;
+    for (int t = 0; t < nparts; ++t) {
+        const int64_t lo = n * t / nparts, hi = n * (t + 1) / nparts;
+        jobs.push_back(std::async(std::launch::async, [&body, lo, hi, t]() { body(lo, hi, t); }));
+    }
+    for (auto &j : jobs) j.get();
+}
+// stitches per-part (col, val) pieces; ptr holds per-row counts in ptr[i+1] on entry
+template <class V> static void stitch(int64_t n, int nparts, std::vector<int> &ptr, std::vector<std::vector<int>> &pcol, std::vector<std::vector<V>> &pval,
+                                      std::vector<int> &col, std::vector<V> &val) {
+    for (int64_t i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
+    col.resize((size_t)ptr[n]);
+    val.resize((size_t)ptr[n]);
+    size_t off = 0;
+    for (size_t t = 0; t < pcol.size(); ++t) {
+        std::copy(pcol[t].begin(), pcol[t].end(), col.begin() + off);
+        std::copy(pval[t].begin(), pval[t].end(), val.begin() + off);
+        off += pcol[t].size();
+    }
+}
+
 // C = A * B   (row-wise Gustavson with a dense marker; columns sorted; structural zeros kept so that planes
 // with equal patterns keep equal patterns after projection)
 template <class VA, class VB, class VC>
 static void spgemm(int64_t n, int64_t m, const std::vector<int> &aptr, const std::vector<int> &acol, const std::vector<VA> &aval,
                    const std::vector<int> &bptr, const std::vector<int> &bcol, const std::vector<VB> &bval, std::vector<int> &cptr,
-                   std::vector<int> &ccol, std::vector<VC> &cval) {
+                   std::vector<int> &ccol, std::vector<VC> &cval, int nthreads = 1) {
     cptr.assign(n + 1, 0);
-    ccol.clear();
-    cval.clear();
-    std::vector<int> marker(m, -1);
-    std::vector<VC> acc(m);
-    std::vector<int> list;
-    for (int64_t i = 0; i < n; ++i) {
-        list.clear();
-        for (int p = aptr[i]; p < aptr[i + 1]; ++p) {
-            const int k = acol[p];
-            const VA a = aval[p];
-            for (int q = bptr[k]; q < bptr[k + 1]; ++q) {
-                const int c = bcol[q];
-                if (marker[c] != (int)i) {
-                    marker[c] = (int)i;
-                    acc[c] = VC(0);
-                    list.push_back(c);
+    const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(nthreads, n / 4096 + 1));
+    std::vector<std::vector<int>> pcol(nparts);
+    std::vector<std::vector<VC>> pval(nparts);
+    parallel_ranges(n, nparts, [&](int64_t lo, int64_t hi, int part) {
+        std::vector<int> marker(m, -1);
+        std::vector<VC> acc(m);
+        std::vector<int> list;
+        std::vector<int> &oc = pcol[part];
+        std::vector<VC> &ov = pval[part];
+        for (int64_t i = lo; i < hi; ++i) {
+            list.clear();
+            for (int p = aptr[i]; p < aptr[i + 1]; ++p) {
+                const int k = acol[p];
+                const VA a = aval[p];
+                for (int q = bptr[k]; q < bptr[k + 1]; ++q) {
+                    const int c = bcol[q];
+                    if (marker[c] != (int)i) {
+                        marker[c] = (int)i;
+                        acc[c] = VC(0);
+                        list.push_back(c);
+                    }
+                    acc[c] += VC(a) * VC(bval[q]);
                 }
-                acc[c] += VC(a) * VC(bval[q]);
             }
+            std::sort(list.begin(), list.end());
+            for (int c : list) {
+                oc.push_back(c);
+                ov.push_back(acc[c]);
+            }
+            cptr[i + 1] = (int)list.size();
         }
-        std::sort(list.begin(), list.end());
-        for (int c : list) {
-            ccol.push_back(c);
-            cval.push_back(acc[c]);
-        }
-        cptr[i + 1] = (int)ccol.size();
-    }
+    });
+    stitch(n, nparts, cptr, pcol, pval, ccol, cval);
 }
 
-CsrZ galerkin(const CsrD &R, const CsrZ &A, const CsrD &P) {
+CsrZ galerkin(const CsrD &R, const CsrZ &A, const CsrD &P, int nthreads) {
     CsrZ T;
     T.n = A.n; T.m = P.m;
-    spgemm<zc, double, zc>(A.n, P.m, A.ptr, A.col, A.val, P.ptr, P.col, P.val, T.ptr, T.col, T.val);
+    spgemm<zc, double, zc>(A.n, P.m, A.ptr, A.col, A.val, P.ptr, P.col, P.val, T.ptr, T.col, T.val, nthreads);
     CsrZ C;
     C.n = R.n; C.m = P.m;
-    spgemm<double, zc, zc>(R.n, P.m, R.ptr, R.col, R.val, T.ptr, T.col, T.val, C.ptr, C.col, C.val);
+    spgemm<double, zc, zc>(R.n, P.m, R.ptr, R.col, R.val, T.ptr, T.col, T.val, C.ptr, C.col, C.val, nthreads);
     return C;
 }
-CsrD galerkin_real(const CsrD &R, const CsrD &A, const CsrD &P) {
+CsrZ galerkin(const CsrD &R, const CsrZ &A, const CsrD &P) { return galerkin(R, A, P, 1); }
+CsrD galerkin_real(const CsrD &R, const CsrD &A, const CsrD &P, int nthreads) {
     CsrD T;
     T.n = A.n; T.m = P.m;
-    spgemm<double, double, double>(A.n, P.m, A.ptr, A.col, A.val, P.ptr, P.col, P.val, T.ptr, T.col, T.val);
+    spgemm<double, double, double>(A.n, P.m, A.ptr, A.col, A.val, P.ptr, P.col, P.val, T.ptr, T.col, T.val, nthreads);
     CsrD C;
     C.n = R.n; C.m = P.m;
-    spgemm<double, double, double>(R.n, P.m, R.ptr, R.col, R.val, T.ptr, T.col, T.val, C.ptr, C.col, C.val);
+    spgemm<double, double, double>(R.n, P.m, R.ptr, R.col, R.val, T.ptr, T.col, T.val, C.ptr, C.col, C.val, nthreads);
     return C;
 }
+CsrD galerkin_real(const CsrD &R, const CsrD &A, const CsrD &P) { return galerkin_real(R, A, P, 1); }
 
 CsrZ csr_lincomb(const std::vector<CsrZ> &planes, const std::vector<zc> &coef) {
     CsrZ C;
@@ -99,22 +143,28 @@ CsrZ csr_lincomb(const std::vector<CsrZ> &planes, const std::vector<zc> &coef) {
     const int64_t n = planes[0].n, m = planes[0].m;
     C.n = n; C.m = m;
     C.ptr.assign(n + 1, 0);
-    std::vector<int> marker(m, -1), list;
-    std::vector<zc> acc(m);
-    for (int64_t i = 0; i < n; ++i) {
-        list.clear();
-        for (size_t k = 0; k < planes.size(); ++k) {
-            const CsrZ &A = planes[k];
-            for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) {
-                const int c = A.col[p];
-                if (marker[c] != (int)i) { marker[c] = (int)i; acc[c] = 0; list.push_back(c); }
-                acc[c] += coef[k] * A.val[p];
+    const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(setup_threads(), n / 4096 + 1));
+    std::vector<std::vector<int>> pcol(nparts);
+    std::vector<std::vector<zc>> pval(nparts);
+    parallel_ranges(n, nparts, [&](int64_t lo, int64_t hi, int part) {
+        std::vector<int> marker(m, -1), list;
+        std::vector<zc> acc(m);
+        for (int64_t i = lo; i < hi; ++i) {
+            list.clear();
+            for (size_t k = 0; k < planes.size(); ++k) {
+                const CsrZ &A = planes[k];
+                for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) {
+                    const int c = A.col[p];
+                    if (marker[c] != (int)i) { marker[c] = (int)i; acc[c] = 0; list.push_back(c); }
+                    acc[c] += coef[k] * A.val[p];
+                }
             }
+            std::sort(list.begin(), list.end());
+            for (int c : list) { pcol[part].push_back(c); pval[part].push_back(acc[c]); }
+            C.ptr[i + 1] = (int)list.size();
         }
-        std::sort(list.begin(), list.end());
-        for (int c : list) { C.col.push_back(c); C.val.push_back(acc[c]); }
-        C.ptr[i + 1] = (int)C.col.size();
-    }
+    });
+    stitch(n, nparts, C.ptr, pcol, pval, C.col, C.val);
     return C;
 }
 
@@ -224,13 +274,15 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
     for (int64_t i = 0; i < n; ++i) { lcg ^= lcg << 13; lcg ^= lcg >> 7; lcg ^= lcg << 17; x[i] = (double)(lcg % 2000) / 1000.0 - 1.0; }
     double rho = 1.0;
     for (int it = 0; it < 20; ++it) {
-        double nrm = 0.0;
-        for (int64_t i = 0; i < n; ++i) {
-            double s = 0.0;
-            for (int p = F.ptr[i]; p < F.ptr[i + 1]; ++p) s += F.val[p] * x[F.col[p]];
-            y[i] = s / Fd[i];
-            nrm += y[i] * y[i];
-        }
+        parallel_ranges(n, setup_threads(), [&](int64_t lo, int64_t hi, int) {
+            for (int64_t i = lo; i < hi; ++i) {
+                double s = 0.0;
+                for (int p = F.ptr[i]; p < F.ptr[i + 1]; ++p) s += F.val[p] * x[F.col[p]];
+                y[i] = s / Fd[i];
+            }
+        });
+        double nrm = 0.0;                                    // (serial sum: the result does not depend on the thread count)
+        for (int64_t i = 0; i < n; ++i) nrm += y[i] * y[i];
         nrm = std::sqrt(nrm);
         if (nrm == 0.0) break;
         rho = nrm;
@@ -241,7 +293,7 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
     // P = Pt - omega * D^-1 F Pt
     CsrD FP;
     FP.n = n; FP.m = na;
-    spgemm<double, double, double>(n, na, F.ptr, F.col, F.val, Pt.ptr, Pt.col, Pt.val, FP.ptr, FP.col, FP.val);
+    spgemm<double, double, double>(n, na, F.ptr, F.col, F.val, Pt.ptr, Pt.col, Pt.val, FP.ptr, FP.col, FP.val, setup_threads());
     CsrD P;
     P.n = n; P.m = na;
     P.ptr.assign(n + 1, 0);
@@ -334,9 +386,10 @@ void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, c
         std::vector<CsrZ> next(cur.size());
         {
             std::vector<std::future<void>> jobs;
+            const int inner = std::max(1, setup_threads() / (int)(cur.size() + 1));     // threads per triple product
             for (size_t q = 0; q < cur.size(); ++q)
-                jobs.push_back(std::async(std::launch::async, [&, q]() { next[q] = galerkin(R, cur[q], P); }));
-            CsrD Snext = galerkin_real(R, S, P);
+                jobs.push_back(std::async(std::launch::async, [&, q]() { next[q] = galerkin(R, cur[q], P, inner); }));
+            CsrD Snext = galerkin_real(R, S, P, inner);
             for (auto &j : jobs) j.get();
             S = std::move(Snext);
         }
