@@ -136,6 +136,21 @@ int wae_beyn_moments(wae_family *h, int32_t npts, const double *z, const double 
                      const double *V, int32_t l, int32_t K, double tol, int32_t maxit, double *A_out,
                      uint64_t out_dev, wae_solve_info *info);
 
+/* -- Beyn moments on several GPUs of one node, from ONE host process (SURVEY.md 8b `beyn_moments(..., ngpu)`, 8e) ------------
+ * The quadrature loop of `beyn` / `compute_moment_matrices` (beyn.jl:62-74,112-138,251-268) with its points shared out over
+ * ngpu devices.  handles[g]: a replica of the family on device g (wae_family_create(..., device = g) + wae_solver_setup with
+ * the same arguments on each; distinct devices); the library runs one host thread and one stream per device.  nsnap > 0 (and
+ * npts >= 2 nsnap): the snapshot-projection scheme of wae_beyn_moments_rb -- nsnap snapshot points solved first, split over
+ * the devices by probe column when ngpu divides l (every device finishes the basis of its columns; the bases are exchanged
+ * with one RCCL all-gather over xGMI), otherwise by point (raw snapshots all-gathered, every device rebuilds the basis); the
+ * other points start from the projection, round-robin over the devices.  nsnap = 0: every point from a zero guess.  The
+ * partial moment tensors are summed on device 0 with one RCCL reduce and copied to A_out (host, d x l x 2K column-major).
+ * RCCL is loaded at first use (dlopen of librccl.so.1); ngpu = 1 runs the same code with one rank.  info: maxima / sums over
+ * all devices.  Everything else as wae_beyn_moments. */
+int wae_beyn_moments_mgpu(wae_family *const *handles, int32_t ngpu, int32_t npts, const double *z, const double *w,
+                          const double *coeff_table, const double *V, int32_t l, int32_t K, double tol, int32_t maxit,
+                          int32_t nsnap, double *A_out, wae_solve_info *info);
+
 /* -- residual check of eigenpairs (the last step of `beyn`'s callers: which Ritz pairs are eigenpairs) --------------
  * res_out[j] = || sum_k c_jk A_k v_j || / sum_k |c_jk| || A_k v_j ||   for the n pairs (coeff_table: n x T complex, row j =
  * the coefficients of L(omega_j); v_j = column j of the column-major d x n matrix P on the host, or P_dev on the device).

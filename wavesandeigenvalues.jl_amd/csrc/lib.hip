@@ -118,6 +118,9 @@ struct wae_family {
     }
 };
 
+int wae_internal_device(const wae_family *h) { return h->device; }
+hipStream_t wae_internal_stream(const wae_family *h) { return h->stream; }
+
 static bool plane_is_real(const CsrZ &A) {
     for (const zc &v : A.val)
         if (v.imag() != 0.0) return false;

@@ -1,0 +1,306 @@
+// wae_beyn_moments_mgpu -- the Beyn quadrature of ONE host process spread over several GPUs of a node (SURVEY.md 8b:
+// `beyn_moments(..., ngpu)`, 8e).  The reference has nothing to port here (serial Julia); the structure follows what the
+// hot path offers: quadrature points are independent, so every GPU holds a replica of the family (one handle per device,
+// created and set up by the caller), takes a share of the work on its own stream under its own host thread, and the only
+// data exchanged over xGMI are (i) the snapshot bases of the projected-guess scheme -- one RCCL all-gather -- and (ii) the
+// partial moment tensors -- one RCCL sum-reduce to device 0.
+//
+// RCCL is bound at first use with dlopen: libwaehip.so carries no link-time dependency on it (a host that already has an
+// RCCL in the process -- PyTorch ships its own -- keeps using that one).
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <functional>
+#include <future>
+#include <mutex>
+
+#include "wae_internal.h"
+
+namespace {
+
+// ---- minimal RCCL binding (types and constants as in <rccl/rccl.h>) ----------------------------------------------------
+typedef struct ncclComm *ncclComm_t;
+enum { NCCL_SUCCESS = 0 };
+enum { NCCL_DOUBLE = 8 };           // ncclFloat64
+enum { NCCL_SUM = 0 };
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Reduce)(const void *, void *, size_t, int, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl &rccl() {
+    static Rccl R;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            R.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (R.lib) break;
+        }
+        if (!R.lib) return;
+        R.CommInitAll = (decltype(R.CommInitAll))dlsym(R.lib, "ncclCommInitAll");
+        R.CommDestroy = (decltype(R.CommDestroy))dlsym(R.lib, "ncclCommDestroy");
+        R.GroupStart = (decltype(R.GroupStart))dlsym(R.lib, "ncclGroupStart");
+        R.GroupEnd = (decltype(R.GroupEnd))dlsym(R.lib, "ncclGroupEnd");
+        R.AllGather = (decltype(R.AllGather))dlsym(R.lib, "ncclAllGather");
+        R.Reduce = (decltype(R.Reduce))dlsym(R.lib, "ncclReduce");
+        R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.lib, "ncclGetErrorString");
+    });
+    return R;
+}
+void nccl_check(int rc, const char *what) {
+    if (rc != NCCL_SUCCESS) {
+        const Rccl &R = rccl();
+        throw WaeError(WAE_ERR_HIP, std::string("RCCL ") + what + ": " + (R.GetErrorString ? R.GetErrorString(rc) : "error"));
+    }
+}
+
+// communicators are kept per device list (creating them costs ~100 ms)
+struct CommSet {
+    std::vector<int> devs;
+    std::vector<ncclComm_t> comms;
+};
+std::vector<CommSet> &comm_cache() { static std::vector<CommSet> c; return c; }
+const std::vector<ncclComm_t> &comms_for(const std::vector<int> &devs) {
+    for (const CommSet &c : comm_cache())
+        if (c.devs == devs) return c.comms;
+    const Rccl &R = rccl();
+    if (!R.lib || !R.CommInitAll || !R.AllGather || !R.Reduce || !R.GroupStart || !R.GroupEnd)
+        throw WaeError(WAE_ERR_HIP, "RCCL (librccl.so) could not be loaded: wae_beyn_moments_mgpu needs it for more than one GPU");
+    CommSet c;
+    c.devs = devs;
+    c.comms.resize(devs.size());
+    nccl_check(R.CommInitAll(c.comms.data(), (int)devs.size(), devs.data()), "ncclCommInitAll");
+    comm_cache().push_back(c);
+    return comm_cache().back().comms;
+}
+
+// slabs[g][s][row][c_local]  ->  store[s][row][g*ls + c_local]   (the probe columns back in order after the all-gather)
+__global__ __launch_bounds__(256) void merge_slabs_kernel(const cplx *__restrict__ slabs, cplx *__restrict__ store, int G, int S, int64_t d, int ls) {
+    const size_t total = (size_t)S * d * G * ls;
+    const int l = G * ls;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e % l);
+        const size_t sr = e / l;                             // s * d + row
+        const int g = c / ls, cl = c - g * ls;
+        store[e] = slabs[((size_t)g * S * d + sr) * ls + cl];
+    }
+}
+
+// S snapshot points spread evenly through n points, bit-reversal ("every prefix covers the contour") order; the rest
+void snapshot_plan(int n, int S, std::vector<int> &snap, std::vector<int> &rest) {
+    S = std::min(S, n);
+    std::vector<int> idx;
+    for (int i = 0; i < S; ++i) {
+        const int v = (int)(((double)i + 0.5) * n / std::max(S, 1));
+        if (idx.empty() || idx.back() != v) idx.push_back(v);
+    }
+    std::vector<char> is_snap(n, 0);
+    for (int v : idx) is_snap[v] = 1;
+    rest.clear();
+    for (int i = 0; i < n; ++i)
+        if (!is_snap[i]) rest.push_back(i);
+    const int m = (int)idx.size();
+    if (m < 3) { snap = idx; return; }
+    int bits = 1;
+    while ((1 << bits) < m) ++bits;
+    std::vector<std::pair<int, int>> key(m);
+    for (int i = 0; i < m; ++i) {
+        int r = 0;
+        for (int b = 0; b < bits; ++b)
+            if (i >> b & 1) r |= 1 << (bits - 1 - b);
+        key[i] = {r, i};
+    }
+    std::stable_sort(key.begin(), key.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first < b.first; });
+    snap.resize(m);
+    for (int i = 0; i < m; ++i) snap[i] = idx[key[i].second];
+}
+
+template <class T> std::vector<T> take(const T *src, const std::vector<int> &rows, int width) {
+    std::vector<T> out((size_t)rows.size() * width);
+    for (size_t i = 0; i < rows.size(); ++i) std::copy(src + (size_t)rows[i] * width, src + (size_t)(rows[i] + 1) * width, out.begin() + i * width);
+    return out;
+}
+
+}   // namespace
+
+extern "C" int wae_beyn_moments_mgpu(wae_family *const *handles, int32_t ngpu, int32_t npts, const double *z, const double *w, const double *coeff_table,
+                                     const double *V, int32_t l, int32_t K, double tol, int32_t maxit, int32_t nsnap, double *A_out,
+                                     wae_solve_info *info) {
+    try {
+        WAE_REQUIRE(handles && ngpu >= 1 && ngpu <= 64 && npts >= 0 && (npts == 0 || (z && w && coeff_table)) && V && l > 0 && K > 0 && A_out,
+                    "bad argument");
+        int64_t d = 0;
+        int32_t T = 0;
+        std::vector<int> devs(ngpu);
+        std::vector<hipStream_t> streams(ngpu);
+        for (int g = 0; g < ngpu; ++g) {
+            WAE_REQUIRE(handles[g], "null handle");
+            int64_t dg = 0;
+            int32_t Tg = 0;
+            if (wae_family_info(handles[g], &dg, &Tg, nullptr) != WAE_OK) throw WaeError(WAE_ERR_INVALID, wae_last_error());
+            if (g == 0) { d = dg; T = Tg; }
+            WAE_REQUIRE(dg == d && Tg == T, "the handles are not replicas of one family");
+            devs[g] = wae_internal_device(handles[g]);
+            streams[g] = wae_internal_stream(handles[g]);
+            for (int q = 0; q < g; ++q) WAE_REQUIRE(devs[q] != devs[g], "two handles on one device");
+        }
+        const std::vector<ncclComm_t> &comms = comms_for(devs);
+        const Rccl &R = rccl();
+        const int npow = 2 * K;
+        const size_t acnt = (size_t)d * l * npow;
+        wae_solve_info tot;
+        memset(&tot, 0, sizeof(tot));
+        const auto t_begin = std::chrono::steady_clock::now();
+        // per-device moment buffers
+        std::vector<DevBuf<cplx>> Ad(ngpu), local(ngpu), slabs(ngpu), store(ngpu);
+        for (int g = 0; g < ngpu; ++g) {
+            HIP_CHECK(hipSetDevice(devs[g]));
+            Ad[g].alloc(acnt);
+            HIP_CHECK(hipMemsetAsync(Ad[g].p, 0, acnt * sizeof(cplx), streams[g]));
+            HIP_CHECK(hipStreamSynchronize(streams[g]));
+        }
+        std::vector<int> snap, rest;
+        if (nsnap > 0 && npts >= 2 * nsnap) snapshot_plan(npts, nsnap, snap, rest);
+        else { rest.resize(npts); for (int i = 0; i < npts; ++i) rest[i] = i; }
+        const int S = (int)snap.size();
+        // runs f(g) on one host thread per device and folds the solve statistics / the first error
+        auto on_all = [&](const std::function<int(int, wae_solve_info *)> &f) {
+            std::vector<std::future<std::pair<int, std::string>>> jobs;
+            std::vector<wae_solve_info> infos(ngpu);
+            for (int g = 0; g < ngpu; ++g)
+                jobs.push_back(std::async(std::launch::async, [&, g]() {
+                    memset(&infos[g], 0, sizeof(wae_solve_info));
+                    const int rc = f(g, &infos[g]);
+                    return std::make_pair(rc, rc < 0 ? std::string(wae_last_error()) : std::string());
+                }));
+            int worst = 0;
+            std::string msg;
+            for (int g = 0; g < ngpu; ++g) {
+                auto r = jobs[g].get();
+                if (r.first < 0 && worst >= 0) { worst = r.first; msg = "device " + std::to_string(devs[g]) + ": " + r.second; }
+                else if (r.first > worst && worst >= 0) worst = r.first;
+                tot.iters_max = std::max(tot.iters_max, infos[g].iters_max);
+                tot.iters_total += infos[g].iters_total;
+                tot.n_unconverged += infos[g].n_unconverged;
+                tot.levels = std::max(tot.levels, infos[g].levels);
+                tot.relres_max = std::max(tot.relres_max, infos[g].relres_max);
+            }
+            if (worst < 0) throw WaeError(worst, msg);
+            return worst;
+        };
+        int code = 0;
+        const size_t vecl_all = (size_t)d * l;
+        if (S == 0) {
+            // no snapshot scheme: every device integrates its share of the points from zero guesses
+            code = std::max(code, on_all([&](int g, wae_solve_info *li) {
+                std::vector<int> mine;
+                for (size_t i = g; i < rest.size(); i += ngpu) mine.push_back(rest[i]);
+                const auto zz = take(z, mine, 2), ww = take(w, mine, 2), cc = take(coeff_table, mine, 2 * T);
+                return wae_beyn_moments(handles[g], (int32_t)mine.size(), zz.data(), ww.data(), cc.data(), V, l, K, tol, maxit, nullptr,
+                                        (uint64_t)(uintptr_t)Ad[g].p, li);
+            }));
+        } else if (l % ngpu == 0) {
+            // (1) snapshot phase split by PROBE COLUMN: device g solves all S snapshot points for its l/ngpu columns and ends with a
+            // finished basis for them; (2) all-gather of the basis vectors, exchange of the small projected terms on the host;
+            // (3) the remaining points round-robin, every system from the projection on the full basis
+            const int ls = l / ngpu;
+            const size_t slab = (size_t)S * d * ls;
+            const auto zs = take(z, snap, 2), ws = take(w, snap, 2), cs = take(coeff_table, snap, 2 * T);
+            for (int g = 0; g < ngpu; ++g) { HIP_CHECK(hipSetDevice(devs[g])); local[g].alloc(slab); slabs[g].alloc(slab * ngpu); store[g].alloc(slab * ngpu); }
+            code = std::max(code, on_all([&](int g, wae_solve_info *li) {
+                return wae_beyn_moments_rb(handles[g], S, zs.data(), ws.data(), cs.data(), V + (size_t)2 * d * g * ls, ls, K, tol, maxit, 0, S, 0,
+                                           (uint64_t)(uintptr_t)local[g].p, nullptr, (uint64_t)(uintptr_t)Ad[g].p, 1, l, g * ls, li);
+            }));
+            nccl_check(R.GroupStart(), "ncclGroupStart");
+            for (int g = 0; g < ngpu; ++g)
+                nccl_check(R.AllGather(local[g].p, slabs[g].p, slab * 2, NCCL_DOUBLE, comms[g], streams[g]), "ncclAllGather");
+            nccl_check(R.GroupEnd(), "ncclGroupEnd");
+            // projected terms and right-hand-side projections of every device's columns
+            int32_t Sx = 0, lx = 0, nk = 0;
+            if (wae_rb_export(handles[0], &Sx, &lx, &nk, nullptr, nullptr, nullptr) != WAE_OK) throw WaeError(WAE_ERR_INVALID, wae_last_error());
+            WAE_REQUIRE(Sx == S && lx == ls, "snapshot basis has an unexpected shape");
+            std::vector<int32_t> kact(std::max(nk, 1));
+            std::vector<double> Hk_all((size_t)nk * S * S * l * 2), g_all((size_t)S * l * 2), Hk((size_t)nk * S * S * ls * 2), gg((size_t)S * ls * 2);
+            for (int g = 0; g < ngpu; ++g) {
+                int32_t S2, l2, nk2;
+                if (wae_rb_export(handles[g], &S2, &l2, &nk2, kact.data(), Hk.data(), gg.data()) != WAE_OK) throw WaeError(WAE_ERR_INVALID, wae_last_error());
+                WAE_REQUIRE(S2 == S && l2 == ls && nk2 == nk, "the devices' snapshot bases differ in shape");
+                for (size_t a = 0; a < (size_t)nk * S * S; ++a)           // [ki][s][i][c]: c fastest
+                    std::copy(Hk.begin() + a * ls * 2, Hk.begin() + (a + 1) * ls * 2, Hk_all.begin() + (a * l + (size_t)g * ls) * 2);
+                for (size_t a = 0; a < (size_t)S; ++a)
+                    std::copy(gg.begin() + a * ls * 2, gg.begin() + (a + 1) * ls * 2, g_all.begin() + (a * l + (size_t)g * ls) * 2);
+            }
+            for (int g = 0; g < ngpu; ++g) {
+                HIP_CHECK(hipSetDevice(devs[g]));
+                hipLaunchKernelGGL(merge_slabs_kernel, dim3(4096), dim3(256), 0, streams[g], slabs[g].p, store[g].p, ngpu, S, d, ls);
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipStreamSynchronize(streams[g]));
+                if (wae_rb_import(handles[g], S, l, (uint64_t)(uintptr_t)store[g].p, nk, kact.data(), Hk_all.data(), g_all.data()) != WAE_OK)
+                    throw WaeError(WAE_ERR_INVALID, wae_last_error());
+            }
+            code = std::max(code, on_all([&](int g, wae_solve_info *li) {
+                std::vector<int> mine;
+                for (size_t i = g; i < rest.size(); i += ngpu) mine.push_back(rest[i]);
+                const auto zz = take(z, mine, 2), ww = take(w, mine, 2), cc = take(coeff_table, mine, 2 * T);
+                return wae_beyn_moments_rb(handles[g], (int32_t)mine.size(), zz.data(), ww.data(), cc.data(), V, l, K, tol, maxit, 2, S, 0,
+                                           (uint64_t)(uintptr_t)store[g].p, nullptr, (uint64_t)(uintptr_t)Ad[g].p, 1, 0, 0, li);
+            }));
+        } else {
+            // l not divisible by the number of devices: the snapshot POINTS are split, the raw snapshots all-gathered, and every
+            // device rebuilds the (same) basis from them (mode 1)
+            const int per = S / ngpu;
+            WAE_REQUIRE(per >= 1, "fewer snapshot points than devices");
+            const int Su = per * ngpu;                          // snapshots actually used; the others join the remaining points
+            for (int i = Su; i < S; ++i) rest.push_back(snap[i]);
+            const size_t slab = (size_t)per * vecl_all;
+            for (int g = 0; g < ngpu; ++g) { HIP_CHECK(hipSetDevice(devs[g])); local[g].alloc(slab); store[g].alloc(slab * ngpu); }
+            code = std::max(code, on_all([&](int g, wae_solve_info *li) {
+                std::vector<int> mine;
+                for (int i = g; i < Su; i += ngpu) mine.push_back(snap[i]);
+                const auto zz = take(z, mine, 2), ww = take(w, mine, 2), cc = take(coeff_table, mine, 2 * T);
+                return wae_beyn_moments_rb(handles[g], per, zz.data(), ww.data(), cc.data(), V, l, K, tol, maxit, 0, per, 0,
+                                           (uint64_t)(uintptr_t)local[g].p, nullptr, (uint64_t)(uintptr_t)Ad[g].p, 1, 0, 0, li);
+            }));
+            nccl_check(R.GroupStart(), "ncclGroupStart");
+            for (int g = 0; g < ngpu; ++g)
+                nccl_check(R.AllGather(local[g].p, store[g].p, slab * 2, NCCL_DOUBLE, comms[g], streams[g]), "ncclAllGather");
+            nccl_check(R.GroupEnd(), "ncclGroupEnd");
+            for (int g = 0; g < ngpu; ++g) { HIP_CHECK(hipSetDevice(devs[g])); HIP_CHECK(hipStreamSynchronize(streams[g])); }
+            code = std::max(code, on_all([&](int g, wae_solve_info *li) {
+                std::vector<int> mine;
+                for (size_t i = g; i < rest.size(); i += ngpu) mine.push_back(rest[i]);
+                const auto zz = take(z, mine, 2), ww = take(w, mine, 2), cc = take(coeff_table, mine, 2 * T);
+                return wae_beyn_moments_rb(handles[g], (int32_t)mine.size(), zz.data(), ww.data(), cc.data(), V, l, K, tol, maxit, 1, Su, Su,
+                                           (uint64_t)(uintptr_t)store[g].p, nullptr, (uint64_t)(uintptr_t)Ad[g].p, 1, 0, 0, li);
+            }));
+        }
+        // sum of the partial moment tensors on device 0 (in place), then to the host
+        nccl_check(R.GroupStart(), "ncclGroupStart");
+        for (int g = 0; g < ngpu; ++g)
+            nccl_check(R.Reduce(Ad[g].p, Ad[g].p, acnt * 2, NCCL_DOUBLE, NCCL_SUM, 0, comms[g], streams[g]), "ncclReduce");
+        nccl_check(R.GroupEnd(), "ncclGroupEnd");
+        for (int g = 0; g < ngpu; ++g) { HIP_CHECK(hipSetDevice(devs[g])); HIP_CHECK(hipStreamSynchronize(streams[g])); }
+        HIP_CHECK(hipSetDevice(devs[0]));
+        HIP_CHECK(hipMemcpy(A_out, Ad[0].p, acnt * sizeof(cplx), hipMemcpyDeviceToHost));
+        for (int g = 0; g < ngpu; ++g) {                        // buffers are freed on their own device
+            HIP_CHECK(hipSetDevice(devs[g]));
+            Ad[g].release(); local[g].release(); slabs[g].release(); store[g].release();
+        }
+        tot.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        if (info) *info = tot;
+        return tot.n_unconverged > 0 ? std::max(code, (int)WAE_WARN_MAXITER) : WAE_OK;
+    } catch (const WaeError &e) {
+        wae_set_error(e.what());
+        return e.code;
+    } catch (const std::exception &e) {
+        wae_set_error(e.what());
+        return WAE_ERR_INVALID;
+    }
+}

@@ -19,6 +19,8 @@ struct WaeError : std::runtime_error {
     WaeError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
 };
 void wae_set_error(const std::string &m);
+int wae_internal_device(const wae_family *h);          // (mgpu.hip drives several handles through the C ABI)
+hipStream_t wae_internal_stream(const wae_family *h);
 
 #define HIP_CHECK(expr)                                                                                  \
     do {                                                                                                 \

@@ -299,3 +299,32 @@ def bloch_sweep_distributed(L, bs, starts, method=None, b_symbol="b", **kw):
             sols.append(sol)
         return row, sols
     return sweep_distributed(list(bs), unit, 3 * nstart)
+
+
+def beyn_moments_mgpu(families, G, V, K=1, N=16, nsnap=None, points=None):
+    """The single-process multi-GPU entry of the C ABI (``wae_beyn_moments_mgpu``; what a Julia host calls): ``families`` is a
+    list of LinearOperatorFamily replicas, one per GPU (``device=g``), all with the same terms and parameters.  Returns the
+    moment tensor d x l x 2K (numpy) and the merged solve statistics.  nsnap=None: the automatic rule of
+    compute_moment_matrices (40 snapshot points for contours of >= 64 points, d >= 1000)."""
+    import ctypes as C
+
+    from .. import _lib
+    from .beyn import coefficient_table
+    L0 = families[0]
+    zs, ws = gauss_points(G, N) if points is None else points
+    zs = np.ascontiguousarray(zs, dtype=np.complex128)
+    ws = np.ascontiguousarray(ws, dtype=np.complex128)
+    fams = [L.ensure_solver() for L in families]
+    d = L0.size()
+    ct = np.ascontiguousarray(coefficient_table(L0, zs), dtype=np.complex128) if len(zs) else np.zeros((0, len(L0.terms)), dtype=np.complex128)
+    Vf = np.asfortranarray(np.asarray(V, dtype=np.complex128))
+    l = Vf.shape[1]
+    if nsnap is None:
+        nsnap = min(40, len(zs) // 2) if (len(zs) >= 64 and d >= 1000) else 0
+    A = np.zeros((d, l, 2 * K), dtype=np.complex128, order="F")
+    info = _lib.SolveInfo()
+    hs = (C.c_void_p * len(fams))(*[f.handle for f in fams])
+    code = _lib.check(_lib.lib().wae_beyn_moments_mgpu(hs, len(fams), len(zs), _lib.zptr(zs), _lib.zptr(ws), _lib.zptr(ct), _lib.zptr(Vf), l, K,
+                                                      L0.solver_tol, L0.solver_maxit, int(nsnap), _lib.zptr(A), C.byref(info)))
+    fams[0]._report(code, info, "beyn_moments_mgpu", fatal=True)
+    return A, fams[0].last_info
