@@ -11,6 +11,12 @@
 #     Ld = WAEHip.DeviceFamily(L)                     # terms -> HBM once
 #     Ω, P = WAEHip.beyn(Ld, Γ; l=16, N=32)           # same keywords as NLEVP.beyn (src/NLEVP/beyn.jl:34)
 #     A = Ld(z); y = A*x; x = A\b; x = A'\b           # operator view instead of a SparseMatrixCSC
+#     sol, n, flag = WAEHip.householder(Ld, Ω[1]; tol=1e-11)      # Householder.jl:70, same keywords / flags
+#     sol, n, flag = WAEHip.mslp(Ld, Ω[1]; tol=1e-11)             # iterative_solvers.jl:93
+#     WAEHip.perturb_fast!(sol, Ld, :τ, 30)                       # LinOpFam.jl:575; no multi-index files needed
+#     res = WAEHip.eig_residuals(Ld, Ω, P)                        # which Ritz pairs are eigenpairs
+#     Lds = [WAEHip.DeviceFamily(L; device=g) for g in 0:7]       # 8 GPUs from one Julia process:
+#     A = WAEHip.compute_moment_matrices(Lds, Γ, V; N=64)         #   RCCL over xGMI inside the library
 module WAEHip
 
 using LinearAlgebra, SparseArrays
@@ -34,6 +40,18 @@ function check(code::Integer)
         error("libwaehip error $code: $msg")
     end
     return code            # > 0: warning (max. iterations / stagnation of an inner solve)
+end
+
+"the reference's `\\` is a direct LU that solves or throws: an inner solve that stopped short of its tolerance must not pass
+silently.  `fatal=true` (contour integrals: a stalled quadrature point corrupts every eigenpair) throws, otherwise a warning;
+`quiet=true` is for callers that judge the outcome themselves (the Newton-type solvers on numerically singular operators)."
+function report(code::Integer, info::SolveInfo, what::AbstractString; fatal::Bool=false, quiet::Bool=false)
+    if info.n_unconverged > 0 && !quiet
+        msg = "$what: $(info.n_unconverged) inner solve(s) did not reach the tolerance (largest relative residual $(info.relres_max), " *
+              (code == 2 ? "stagnation" : "iteration limit") * ")"
+        fatal ? error(msg) : @warn msg
+    end
+    return code
 end
 
 mutable struct DeviceFamily
@@ -117,7 +135,32 @@ function Base.:\(A::Operator, B::StridedVecOrMat{ComplexF64})
     check(ccall((:wae_solve, libwaehip), Cint,
                 (Ptr{Cvoid}, Ptr{ComplexF64}, Int32, Ptr{ComplexF64}, Ptr{ComplexF64}, Int32, Int32, Float64, Int32, Ref{SolveInfo}),
                 A.fam.handle, A.c, 1, B, X, size(B, 2), A.op, A.fam.tol, A.fam.maxit, info))
+    report(0, info[], "\\")
     return X
+end
+
+"`A\\b` with a known dominant direction of the solution (`u = L(z)\\(L(z,1)*x0)`, iterative_solvers.jl:307,571-572): wae_solve_guess"
+function solve_guess(A::Operator, B::StridedVecOrMat{ComplexF64}, G::StridedVecOrMat{ComplexF64}; quiet::Bool=true)
+    ensure_solver!(A.fam)
+    X = similar(B); info = Ref{SolveInfo}()
+    code = check(ccall((:wae_solve_guess, libwaehip), Cint,
+                (Ptr{Cvoid}, Ptr{ComplexF64}, Int32, Ptr{ComplexF64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Int32, Int32, Float64, Int32, Ref{SolveInfo}),
+                A.fam.handle, A.c, 1, B, G, X, size(B, 2), A.op, A.fam.tol, A.fam.maxit, info))
+    report(code, info[], "solve_guess"; quiet=quiet)
+    return X
+end
+
+"res[j] = ||L(ω_j) v_j|| / Σ_k |c_jk| ||A_k v_j||: which Ritz pairs of `beyn` are eigenpairs (wae_eig_residuals)"
+function eig_residuals(fam::DeviceFamily, Ω::AbstractVector, P::Matrix{ComplexF64})
+    L = fam.L
+    saved = (copy(L.params), L.active, L.mode); L.active = [L.eigval]; L.mode = :all
+    ct = Matrix{ComplexF64}(undef, length(L.terms), length(Ω))
+    for (j, w) in enumerate(Ω); ct[:, j] = coefficients(L, w); end
+    L.params, L.active, L.mode = saved
+    res = zeros(Float64, length(Ω))
+    check(ccall((:wae_eig_residuals, libwaehip), Cint, (Ptr{Cvoid}, Int32, Ptr{ComplexF64}, Ptr{ComplexF64}, UInt64, Ptr{Float64}),
+                fam.handle, length(Ω), ct, P, 0, res))
+    return res
 end
 
 # snapshot points for the projected initial guesses: rb indices spread evenly through the quadrature list, re-ordered so
@@ -155,6 +198,7 @@ function compute_moment_matrices(fam::DeviceFamily, Γ, V::Matrix{ComplexF64}; K
                     (Ptr{Cvoid}, Int32, Ptr{ComplexF64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Int32, Int32, Float64, Int32,
                      Ptr{ComplexF64}, UInt64, Ref{SolveInfo}),
                     fam.handle, npts, zs, ws, ct, V, l, K, fam.tol, fam.maxit, A, 0, info))
+        report(0, info[], "beyn moments"; fatal=true)
         return A
     end
     idx, rest = _snapshot_split(npts, rb)
@@ -164,9 +208,11 @@ function compute_moment_matrices(fam::DeviceFamily, Γ, V::Matrix{ComplexF64}; K
     # mode 0: the snapshot points (solutions kept in the handle's store); mode 2: all other points from the projection
     check(ccall((:wae_beyn_moments_rb, libwaehip), Cint, sig, fam.handle, length(idx), zs[idx], ws[idx], ct[:, idx], V, l, K,
                 fam.tol, fam.maxit, 0, length(idx), 0, 0, A, 0, 0, 0, 0, info))
+    report(0, info[], "beyn moments (snapshot points)"; fatal=true)
     # V = C_NULL: the probe matrix uploaded by the mode-0 call is still on the device (include/waehip.h)
     check(ccall((:wae_beyn_moments_rb, libwaehip), Cint, sig, fam.handle, length(rest), zs[rest], ws[rest], ct[:, rest], C_NULL, l, K,
                 fam.tol, fam.maxit, 2, length(idx), 0, 0, A1, 0, 0, 0, 0, info))
+    report(0, info[], "beyn moments (projected points)"; fatal=true)
     return A .+ A1                                                  # the moments are a plain sum over quadrature points
 end
 
@@ -197,6 +243,339 @@ function arnoldi_shiftinvert(A::Operator, M::Operator, m::Integer, v0::Vector{Co
     return H, V
 end
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# The solver surface of NLEVP_exports.jl:1-17 for a DeviceFamily.  The reference's householder / mslp / perturb_fast! cannot
+# run unchanged on the operator view: they hand the matrix itself to Arpack.eigs and lu (Householder.jl:100-101,115;
+# iterative_solvers.jl:132-133; perturbation.jl:385).  These methods keep the reference's signatures, flag conventions and
+# parameter-mutation semantics and put every factorisation / solve / SpMV on the device.
+# ---------------------------------------------------------------------------------------------------------------
+import ..NLEVP: Solution, pade, poly_roots, householder_update
+import ..NLEVP: itsol_converged, itsol_maxiter, itsol_slow_convergence, itsol_impossible, itsol_singular_exception,
+                itsol_arpack_exception, itsol_isnan, itsol_unknown
+
+struct EigsError <: Exception
+    msg::String
+end
+
+"`nsys` shift-invert Arnoldi processes in lock-step (wae_arnoldi_shiftinvert_batch): coefficient rows cA, cM (T x nsys),
+start vectors V0 (d x nsys).  Returns H (m+1, m, nsys), V (d, m+1, nsys) and the solve statistics."
+function arnoldi_batch(fam::DeviceFamily, cA::Matrix{ComplexF64}, cM::Matrix{ComplexF64}, m::Integer, V0::Matrix{ComplexF64}, op::Int32;
+                       ritz_tol::Float64=0.0)
+    ensure_solver!(fam)
+    d, nsys = size(V0)
+    H = zeros(ComplexF64, m + 1, m, nsys); V = zeros(ComplexF64, d, m + 1, nsys); info = Ref{SolveInfo}()
+    check(ccall((:wae_arnoldi_shiftinvert_batch, libwaehip), Cint,
+                (Ptr{Cvoid}, Int32, Ptr{ComplexF64}, Ptr{ComplexF64}, Int32, Ptr{ComplexF64}, Int32, Float64, Int32, Float64,
+                 Ptr{ComplexF64}, Ptr{ComplexF64}, Ref{SolveInfo}),
+                fam.handle, nsys, cA, cM, m, V0, op, fam.tol, fam.maxit, ritz_tol, H, V, info))
+    return H, V, info[]
+end
+
+"lam, v[, gap] of `Arpack.eigs(A, M, nev=nev, sigma=0, v0=v0)` (Householder.jl:100-101; iterative_solvers.jl:132-133): short
+Arnoldi factorisations of (A - σM)^{-1} M on the device, restarted with the wanted Ritz vectors; Ritz extraction on the host.
+σ: a shift far below the spectral gap once |λ| itself has fallen below it (an iterative inner solver needs a regular operator
+where the reference relies on UMFPACK factorising the numerically singular A, Householder.jl:145)."
+function eigs(A::Operator, M::Operator; nev::Int=1, v0=nothing, tol::Float64=1e-12, maxiter::Int=300, sigma=0.0)
+    fam = A.fam; d = size(A)[1]
+    step = min(d, max(20, 2nev + 1), max(6, 2nev + 2))
+    v = v0 === nothing ? ones(ComplexF64, d) : Vector{ComplexF64}(v0)
+    cA = A.c .- sigma .* M.c
+    sig_out = A.op == OP_C ? conj(sigma) : sigma
+    last = nothing; gap = Inf; total = 0; failed = 0
+    while total < maxiter
+        H3, V3, info = arnoldi_batch(fam, reshape(cA, :, 1), reshape(M.c, :, 1), step, reshape(v, :, 1), A.op; ritz_tol=(nev == 1 ? tol : 0.0))
+        H, V = H3[:, :, 1], V3[:, :, 1]
+        total += step
+        if info.n_unconverged > 0 && info.relres_max > 1e-4        # inner solves that do not even reach 1e-4: give up like ARPACK
+            failed += 1
+            failed >= 2 && throw(EigsError("inner solves stalled at relative residual $(info.relres_max)"))
+        end
+        m = step
+        while m > 1 && all(H[:, m] .== 0); m -= 1; end              # steps not taken (early exit on the device)
+        taken = m
+        for j in 1:m
+            if H[j+1, j] == 0; m = j; break; end                    # invariant subspace
+        end
+        F = eigen(H[1:m, 1:m])
+        ord = sortperm(abs.(F.values); rev=true)
+        theta, Y = F.values[ord], F.vectors[:, ord]
+        k = min(nev, m)
+        res = abs(H[m+1, m]) .* abs.(Y[m, 1:k])
+        X = V[:, 1:m] * Y[:, 1:k]
+        for j in 1:k; X[:, j] ./= norm(X[:, j]); end
+        last = (sig_out .+ 1.0 ./ theta[1:k], X)
+        m > k && (gap = abs(1.0 / theta[k+1]))
+        (all(res .<= tol .* abs.(theta[1:k])) || m < taken || m >= d) && return last[1], last[2], gap
+        v = X * ones(ComplexF64, k)
+    end
+    last === nothing && throw(EigsError("no Ritz pair"))
+    return last[1], last[2], gap
+end
+
+"λ_k, v_k of `perturb` / `perturb_disk` / `perturb_norm` (perturbation.jl:319-367,374-444,487-560) as ONE device call (wae_perturb).
+norm_mode 0/1/2 as in include/waehip.h (+16: eigenvalue series only)."
+function perturb_device(fam::DeviceFamily, N::Int, v0::Vector{ComplexF64}, v0Adj::Vector{ComplexF64}, norm_mode::Int; cY=nothing, quiet::Bool=false)
+    ensure_solver!(fam)
+    L = fam.L; T = length(L.terms); d = length(v0)
+    table = zeros(ComplexF64, T, N + 1, N + 1)                     # [(m*(N+1)+n)*T + k] in C order = [k, n+1, m+1] here
+    for m in 0:N, n in 0:N-m
+        table[:, n+1, m+1] = coefficients(L, m, n)
+    end
+    lam = zeros(ComplexF64, N + 1); V = zeros(ComplexF64, d, N + 1); info = Ref{SolveInfo}()
+    code = check(ccall((:wae_perturb, libwaehip), Cint,
+                (Ptr{Cvoid}, Ptr{ComplexF64}, Int32, Ptr{ComplexF64}, Ptr{ComplexF64}, Int32, Ptr{ComplexF64}, Float64, Int32,
+                 Ptr{ComplexF64}, Ptr{ComplexF64}, Ref{SolveInfo}),
+                fam.handle, table, N, v0, v0Adj, norm_mode, cY === nothing ? C_NULL : cY, fam.tol, fam.maxit, lam, V, info))
+    report(code, info[], "perturb (order $N)"; quiet=quiet)
+    return lam, [V[:, k] for k in 1:N+1]
+end
+
+function _perturb_wrapper!(sol::Solution, fam::DeviceFamily, param::Symbol, N::Int, mode::Symbol, norm_mode::Int; cY=nothing)
+    L = fam.L                                                       # LinOpFam.jl:546-560
+    active, params, current_mode = L.active, L.params, L.mode
+    L.params = sol.params; L.active = [sol.eigval, param]; L.mode = mode
+    key = Symbol("$(string(param))/Taylor")
+    try
+        lam, v = perturb_device(fam, N, Vector{ComplexF64}(sol.v), Vector{ComplexF64}(sol.v_adj), mode == :householder ? 16 : norm_mode;
+                                cY=cY, quiet=(mode == :householder))
+        lam[1] = sol.params[sol.eigval]
+        sol.eigval_pert[key], sol.v_pert[key] = lam, v
+    finally
+        L.active, L.mode, L.params = active, current_mode, params
+    end
+    return
+end
+"perturb!(sol, Ld, param, N; mode)   (LinOpFam.jl:546-560)"
+perturb!(sol::Solution, fam::DeviceFamily, param::Symbol, N::Int; mode=:compact) = _perturb_wrapper!(sol, fam, param, N, mode, 0)
+"perturb_fast!(sol, Ld, param, N; mode)   (LinOpFam.jl:575-589): needs no multi-index files (deps/build.jl)"
+perturb_fast!(sol::Solution, fam::DeviceFamily, param::Symbol, N::Int; mode=:compact) = _perturb_wrapper!(sol, fam, param, N, mode, 1)
+"perturb_norm!(sol, Ld, param, N; mode)   (LinOpFam.jl:604-618): Y = -L.terms[end].coeff"
+function perturb_norm!(sol::Solution, fam::DeviceFamily, param::Symbol, N::Int; mode=:compact)
+    cY = zeros(ComplexF64, length(fam.L.terms)); cY[end] = -1
+    _perturb_wrapper!(sol, fam, param, N, mode, 2; cY=cY)
+end
+
+# one pass of the loop body shared by householder and mslp (Householder.jl:96-120)
+function _aux_step(fam::DeviceFamily, z, order, nev, v0, v0_adj, update, state)
+    L = fam.L
+    L.params[L.eigval] = z; L.params[L.auxval] = 0
+    L.active = [L.eigval]; L.mode = :all
+    A = fam(z)
+    cM = zeros(ComplexF64, length(L.terms)); cM[end] = -1           # M = -L.terms[end].coeff  (Householder.jl:92)
+    M = Operator(fam, cM, OP_N)
+    gap_prev, lam_prev = get(state, :gap, Inf), get(state, :lam, Inf)
+    sigma = (isfinite(gap_prev) && lam_prev < 1e-4 * gap_prev) ? 1e-5 * gap_prev : 0.0
+    lam, v, gap = eigs(A, M; nev=nev, v0=v0, sigma=sigma)
+    lam_adj, v_adj, _ = eigs(A', M'; nev=nev, v0=v0_adj, sigma=sigma)
+    state[:gap] = isfinite(gap) ? gap : gap_prev
+    state[:lam] = minimum(abs.(lam))
+    p = sortperm(abs.(lam)); lam, v = lam[p], v[:, p]
+    p = sortperm(abs.(lam_adj)); v_adj = v_adj[:, p]
+    cand = ComplexF64[]
+    for i in 1:min(nev, length(lam), size(v_adj, 2))
+        L.params[L.auxval] = lam[i]
+        sol = Solution(L.params, v[:, i], v_adj[:, i], L.auxval)
+        perturb!(sol, fam, L.eigval, order; mode=:householder)
+        push!(cand, update(sol.eigval_pert[Symbol("$(string(L.eigval))/Taylor")]))
+    end
+    return lam, v, v_adj, cand
+end
+
+function _normalise(fam::DeviceFamily, v0, v0_adj)                 # Householder.jl:189-190
+    L = fam.L
+    cM = zeros(ComplexF64, length(L.terms)); cM[end] = -1
+    v0 = v0 ./ sqrt(dot(v0, Operator(fam, cM, OP_N) * v0))
+    saved = (L.active, L.mode); L.active = [L.eigval]; L.mode = :all
+    v0_adj = v0_adj ./ conj(dot(v0_adj, fam(L.params[L.eigval], 1) * v0))
+    L.active, L.mode = saved
+    return v0, v0_adj
+end
+
+"sol, n, flag = householder(Ld, z; maxiter, tol, relax, lam_tol, order, nev, v0, v0_adj, output)   (Householder.jl:70-192)"
+function householder(fam::DeviceFamily, z; maxiter=10, tol=0., relax=1., lam_tol=Inf, order=1, nev=1, v0=[], v0_adj=[], output=false)
+    L = fam.L
+    z = ComplexF64(z); z0 = complex(Inf); lam = Inf; n = 0
+    active, mode = L.active, L.mode
+    d = size(L.terms[1].coeff, 1)
+    v0 == [] && (v0 = ones(ComplexF64, d))
+    v0_adj == [] && (v0_adj = conj.(v0))
+    flag = 1; state = Dict{Symbol,Float64}()
+    try
+        while abs(z - z0) > tol && n < maxiter
+            output && println(n, "\t\t", abs(lam), "\t", abs(z - z0), "\t", z)
+            z0 = z
+            lams, v, v_adj, dzs = _aux_step(fam, z, order, nev, v0, v0_adj, c -> householder_update([factorial(i - 1) * c[i] for i in 1:length(c)]), state)
+            i = sortperm(abs.(dzs))[1]
+            lam = lams[i]; L.params[L.auxval] = lam
+            z += relax * dzs[i]
+            v0 = (1 - relax) .* v0 .+ relax .* v[:, i]
+            v0_adj = (1 - relax) .* v0_adj .+ relax .* v_adj[:, i]
+            n += 1
+        end
+    catch excp
+        if excp isa EigsError; flag = -4
+        elseif excp isa LinearAlgebra.SingularException; flag = -6; L.params[L.eigval] = z
+        else; flag = -2; L.params[L.eigval] = z; end
+    end
+    if flag == 1
+        L.params[L.eigval] = z
+        flag = n >= maxiter ? -1 : (abs(lam) <= lam_tol ? 1 : (abs(z - z0) <= tol ? 0 : (isnan(z) ? -5 : -3)))
+    end
+    L.active, L.mode = active, mode
+    v0, v0_adj = _normalise(fam, v0, v0_adj)
+    return Solution(L.params, v0, v0_adj, L.eigval), n, flag
+end
+
+"sol, n, flag = mslp(Ld, z; maxiter, tol, relax, lam_tol, order, nev, v0, v0_adj, num_order, scale, output)   (iterative_solvers.jl:93-252).
+The family must end with its auxiliary term (`discretize` adds it, Helmholtz.jl:571-574): the device copy is immutable."
+function mslp(fam::DeviceFamily, z; maxiter=10, tol=0., relax=1., lam_tol=Inf, order=1, nev=1, v0=[], v0_adj=[], num_order=1, scale=1, output=false)
+    L = fam.L
+    L.terms[end].operator == "__aux__" || error("mslp(::DeviceFamily): push the __aux__ term before creating the DeviceFamily (iterative_solvers.jl:119-123)")
+    z = ComplexF64(z) * scale; tol *= scale
+    z0 = complex(Inf); lam = Inf; lam0 = complex(Inf); n = 0
+    active, mode = L.active, L.mode
+    d = size(L.terms[1].coeff, 1)
+    v0 == [] && (v0 = ones(ComplexF64, d))
+    v0_adj == [] && (v0_adj = conj.(v0))
+    flag = itsol_converged; state = Dict{Symbol,Float64}()
+    polyval(p, x) = foldr((a, acc) -> a + x * acc, p)
+    try
+        while abs(z - z0) > tol && n < maxiter
+            output && println(n, "\t\t", abs(z - z0) / scale, "\t", z / scale)
+            pades = Tuple{Vector{ComplexF64},Vector{ComplexF64}}[]
+            upd = function (c)
+                num, den = pade(c, num_order, order - num_order)
+                push!(pades, (num, den))
+                r = poly_roots(num)
+                return r[sortperm(abs.(r))[1]]
+            end
+            lams, v, v_adj, dzs = _aux_step(fam, z, order, nev, v0, v0_adj, upd, state)
+            i = isinf(z0) ? sortperm(abs.(dzs))[1] : sortperm([abs(lam0 - polyval(nd[1], z0 - z) / polyval(nd[2], z0 - z)) for nd in pades])[1]
+            lam = lams[i]; L.params[L.auxval] = lam
+            z0 = z; lam0 = lam
+            z += relax * dzs[i]
+            v0 = (1 - relax) .* v0 .+ relax .* v[:, i]
+            v0_adj = (1 - relax) .* v0_adj .+ relax .* v_adj[:, i]
+            n += 1
+        end
+    catch excp
+        if excp isa EigsError; flag = itsol_arpack_exception
+        elseif excp isa LinearAlgebra.SingularException; flag = itsol_singular_exception; L.params[L.eigval] = z
+        else; flag = itsol_unknown; L.params[L.eigval] = z; end
+    end
+    if flag == itsol_converged
+        L.params[L.eigval] = z
+        flag = n >= maxiter ? itsol_maxiter : (abs(lam) <= lam_tol ? itsol_converged : (abs(z - z0) <= tol ? itsol_slow_convergence : (isnan(z) ? itsol_isnan : itsol_impossible)))
+    end
+    L.active, L.mode = active, mode
+    v0, v0_adj = _normalise(fam, v0, v0_adj)
+    return Solution(L.params, v0, v0_adj, L.eigval), n, flag
+end
+
+"sol, n, flag = inveriter(Ld, z; maxiter, tol, relax, x0, v, output)   (iterative_solvers.jl:285-347): u = L(z)\\(L(z,1) x0) on the device,
+with the current iterate deflated as the known dominant direction of the solution (wae_solve_guess)"
+function inveriter(fam::DeviceFamily, z; maxiter=10, tol=0., relax=1., x0=[], v=[], output=false)
+    L = fam.L
+    d = size(L.terms[1].coeff, 1)
+    x0 == [] && (x0 = ones(ComplexF64, d)); v == [] && (v = ones(ComplexF64, d))
+    z = ComplexF64(z); z0 = complex(Inf); n = 0; flag = itsol_converged
+    active, mode = L.active, L.mode; L.active = [L.eigval]; L.mode = :all
+    try
+        while abs(z - z0) > tol && n < maxiter
+            output && println(n, "\t\t", abs(z - z0), "\t", z)
+            z0 = z
+            u = solve_guess(fam(z), fam(z, 1) * x0, x0)
+            z = z0 - dot(v, x0) / dot(v, u)
+            x0 = u ./ dot(v, u)
+            n += 1
+        end
+    catch excp
+        flag = excp isa LinearAlgebra.SingularException ? itsol_singular_exception : itsol_unknown
+    end
+    if flag == itsol_converged
+        flag = n >= maxiter ? itsol_maxiter : (abs(z - z0) <= tol ? itsol_converged : (isnan(z) ? itsol_isnan : itsol_impossible))
+    end
+    L.params[L.eigval] = z
+    L.active, L.mode = active, mode
+    return Solution(L.params, x0, ComplexF64[], L.eigval), n, flag
+end
+
+"Dict ω => [Solution, inside] = solve(Ld, Γ; Δl, N, tol, eigvals, maxcycles, nev, max_outer_cycles, atol_σ, rtol_σ, loglevel)
+(solver.jl:36-184): Beyn with growing probe blocks, analytic deflation of the known eigenpairs from the moments, local refinement
+(the reference calls the un-included `mehrmann` at :106; `inveriter` is the same algorithm, mehrmann.jl:1-72)"
+function solve(fam::DeviceFamily, Γ; Δl=1, N=16, tol=1e-8, eigvals=Dict(), maxcycles=1, nev=1, max_outer_cycles=1, atol_σ=1e-12, rtol_σ=1e-8, loglevel=0)
+    L = fam.L
+    d = size(L.terms[1].coeff, 1)
+    eigvals = Dict{ComplexF64,Any}(eigvals)
+    A = Array{Array{ComplexF64,3},1}()
+    l = 0
+    for cycle in 1:max_outer_cycles * max(1, div(d, Δl))
+        l >= d && break
+        V = zeros(ComplexF64, d, Δl); for i in 1:Δl; l + i <= d && (V[l+i, i] = 1); end
+        mom = compute_moment_matrices(fam, Γ, V; K=1, N=N)
+        for (ω, val) in eigvals                                    # deflation of known eigenpairs (solver.jl:57-64,131-137)
+            sol = val[1]; val[2] || continue
+            for p in 0:size(mom, 3)-1
+                mom[:, :, p+1] .-= (-2π * im * ω^p) .* (sol.v * (sol.v_adj[l+1:l+Δl])')
+            end
+        end
+        push!(A, mom); l += Δl
+        B0 = hcat((a[:, :, 1] for a in A)...); B1 = hcat((a[:, :, 2] for a in A)...)
+        F = svd(B0)
+        σmax = isempty(F.S) ? 0.0 : F.S[1]
+        keep = (F.S .> atol_σ) .& (F.S .> rtol_σ * σmax)
+        any(keep) || break
+        U, S, W = F.U[:, keep], F.S[keep], F.V[:, keep]
+        Ω, P = eigen(U' * B1 * W * Diagonal(1 ./ S)); P = U * P
+        found_new = false
+        for (j, ω0) in enumerate(Ω)
+            inpoly(ω0, Γ) || continue
+            sol, n, flag = inveriter(fam, ω0; maxiter=10, tol=tol, x0=P[:, j], v=P[:, j])
+            flag == itsol_converged || continue
+            ω = sol.params[L.eigval]
+            any(abs(ω - w) <= 10tol * max(1, abs(w)) for w in keys(eigvals)) && continue
+            # adjoint vector by one more inverse iteration on L(ω)' (normalised like Householder.jl:189-190)
+            y = solve_guess(fam(ω)', (fam(ω, 1))' * conj.(sol.v), conj.(sol.v))
+            sol.v_adj = y ./ conj(dot(y, fam(ω, 1) * sol.v))
+            eigvals[ω] = Any[sol, inpoly(ω, Γ)]
+            found_new = true
+            loglevel > 0 && println("solve: new eigenvalue ", ω, " after ", n, " iterations")
+        end
+        (!found_new && sum(keep) < l) && break                     # rank gap reached and nothing new: done (solver.jl:172)
+    end
+    return eigvals
+end
+
+# ---------------------------------------------------------------------------------------------------------------
+# several GPUs of one node from this one Julia process (SURVEY.md 8b/8e): one DeviceFamily replica per device
+# ---------------------------------------------------------------------------------------------------------------
+"moments like `compute_moment_matrices`, quadrature points and snapshot phase shared out over `fams` (one replica per GPU:
+`[DeviceFamily(L; device=g) for g in 0:7]`); RCCL all-gather / reduce inside the library (wae_beyn_moments_mgpu)"
+function compute_moment_matrices(fams::Vector{DeviceFamily}, Γ, V::Matrix{ComplexF64}; K=1, N=16, rb=nothing)
+    foreach(ensure_solver!, fams)
+    L = fams[1].L
+    X, W = FastGaussQuadrature.gausslegendre(N)
+    zs = ComplexF64[]; ws = ComplexF64[]
+    for i in 1:length(Γ)
+        a, b = Γ[i], Γ[i == length(Γ) ? 1 : i + 1]
+        append!(zs, X .* (b - a) / 2 .+ (a + b) / 2); append!(ws, W .* (b - a) / 2)
+    end
+    saved = (L.active, L.mode); L.active = [L.eigval]; L.mode = :all
+    ct = Matrix{ComplexF64}(undef, length(L.terms), length(zs))
+    for (j, z) in enumerate(zs); ct[:, j] = coefficients(L, z); end
+    L.active, L.mode = saved
+    d, l = size(V); npts = length(zs)
+    rb === nothing && (rb = (npts >= 64 && d >= 1000) ? min(40, div(npts, 2)) : 0)
+    A = zeros(ComplexF64, d, l, 2K); info = Ref{SolveInfo}()
+    hs = [f.handle for f in fams]
+    code = check(ccall((:wae_beyn_moments_mgpu, libwaehip), Cint,
+                (Ptr{Ptr{Cvoid}}, Int32, Int32, Ptr{ComplexF64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Int32, Int32, Float64, Int32,
+                 Int32, Ptr{ComplexF64}, Ref{SolveInfo}),
+                hs, length(hs), npts, zs, ws, ct, V, l, K, fams[1].tol, fams[1].maxit, rb, A, info))
+    report(code, info[], "beyn moments ($(length(hs)) GPUs)"; fatal=true)
+    return A
+end
 
 # ---------------------------------------------------------------------------------------------------------------
 # operator interchange: the WAEFAM1 container read by wae_amd.nlevp.save.load_family (Python harness).  The text format

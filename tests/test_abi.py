@@ -84,3 +84,83 @@ def test_header_is_valid_c99_and_the_info_struct_layout_matches_ctypes(tmp_path)
     jl = open(os.path.join(ROOT, "julia", "WAEHip.jl"), encoding="utf-8").read()
     m = re.search(r"struct SolveInfo(.*?)end", jl, re.S)
     assert m and re.findall(r"::(\w+)", m.group(1)) == ["Int32"] * 4 + ["Float64"] * 2
+
+
+def _header_prototypes():
+    """name -> list of C parameter type strings, from include/waehip.h"""
+    hdr = open(os.path.join(ROOT, "include", "waehip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|int64_t|const char \*)\s*\*?\s*(wae_[a-z_0-9]+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.S):
+        args = [a.strip() for a in m.group(2).replace("\n", " ").split(",")]
+        protos[m.group(1)] = [] if args == ["void"] else args
+    return protos
+
+
+def _julia_ccalls():
+    """(name, [julia argument types]) of every ccall in julia/WAEHip.jl (signature tuples given inline or through `sig`)"""
+    jl = open(os.path.join(ROOT, "julia", "WAEHip.jl"), encoding="utf-8").read()
+    sigs = {m.group(1): m.group(2) for m in re.finditer(r"\n\s*(sig)\s*=\s*\((.*?)\)\n", jl, flags=re.S)}
+    out = []
+    for m in re.finditer(r"ccall\(\(:(wae_[a-z_0-9]+), libwaehip\),\s*(\w+),\s*(\(|sig\b)", jl):
+        name = m.group(1)
+        if m.group(3) == "sig":
+            body = sigs["sig"]
+        else:
+            i = m.end()
+            depth, j = 1, i
+            while depth:
+                depth += {"(": 1, ")": -1}.get(jl[j], 0)
+                j += 1
+            body = jl[i:j - 1]
+        types, depth, cur = [], 0, ""
+        for ch in body:
+            if ch in "{(":
+                depth += 1
+            if ch in "})":
+                depth -= 1
+            if ch == "," and depth == 0:
+                types.append(cur.strip()); cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            types.append(cur.strip())
+        out.append((name, types))
+    return out
+
+
+def test_julia_ccall_signatures_match_the_header():
+    """julia/WAEHip.jl cannot be executed here (no julia binary): its ccall signatures are checked mechanically against
+    include/waehip.h -- same symbol, same number of arguments, pointer where the header has a pointer, same integer / float
+    width where it has a scalar."""
+    protos = _header_prototypes()
+    calls = _julia_ccalls()
+    assert len(calls) >= 14
+    seen = set()
+    for name, types in calls:
+        assert name in protos, name
+        cargs = protos[name]
+        assert len(types) == len(cargs), (name, types, cargs)
+        for jt, ct in zip(types, cargs):
+            if "*" in ct:
+                assert jt.startswith(("Ptr{", "Ref{")) or jt == "Cstring", (name, jt, ct)
+            elif ct.startswith("int64_t"):
+                assert jt == "Int64", (name, jt, ct)
+            elif ct.startswith("int32_t"):
+                assert jt in ("Int32", "Cint"), (name, jt, ct)
+            elif ct.startswith("uint64_t"):
+                assert jt == "UInt64", (name, jt, ct)
+            elif ct.startswith("double"):
+                assert jt == "Float64", (name, jt, ct)
+            else:
+                raise AssertionError((name, jt, ct))
+        seen.add(name)
+    for must in ("wae_family_create", "wae_spmv_sum", "wae_solver_setup", "wae_solve", "wae_solve_guess", "wae_beyn_moments",
+                 "wae_beyn_moments_rb", "wae_beyn_moments_mgpu", "wae_eig_residuals", "wae_arnoldi_shiftinvert_batch", "wae_perturb"):
+        assert must in seen, must
+    # the file is at least bracket-balanced (a cheap stand-in for a parser)
+    jl = open(os.path.join(ROOT, "julia", "WAEHip.jl"), encoding="utf-8").read()
+    code = re.sub(r'"(?:\\.|[^"\\])*"', '""', re.sub(r"#=.*?=#", "", jl, flags=re.S))
+    code = "\n".join(ln.split("#")[0] for ln in code.split("\n"))
+    for a, b in ("()", "[]", "{}"):
+        assert code.count(a) == code.count(b), (a, code.count(a), code.count(b))
