@@ -242,6 +242,20 @@ int wae_perturb(wae_family *h, const double *coeff_table, int32_t N, const doubl
  * matrices share one CSR pattern (rowptr npoints+1, col nnz; real values).  wae_p1_assemble returns a handle, wae_p1_info
  * the sizes, wae_p1_get copies the arrays out (any pointer may be NULL), wae_p1_free releases it. */
 int wae_p1_assemble(int32_t device, int64_t npoints, const double *points, int64_t ntets, const int32_t *tets, const double *c_tet, void **out);
+/* The other two operators of `discretize` for a P1 Helmholtz problem, same pipeline and same handle type (wae_p1_info /
+ * wae_p1_get / wae_p1_free; the values come back in the `mass` array of wae_p1_get, `stiff` is zero):
+ *  - admittance boundary (src/Helmholtz.jl:443-463 with src/FEM/FEM.jl:9-20,435-441): per boundary triangle
+ *        b_ab = c_tri |(x0-x2) x (x1-x2)| (1 + delta_ab) / 24 ;   the operator term is  C = -i b  (Helmholtz.jl:459).
+ *    tris: 3 point indices (0-based) per triangle, c_tri: speed of sound of the tetrahedron behind each (NULL = 1).
+ *  - flame (src/Helmholtz.jl:292-344,464-487 with FEM.jl:2429-2431,2442-2448): Q = sum over the flame tetrahedra of S (x) g,
+ *        S_a = |det J|/24 on the four nodes of a flame tetrahedron,   g_b = -nlocal grad(phi_b).n_ref on the reference
+ *        tetrahedron,   nlocal = nglobal_scaled / V_flame  (the caller passes (gamma-1)/rho * Q02U0, Helmholtz.jl:325; the
+ *        flame volume is summed on the device and returned in volume_out if not NULL).
+ *    flame_tets: indices into tets of the nflame flame tetrahedra; ref_tet: index of the tetrahedron that contains the
+ *    reference point (Meshutils.jl:800-816 finds it; that search stays on the host); n_ref: 3 doubles. */
+int wae_p1_assemble_boundary(int32_t device, int64_t npoints, const double *points, int64_t ntris, const int32_t *tris, const double *c_tri, void **out);
+int wae_p1_assemble_flame(int32_t device, int64_t npoints, const double *points, int64_t ntets, const int32_t *tets, int64_t nflame,
+                          const int32_t *flame_tets, int32_t ref_tet, const double *n_ref, double nglobal_scaled, void **out, double *volume_out);
 int wae_p1_info(const void *handle, int64_t *npoints, int64_t *nnz);
 int wae_p1_get(const void *handle, int32_t *rowptr, int32_t *col, double *mass, double *stiff);
 int wae_p1_free(void *handle);

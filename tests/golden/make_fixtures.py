@@ -170,7 +170,27 @@ def rijke_mesh():
     print("wrote rijke_shape.npz  omega/2pi =", sol.params["ω"] / 2 / np.pi, " |sens| range", np.abs(sens[:, pick]).min(), np.abs(sens[:, pick]).max())
 
 
+def rijke_flame():
+    """Flame description of the tutorial set-up as plain arrays (docs/src/tutorial_04_perturbation_theory.md:29-48): indices of
+    the flame tetrahedra, the reference tetrahedron found by the oracle's restatement of find_tetrahedron_containing_point
+    (Meshutils.jl:800-816), n_ref and (γ-1)/ρ·Q02U0.  Input of the device flame assembly test.  Output: rijke_flame.npz."""
+    from oracle import helmholtz_p1 as H
+    mesh, _ = H.rijke_tube(os.path.join(REF, "docs/src/Rijke_mm.msh"), n=0.01, tau=0.001)
+    gamma, rho, Tu, Tb, P0 = 1.4, 1.225, 300.0, 1200.0, 101325.0
+    Q02U0 = P0 * (Tb / Tu - 1) * (np.pi * 0.025 ** 2) * gamma / (gamma - 1)
+    x_ref, n_ref = [0.0, 0.0, -0.00101], [0.0, 0.0, 1.0]
+    flame = np.asarray(mesh.domains["Flame"]["simplices"], dtype=np.int32)
+    ref = H.find_tetrahedron_containing_point(mesh, x_ref)
+    np.savez_compressed(os.path.join(HERE, "rijke_flame.npz"), flame_tets=flame, ref_tet=np.int32(ref), n_ref=np.asarray(n_ref, dtype=np.float64),
+                        x_ref=np.asarray(x_ref, dtype=np.float64), nglobal_scaled=np.float64((gamma - 1) / rho * Q02U0),
+                        volume=np.float64(H.compute_size(mesh, "Flame")))
+    print("wrote rijke_flame.npz", len(flame), "flame tetrahedra, reference tetrahedron", ref)
+
+
 if __name__ == "__main__":
+    if "--flame" in sys.argv:
+        rijke_flame()
+        sys.exit(0)
     if "--mesh" in sys.argv:
         rijke_mesh()
         sys.exit(0)

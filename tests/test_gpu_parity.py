@@ -820,3 +820,76 @@ def test_saved_family_and_solution_files_drive_the_device(tmp_path):
     assert back("τ", 0.001 + 1e-5, 8) == sols[0]("τ", 0.001 + 1e-5, 8)
     assert abs(back("τ", 0.001 + 1e-5, 8) - c(G["G3"]["omega_exact"])) < 1e-6
     L0._drop_device()
+
+
+def test_device_p1_assembly_of_boundary_mass_and_flame_operators():
+    """SURVEY 8f-2, second half: the admittance boundary mass C (Helmholtz.jl:443-463; FEM.jl:435-441) and the flame operator
+    Q = S (x) g (Helmholtz.jl:292-344,464-487; FEM.jl:2429-2431,2442-2448) assembled on the device, against the golden
+    Rijke-tube C (nnz 141) and Q (nnz 332) -- pinned through the tutorial eigenvalues G1/G5 -- from the tutorial mesh's
+    geometry, and against the numpy assembly of the synthetic annulus (12 flames = 12 calls).  With all four device-assembled
+    terms the family reproduces G5 (mslp, active flame)."""
+    import os
+    from wae_amd.helmholtz.assemble import assemble_p1, assemble_p1_boundary, assemble_p1_flame
+    z = np.load(os.path.join(F.GOLDEN_DIR, "rijke_mesh.npz"))
+    fl = np.load(os.path.join(F.GOLDEN_DIR, "rijke_flame.npz"))
+    t = F.rijke_terms()
+    C_dev = assemble_p1_boundary(z["points"], z["outlet_triangles"], z["outlet_c"])
+    Q_dev, vol = assemble_p1_flame(z["points"], z["tetrahedra"], fl["flame_tets"], int(fl["ref_tet"]), fl["n_ref"], float(fl["nglobal_scaled"]))
+    assert abs(vol - float(fl["volume"])) <= 1e-13 * float(fl["volume"])
+    for A, B, nnz in ((C_dev, t["C"], 141), (Q_dev, t["Q"], 332)):
+        A, B = sp.csr_matrix(A), sp.csr_matrix(B)
+        A.sort_indices(); B.sort_indices()
+        assert A.nnz == B.nnz == nnz
+        assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+        assert np.max(np.abs(A.data - B.data)) <= 1e-13 * np.max(np.abs(B.data))
+    assert np.all(C_dev.data.real == 0)                               # purely imaginary, like the reference's (Helmholtz.jl:459)
+    # the whole Rijke family from the device assembly reproduces G5
+    M_dev, K_dev = assemble_p1(z["points"], z["tetrahedra"], z["c_tet"])
+    Lp = helmholtz_family({"M": M_dev, "K": K_dev, "C": C_dev, "Q": Q_dev}, n=1.0, tau=0.001)
+    Lp.solver_ref = 340 * 2 * np.pi
+    sol, n, flag = mslp(Lp, 340 * 2 * np.pi, maxiter=20, tol=1e-11)
+    assert abs(sol.params["ω"] - c(G["G5"]["omega"])) < 1e-10 * abs(c(G["G5"]["omega"]))
+    Lp._drop_device()
+    # synthetic annulus: outlet faces and the 12 flame slabs, found the way helmholtz/annulus.py finds them
+    pb = annulus.build("small")
+    nth, nz, nr = pb["info"]["grid"]
+    pts, tets, _ = annulus._mesh(nth, nz, nr)
+    ctr = pts[tets].mean(axis=1)
+    c_tet = np.where(ctr[:, 2] < annulus.Z_JUMP, annulus.C_COLD, annulus.C_HOT)
+    top = np.isclose(pts[:, 2], annulus.HEIGHT)
+    faces = np.array([[0, 1, 2], [0, 1, 3], [0, 2, 3], [1, 2, 3]])
+    tri_nodes = tets[:, faces]
+    t_idx, f_idx = np.nonzero(top[tri_nodes].all(axis=2))
+    C2 = assemble_p1_boundary(pts, tri_nodes[t_idx, f_idx], c_tet[t_idx])
+    assert abs(C2 - pb["terms"]["C"]).max() <= 1e-13 * abs(pb["terms"]["C"]).max() and C2.nnz == pb["terms"]["C"].nnz
+    gamma, rho, Tu, Tb, P0 = 1.4, 1.225, 300.0, 1200.0, 101325.0
+    nsec = annulus.N_SECTOR
+    Q02U0 = P0 * (Tb / Tu - 1) * (np.pi * (annulus.R_OUT ** 2 - annulus.R_IN ** 2) / nsec) * gamma / (gamma - 1)
+    ang = np.mod(np.arctan2(ctr[:, 1], ctr[:, 0]), 2 * np.pi)
+    sector = np.floor(ang / (2 * np.pi / nsec)).astype(int)
+    frac = ang / (2 * np.pi / nsec) - sector
+    in_flame = (ctr[:, 2] > annulus.FLAME_Z0) & (ctr[:, 2] < annulus.FLAME_Z1) & (frac > 0.25) & (frac < 0.75)
+    X = pts[tets]
+    Jm = np.transpose(X[:, :3, :] - X[:, 3:4, :], (0, 2, 1))
+    Q2 = None
+    for f in range(nsec):
+        sel = np.nonzero(in_flame & (sector == f))[0]
+        a0 = (f + 0.5) * 2 * np.pi / nsec
+        r_mid = 0.5 * (annulus.R_IN + annulus.R_OUT)
+        x_ref = np.array([r_mid * np.cos(a0), r_mid * np.sin(a0), annulus.REF_Z]) + 1e-7
+        ref = -1
+        for it in np.nonzero(np.linalg.norm(ctr - x_ref, axis=1) < 4 * annulus.HEIGHT / nz)[0]:      # host-side point location
+            xi = np.linalg.solve(Jm[it], x_ref - X[it, 3])
+            xi = np.append(xi, 1 - xi.sum())
+            if np.all((xi >= 0) & (xi <= 1)):
+                ref = it
+                break
+        Qf, _ = assemble_p1_flame(pts, tets, sel, ref, [0.0, 0.0, 1.0], (gamma - 1) / rho * Q02U0)
+        Q2 = Qf if Q2 is None else Q2 + Qf
+    # values only: where grad(phi_b).n_ref vanishes the cofactor formula gives an exact 0 and numpy's inverse a rounding-sized
+    # number, so the stored patterns differ in entries of relative size 1e-16 (pattern equality is shown on the Rijke fixture)
+    Qn = sp.csr_matrix(pb["terms"]["Q"])
+    assert abs(Q2 - Qn).max() <= 1e-13 * abs(Qn).max()
+    assert (abs(Q2) > 1e-10 * abs(Qn).max()).nnz == (abs(Qn) > 1e-10 * abs(Qn).max()).nnz
+    with pytest.raises(_lib.WaeError):
+        assemble_p1_flame(pts, tets, sel, len(tets) + 3, [0.0, 0.0, 1.0], 1.0)

@@ -12,6 +12,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "wae_internal.h"
@@ -196,9 +197,188 @@ template <class T> struct Dev {
     ~Dev() { if (p) (void)hipFree(p); }
 };
 
+// keyed triplets (key = row * np + col; up to two value streams) -> CSR: stable radix sort (duplicates adjacent, in
+// element order: the sums are deterministic, no atomics), reduce-by-key, row pointer from the unique keys
+P1Handle *triplets_to_csr(int64_t npoints, size_t ne, Dev<unsigned long long> &k0, Dev<double> &mv, Dev<double> *kv) {
+    Dev<double> ms(ne), ks(kv ? ne : 1), mu(ne), ku(kv ? ne : 1);
+    Dev<int> dcol(ne), drow((size_t)npoints + 1), dnum(1);
+    Dev<unsigned long long> k1(ne), ku0(ne);
+    Dev<unsigned int> i0(ne), i1(ne);
+    const unsigned g = (unsigned)std::min<size_t>((ne + 255) / 256, 8192);
+    hipLaunchKernelGGL(iota_kernel, dim3(g), dim3(256), 0, 0, i0.p, ne);
+    int bits = 1;
+    while (bits < 64 && ((unsigned long long)npoints * (unsigned long long)npoints) >> bits) ++bits;
+    size_t tmp_bytes = 0;
+    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0.p, k1.p, i0.p, i1.p, (int)ne, 0, bits));
+    Dev<char> tmp(tmp_bytes);
+    HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, k0.p, k1.p, i0.p, i1.p, (int)ne, 0, bits));
+    hipLaunchKernelGGL(gather_d_kernel, dim3(g), dim3(256), 0, 0, mv.p, i1.p, ms.p, ne);
+    if (kv) hipLaunchKernelGGL(gather_d_kernel, dim3(g), dim3(256), 0, 0, kv->p, i1.p, ks.p, ne);
+    size_t tb2 = 0;
+    HIP_CHECK(hipcub::DeviceReduce::ReduceByKey(nullptr, tb2, k1.p, ku0.p, ms.p, mu.p, dnum.p, hipcub::Sum(), (int)ne));
+    Dev<char> tmp2(tb2);
+    HIP_CHECK(hipcub::DeviceReduce::ReduceByKey(tmp2.p, tb2, k1.p, ku0.p, ms.p, mu.p, dnum.p, hipcub::Sum(), (int)ne));
+    if (kv) HIP_CHECK(hipcub::DeviceReduce::ReduceByKey(tmp2.p, tb2, k1.p, ku0.p, ks.p, ku.p, dnum.p, hipcub::Sum(), (int)ne));
+    int nnz = 0;
+    HIP_CHECK(hipMemcpy(&nnz, dnum.p, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemset(drow.p, 0xff, ((size_t)npoints + 1) * sizeof(int)));          // -1 = row without entries
+    hipLaunchKernelGGL(split_keys_kernel, dim3(g), dim3(256), 0, 0, ku0.p, (size_t)nnz, (unsigned long long)npoints, dcol.p, drow.p);
+    HIP_CHECK(hipGetLastError());
+    std::unique_ptr<P1Handle> H(new P1Handle);
+    H->np = npoints; H->nnz = nnz;
+    H->rowptr.resize((size_t)npoints + 1); H->col.resize(nnz); H->m.resize(nnz); H->k.assign(nnz, 0.0);
+    HIP_CHECK(hipMemcpy(H->rowptr.data(), drow.p, ((size_t)npoints + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(H->col.data(), dcol.p, (size_t)nnz * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(H->m.data(), mu.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost));
+    if (kv) HIP_CHECK(hipMemcpy(H->k.data(), ku.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost));
+    H->rowptr[npoints] = nnz;
+    for (int64_t r = npoints - 1; r >= 0; --r)
+        if (H->rowptr[r] < 0) H->rowptr[r] = H->rowptr[r + 1];
+    return H.release();
+}
+
+// boundary mass of one triangle: b_ab = c |(x0-x2) x (x1-x2)| (1+delta_ab)/24  (FEM.jl:9-20,435-441; Helmholtz.jl:151-156); C = -i b
+__global__ __launch_bounds__(256) void p1_boundary_kernel(const double *__restrict__ pts, const int *__restrict__ tris, const double *__restrict__ c_tri,
+                                                          int64_t nt, int64_t np, unsigned long long *__restrict__ keys, double *__restrict__ bv) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nt) return;
+    int v[3];
+    double X[3][3];
+    for (int a = 0; a < 3; ++a) {
+        v[a] = tris[t * 3 + a];
+        for (int k = 0; k < 3; ++k) X[a][k] = pts[(size_t)v[a] * 3 + k];
+    }
+    const double u0 = X[0][0] - X[2][0], u1 = X[0][1] - X[2][1], u2 = X[0][2] - X[2][2];
+    const double w0 = X[1][0] - X[2][0], w1 = X[1][1] - X[2][1], w2 = X[1][2] - X[2][2];
+    const double n0 = u1 * w2 - u2 * w1, n1 = u2 * w0 - u0 * w2, n2 = u0 * w1 - u1 * w0;
+    const double det = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+    const double c = c_tri ? c_tri[t] : 1.0;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            const size_t o = (size_t)t * 9 + a * 3 + b;
+            keys[o] = (unsigned long long)v[a] * (unsigned long long)np + (unsigned long long)v[b];
+            bv[o] = c * ((a == b ? 2.0 : 1.0) / 24.0) * det;
+        }
+}
+
+// |det J| of the listed tetrahedra (volume source S_a = |det J|/24 per node, FEM.jl:2429-2431; flame volume = sum |det J|/6)
+__global__ __launch_bounds__(256) void p1_det_kernel(const double *__restrict__ pts, const int *__restrict__ tets, const int *__restrict__ list, int64_t n,
+                                                     double *__restrict__ adet) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int t = list[i];
+    double X[4][3];
+    for (int a = 0; a < 4; ++a)
+        for (int k = 0; k < 3; ++k) X[a][k] = pts[(size_t)tets[(size_t)t * 4 + a] * 3 + k];
+    double J[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int a = 0; a < 3; ++a) J[r][a] = X[a][r] - X[3][r];
+    const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) + J[0][1] * (J[1][2] * J[2][0] - J[1][0] * J[2][2]) +
+                       J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+    adet[i] = fabs(det);
+}
+// Q triplets: (node a of flame tetrahedron i, node b of the reference tetrahedron) -> |det J_i|/24 * g_b   (Helmholtz.jl:19-33,483)
+__global__ __launch_bounds__(256) void p1_flame_kernel(const int *__restrict__ tets, const int *__restrict__ list, int64_t n, const double *__restrict__ adet,
+                                                       int r0, int r1, int r2, int r3, double g0, double g1, double g2, double g3, int64_t np,
+                                                       unsigned long long *__restrict__ keys, double *__restrict__ qv) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int t = list[i];
+    const double s = adet[i] / 24.0;
+    const int rn[4] = {r0, r1, r2, r3};
+    const double g[4] = {g0, g1, g2, g3};
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) {
+            const size_t o = (size_t)i * 16 + a * 4 + b;
+            keys[o] = (unsigned long long)tets[(size_t)t * 4 + a] * (unsigned long long)np + (unsigned long long)rn[b];
+            qv[o] = s * g[b];
+        }
+}
+
 }  // namespace
 
 extern "C" {
+
+int wae_p1_assemble_boundary(int32_t device, int64_t npoints, const double *points, int64_t ntris, const int32_t *tris, const double *c_tri, void **out) {
+    return wae_guarded([&]() {
+        if (!(npoints > 0 && ntris > 0 && points && tris && out)) throw WaeError(WAE_ERR_INVALID, "bad argument");
+        for (int64_t i = 0; i < ntris * 3; ++i)
+            if (tris[i] < 0 || tris[i] >= npoints) throw WaeError(WAE_ERR_INVALID, "triangle refers to a point outside 0..npoints-1");
+        HIP_CHECK(hipSetDevice(device));
+        const size_t ne = (size_t)ntris * 9;
+        Dev<double> dpts((size_t)npoints * 3), dc(c_tri ? (size_t)ntris : 1), bv(ne);
+        Dev<int> dt((size_t)ntris * 3);
+        Dev<unsigned long long> k0(ne);
+        HIP_CHECK(hipMemcpy(dpts.p, points, (size_t)npoints * 3 * sizeof(double), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dt.p, tris, (size_t)ntris * 3 * sizeof(int), hipMemcpyHostToDevice));
+        if (c_tri) HIP_CHECK(hipMemcpy(dc.p, c_tri, (size_t)ntris * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(p1_boundary_kernel, dim3((unsigned)((ntris + 255) / 256)), dim3(256), 0, 0, dpts.p, dt.p, c_tri ? dc.p : nullptr, ntris, npoints,
+                           k0.p, bv.p);
+        HIP_CHECK(hipGetLastError());
+        *out = triplets_to_csr(npoints, ne, k0, bv, nullptr);
+        return WAE_OK;
+    });
+}
+
+int wae_p1_assemble_flame(int32_t device, int64_t npoints, const double *points, int64_t ntets, const int32_t *tets, int64_t nflame,
+                          const int32_t *flame_tets, int32_t ref_tet, const double *n_ref, double nglobal_scaled, void **out, double *volume_out) {
+    return wae_guarded([&]() {
+        if (!(npoints > 0 && ntets > 0 && nflame > 0 && points && tets && flame_tets && n_ref && out)) throw WaeError(WAE_ERR_INVALID, "bad argument");
+        if (ref_tet < 0 || ref_tet >= ntets) throw WaeError(WAE_ERR_INVALID, "reference tetrahedron out of range");
+        for (int64_t i = 0; i < nflame; ++i)
+            if (flame_tets[i] < 0 || flame_tets[i] >= ntets) throw WaeError(WAE_ERR_INVALID, "flame tetrahedron out of range");
+        for (int64_t i = 0; i < ntets * 4; ++i)
+            if (tets[i] < 0 || tets[i] >= npoints) throw WaeError(WAE_ERR_INVALID, "tetrahedron refers to a point outside 0..npoints-1");
+        HIP_CHECK(hipSetDevice(device));
+        const size_t ne = (size_t)nflame * 16;
+        Dev<double> dpts((size_t)npoints * 3), adet((size_t)nflame), vol(1), qv(ne);
+        Dev<int> dt((size_t)ntets * 4), dl((size_t)nflame);
+        Dev<unsigned long long> k0(ne);
+        HIP_CHECK(hipMemcpy(dpts.p, points, (size_t)npoints * 3 * sizeof(double), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dt.p, tets, (size_t)ntets * 4 * sizeof(int), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dl.p, flame_tets, (size_t)nflame * sizeof(int), hipMemcpyHostToDevice));
+        const unsigned gb = (unsigned)((nflame + 255) / 256);
+        hipLaunchKernelGGL(p1_det_kernel, dim3(gb), dim3(256), 0, 0, dpts.p, dt.p, dl.p, nflame, adet.p);
+        HIP_CHECK(hipGetLastError());
+        // flame volume = sum |det J| / 6 (Meshutils.jl:757-767), summed in a fixed tree order on the device
+        size_t tb = 0;
+        HIP_CHECK(hipcub::DeviceReduce::Sum(nullptr, tb, adet.p, vol.p, (int)nflame));
+        Dev<char> tmp(tb);
+        HIP_CHECK(hipcub::DeviceReduce::Sum(tmp.p, tb, adet.p, vol.p, (int)nflame));
+        double det_sum = 0.0;
+        HIP_CHECK(hipMemcpy(&det_sum, vol.p, sizeof(double), hipMemcpyDeviceToHost));
+        const double volume = det_sum / 6.0;
+        if (!(volume > 0.0)) throw WaeError(WAE_ERR_INVALID, "flame domain has no volume");
+        if (volume_out) *volume_out = volume;
+        const double nlocal = nglobal_scaled / volume;                                 // Helmholtz.jl:325
+        // g_b = -nlocal grad(phi_b) . n_ref on the reference tetrahedron (FEM.jl:2442-2448, Helmholtz.jl:482): 4 numbers, on the host
+        int rn[4];
+        double X[4][3];
+        for (int a = 0; a < 4; ++a) {
+            rn[a] = tets[(size_t)ref_tet * 4 + a];
+            for (int k = 0; k < 3; ++k) X[a][k] = points[(size_t)rn[a] * 3 + k];
+        }
+        double J[3][3];
+        for (int r = 0; r < 3; ++r)
+            for (int a = 0; a < 3; ++a) J[r][a] = X[a][r] - X[3][r];
+        const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1], c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2], c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+        const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+        if (det == 0.0) throw WaeError(WAE_ERR_INVALID, "degenerate reference tetrahedron");
+        const double id = 1.0 / det;
+        double G[4][3];
+        G[0][0] = c00 * id; G[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id; G[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+        G[1][0] = c01 * id; G[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id; G[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+        G[2][0] = c02 * id; G[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id; G[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+        for (int k = 0; k < 3; ++k) G[3][k] = -(G[0][k] + G[1][k] + G[2][k]);
+        double g[4];
+        for (int b = 0; b < 4; ++b) g[b] = -nlocal * (G[b][0] * n_ref[0] + G[b][1] * n_ref[1] + G[b][2] * n_ref[2]);
+        hipLaunchKernelGGL(p1_flame_kernel, dim3(gb), dim3(256), 0, 0, dt.p, dl.p, nflame, adet.p, rn[0], rn[1], rn[2], rn[3], g[0], g[1], g[2], g[3], npoints,
+                           k0.p, qv.p);
+        HIP_CHECK(hipGetLastError());
+        *out = triplets_to_csr(npoints, ne, k0, qv, nullptr);
+        return WAE_OK;
+    });
+}
 
 int wae_p1_assemble(int32_t device, int64_t npoints, const double *points, int64_t ntets, const int32_t *tets, const double *c_tet, void **out) {
     return wae_guarded([&]() {
@@ -208,49 +388,16 @@ int wae_p1_assemble(int32_t device, int64_t npoints, const double *points, int64
             if (tets[i] < 0 || tets[i] >= npoints) throw WaeError(WAE_ERR_INVALID, "tetrahedron refers to a point outside 0..npoints-1");
         HIP_CHECK(hipSetDevice(device));
         const size_t ne = (size_t)ntets * 16;
-        Dev<double> dpts((size_t)npoints * 3), dc(c_tet ? (size_t)ntets : 1), mv(ne), kv(ne), ms(ne), ks(ne), mu(ne), ku(ne);
-        Dev<int> dt((size_t)ntets * 4), dcol(ne), drow((size_t)npoints + 1), dnum(1);
-        Dev<unsigned long long> k0(ne), k1(ne), ku0(ne);
-        Dev<unsigned int> i0(ne), i1(ne);
+        Dev<double> dpts((size_t)npoints * 3), dc(c_tet ? (size_t)ntets : 1), mv(ne), kv(ne);
+        Dev<int> dt((size_t)ntets * 4);
+        Dev<unsigned long long> k0(ne);
         HIP_CHECK(hipMemcpy(dpts.p, points, (size_t)npoints * 3 * sizeof(double), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(dt.p, tets, (size_t)ntets * 4 * sizeof(int), hipMemcpyHostToDevice));
         if (c_tet) HIP_CHECK(hipMemcpy(dc.p, c_tet, (size_t)ntets * sizeof(double), hipMemcpyHostToDevice));
         hipLaunchKernelGGL(p1_local_kernel, dim3((unsigned)((ntets + 255) / 256)), dim3(256), 0, 0, dpts.p, dt.p, c_tet ? dc.p : nullptr, ntets, npoints,
                            k0.p, mv.p, kv.p);
         HIP_CHECK(hipGetLastError());
-        const unsigned g = (unsigned)std::min<size_t>((ne + 255) / 256, 8192);
-        hipLaunchKernelGGL(iota_kernel, dim3(g), dim3(256), 0, 0, i0.p, ne);
-        // stable sort of (key, triplet index)
-        int bits = 1;
-        while (bits < 64 && ((unsigned long long)npoints * (unsigned long long)npoints) >> bits) ++bits;
-        size_t tmp_bytes = 0;
-        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k0.p, k1.p, i0.p, i1.p, (int)ne, 0, bits));
-        Dev<char> tmp(tmp_bytes);
-        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, k0.p, k1.p, i0.p, i1.p, (int)ne, 0, bits));
-        hipLaunchKernelGGL(gather_d_kernel, dim3(g), dim3(256), 0, 0, mv.p, i1.p, ms.p, ne);
-        hipLaunchKernelGGL(gather_d_kernel, dim3(g), dim3(256), 0, 0, kv.p, i1.p, ks.p, ne);
-        // segment sums
-        size_t tb2 = 0;
-        HIP_CHECK(hipcub::DeviceReduce::ReduceByKey(nullptr, tb2, k1.p, ku0.p, ms.p, mu.p, dnum.p, hipcub::Sum(), (int)ne));
-        Dev<char> tmp2(tb2);
-        HIP_CHECK(hipcub::DeviceReduce::ReduceByKey(tmp2.p, tb2, k1.p, ku0.p, ms.p, mu.p, dnum.p, hipcub::Sum(), (int)ne));
-        HIP_CHECK(hipcub::DeviceReduce::ReduceByKey(tmp2.p, tb2, k1.p, ku0.p, ks.p, ku.p, dnum.p, hipcub::Sum(), (int)ne));
-        int nnz = 0;
-        HIP_CHECK(hipMemcpy(&nnz, dnum.p, sizeof(int), hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemset(drow.p, 0xff, ((size_t)npoints + 1) * sizeof(int)));          // -1 = row without entries
-        hipLaunchKernelGGL(split_keys_kernel, dim3(g), dim3(256), 0, 0, ku0.p, (size_t)nnz, (unsigned long long)npoints, dcol.p, drow.p);
-        HIP_CHECK(hipGetLastError());
-        auto *H = new P1Handle;
-        H->np = npoints; H->nnz = nnz;
-        H->rowptr.resize((size_t)npoints + 1); H->col.resize(nnz); H->m.resize(nnz); H->k.resize(nnz);
-        HIP_CHECK(hipMemcpy(H->rowptr.data(), drow.p, ((size_t)npoints + 1) * sizeof(int), hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(H->col.data(), dcol.p, (size_t)nnz * sizeof(int), hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(H->m.data(), mu.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(H->k.data(), ku.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost));
-        H->rowptr[npoints] = nnz;
-        for (int64_t r = npoints - 1; r >= 0; --r)
-            if (H->rowptr[r] < 0) H->rowptr[r] = H->rowptr[r + 1];
-        *out = H;
+        *out = triplets_to_csr(npoints, ne, k0, mv, &kv);
         return WAE_OK;
     });
 }

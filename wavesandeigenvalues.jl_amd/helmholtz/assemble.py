@@ -36,6 +36,52 @@ def assemble_p1(points, tets, c_tet=None, device=0, dtype=np.complex128):
     return (sp.csr_matrix((m.astype(dtype), col, rowptr), shape=shape), sp.csr_matrix((k.astype(dtype), col.copy(), rowptr.copy()), shape=shape))
 
 
+def _take_csr(L, h, dtype):
+    """copy a P1 handle out as a scipy CSR matrix (values = the `mass` array) and free it"""
+    dp = C.POINTER(C.c_double)
+    try:
+        n, nnz = C.c_int64(0), C.c_int64(0)
+        _lib.check(L.wae_p1_info(h, C.byref(n), C.byref(nnz)))
+        rowptr = np.zeros(n.value + 1, dtype=np.int32)
+        col = np.zeros(nnz.value, dtype=np.int32)
+        v = np.zeros(nnz.value, dtype=np.float64)
+        _lib.check(L.wae_p1_get(h, rowptr.ctypes.data_as(C.POINTER(C.c_int32)), col.ctypes.data_as(C.POINTER(C.c_int32)), v.ctypes.data_as(dp), None))
+    finally:
+        L.wae_p1_free(h)
+    return sp.csr_matrix((v.astype(dtype), col, rowptr), shape=(n.value, n.value))
+
+
+def assemble_p1_boundary(points, tris, c_tri=None, device=0):
+    """Boundary mass term of an admittance boundary on the device (wae_p1_assemble_boundary):
+    C = -i·c·|e1×e2|·(1+δ_ab)/24 per boundary triangle (src/Helmholtz.jl:443-463, src/FEM/FEM.jl:435-441).  Returns C (complex CSR)."""
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    tt = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+    cc = None if c_tri is None else np.ascontiguousarray(c_tri, dtype=np.float64)
+    L = _lib.lib()
+    h = C.c_void_p()
+    dp = C.POINTER(C.c_double)
+    _lib.check(L.wae_p1_assemble_boundary(int(device), pts.shape[0], pts.ctypes.data_as(dp), tt.shape[0], tt.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          None if cc is None else cc.ctypes.data_as(dp), C.byref(h)))
+    return -1j * _take_csr(L, h, np.complex128)
+
+
+def assemble_p1_flame(points, tets, flame_tets, ref_tet, n_ref, nglobal_scaled, device=0):
+    """Flame operator Q = Σ_flame S ⊗ g on the device (wae_p1_assemble_flame; src/Helmholtz.jl:292-344,464-487):
+    ``nglobal_scaled`` = (γ-1)/ρ·Q02U0, the library divides by the flame volume it sums itself.  Returns (Q, V_flame)."""
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    tt = np.ascontiguousarray(tets, dtype=np.int32).reshape(-1, 4)
+    fl = np.ascontiguousarray(flame_tets, dtype=np.int32)
+    nr = np.ascontiguousarray(n_ref, dtype=np.float64)
+    L = _lib.lib()
+    h = C.c_void_p()
+    vol = C.c_double(0.0)
+    dp = C.POINTER(C.c_double)
+    ip = C.POINTER(C.c_int32)
+    _lib.check(L.wae_p1_assemble_flame(int(device), pts.shape[0], pts.ctypes.data_as(dp), tt.shape[0], tt.ctypes.data_as(ip), len(fl), fl.ctypes.data_as(ip),
+                                       int(ref_tet), nr.ctypes.data_as(dp), float(nglobal_scaled), C.byref(h), C.byref(vol)))
+    return _take_csr(L, h, np.complex128), vol.value
+
+
 def discrete_adjoint_shape_sensitivity(points, tets, c_tet, surface_points, sol, L, bnd_tris=None, bnd_c=None, Y=None, h=1e-9,
                                        device=0):
     """sens = discrete_adjoint_shape_sensitivity(...)   (src/shape_sensitivity.jl:16-141, full mesh, P1)
