@@ -98,6 +98,7 @@ def main():
                     help="snapshot points for projected initial guesses (wae_beyn_moments_rb); -1 = the package's automatic "
                          "rule min(40, points/2); 0 = every system from a zero guess")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-newton", action="store_true", help="skip the Newton-type refinement figures")
     ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of host time the CPU baseline may spend")
     args = ap.parse_args()
     if args.rb < 0:
@@ -183,7 +184,7 @@ def main():
             r = (fam.eig_residuals(np.array([L.coefficients(w) for w in Om]), P_dev=Pt.data_ptr())
                  if len(Om) else np.zeros(0))                                # the eigenvectors never leave the device
             t.append(time.time())
-            res = (Om, r, S)
+            res = (Om, r, S, Pd, mask)
             for name, a, b in (("moments", 0, 1), ("allreduce", 1, 2), ("d2h", 2, 3), ("svd_eig", 3, 4), ("residuals", 4, 5)):
                 tim[name] = t[b] - t[a]
         return info, res
@@ -217,9 +218,11 @@ def main():
     dt = float(dt.item())
 
     if rank == 0:
-        info, (Om, r, S) = last
+        info, (Om, r, S, Pd, inside_mask) = last
         good = r <= 1e-6
         n_eig = int(good.sum())
+        good_mask_full = np.zeros(len(inside_mask), dtype=bool)        # columns of Pd (all Ritz pairs) that are verified eigenpairs
+        good_mask_full[np.nonzero(inside_mask)[0][good]] = True
         # roofline of the dominant kernel, measured live (HIP events on the library's stream)
         cz = L.coefficients(2 * np.pi * (500 + 20j))
         mask = [1 if c != 0 else 0 for c in cz]
@@ -233,12 +236,14 @@ def main():
         tri = _C.c_double(0.0)                 # device triad a = b + s*c over 2^27 doubles: the streaming rate this GPU attains
         _wl.check(_wl.lib().wae_bench_triad(int(os.environ.get("LOCAL_RANK", 0)), 1 << 27, 20, _C.byref(tri)))
         traffic = None       # HBM bytes per launch from the PMC passes committed under profiles/ (not collectable in-run)
-        tfile = os.path.join(ROOT, "profiles", f"r01_spmv_traffic_{args.preset}.json")
+        tfile = os.path.join(ROOT, "profiles", f"r02_spmv_traffic_{args.preset}.json")
         if os.path.exists(tfile):
             tj = json.load(open(tfile))
             if tj.get("preset") == args.preset and tj.get("r") == rb:
                 traffic = tj["traffic_bytes"]
-        roof = {"bound": "hbm", "kernel": "spmv_lds_kernel<4> (fused multi-term complex CSR SpMV, r columns per launch)",
+        tiled = os.environ.get("WAE_SPMV_TILE", "1") != "0" and os.environ.get("WAE_REORDER", "1") != "0"
+        roof = {"bound": "hbm", "kernel": ("spmv_tile_kernel<true>" if tiled else "spmv_lds_kernel<4>")
+                                          + " (fused multi-term complex CSR SpMV of the fine level, r columns per launch)",
                 "achieved": abytes / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": abytes / ms / 1e6 / HBM_PEAK_GBS, "traffic": traffic,
                 "r": rb, "us_per_launch": ms * 1e3, "algorithmic_bytes": int(abytes),
@@ -273,6 +278,27 @@ def main():
             "step_breakdown_seconds": {k: round(v, 4) for k, v in tim.items()},
             "roofline": roof,
         }
+        if world == 1 and not args.no_newton:
+            # The Newton-type half of the hot path (north_star names it beside Beyn): every Beyn estimate refined by `householder`
+            # (Householder.jl:70-192; two shift-invert Arnoldi processes + one first-order perturbation per Newton step), all
+            # estimates in one lock-step batch.  Outside the timed region; its own figures.
+            from wae_amd.nlevp import householder_many
+            P_host = Pd[:, torch.from_numpy(good_mask_full).to(Pd.device)].cpu().numpy() if n_eig else np.zeros((d, 0), dtype=complex)
+            t0n = time.time()
+            tol_beyn = L.solver_tol
+            L.solver_tol = 1e-12                  # the Ritz test of the shift-invert Arnoldi (1e-12) needs inner solves at least as accurate
+            try:
+                outs = householder_many(L, list(Om[good]), maxiter=6, tol=1e-8 * 2 * np.pi, v0s=P_host) if n_eig else []
+            finally:
+                L.solver_tol = tol_beyn
+            t_newton = time.time() - t0n
+            conv = [o for o in outs if o[2] in (0, 1)]
+            shift = [abs(o[0].params["ω"] - w) / abs(w) for o, w in zip(outs, Om[good])]
+            out["newton"] = {"what": "householder_many over the Beyn estimates (tol 1e-8 Hz-relative step, at most 6 Newton steps)",
+                             "eigenpairs_refined_per_sec": len(conv) / t_newton if t_newton > 0 else None, "seconds": t_newton,
+                             "refined": len(conv), "of": len(outs), "newton_steps": [int(o[1]) for o in outs],
+                             "largest_relative_shift_from_beyn_estimate": float(max(shift)) if shift else None,
+                             "spmv_r1": roof["r1"], "spmv_r8": roof["r8"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.l, args.N, max(n_eig, 1), d, args.tau, args.n, budget_s=args.cpu_budget)
         print(json.dumps(out))

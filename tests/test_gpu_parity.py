@@ -893,3 +893,38 @@ def test_device_p1_assembly_of_boundary_mass_and_flame_operators():
     assert (abs(Q2) > 1e-10 * abs(Qn).max()).nnz == (abs(Qn) > 1e-10 * abs(Qn).max()).nnz
     with pytest.raises(_lib.WaeError):
         assemble_p1_flame(pts, tets, sel, len(tets) + 3, [0.0, 0.0, 1.0], 1.0)
+
+
+def test_long_rows_are_split_off_and_summed_by_a_workgroup(monkeypatch):
+    """Rows with many entries (the reference nodes' rows of the TRANSPOSED flame term: one entry per flame node, ~5 000 at 1M DoF)
+    leave the groups' CSR arrays and are summed by a pre-kernel (OpDev::long_*).  With the threshold lowered to 32 entries the
+    small annulus has such rows in the T orientation of Q (75 entries each) and, through the dense admittance-like term
+    added here, in the N orientation too: every batch width, every op, the per-term-input product and a solve agree with scipy."""
+    monkeypatch.setenv("WAE_LONG_ROW", "32")
+    pb = annulus.build("small")
+    T = dict(pb["terms"])
+    d = pb["d"]
+    # a few dense-ish rows in N orientation: couple node 5 and node 77 to 200 other nodes (non-symmetric, complex)
+    rng = np.random.default_rng(11)
+    cols = rng.choice(d, 200, replace=False)
+    E = sp.coo_matrix((rng.standard_normal(400) + 1j * rng.standard_normal(400), (np.repeat([5, 77], 200), np.tile(cols, 2))), shape=(d, d)).tocsr()
+    Lp = helmholtz_family(T, n=0.8, tau=3e-4)
+    Lp.push(Term(E, (pow1,), (("ω",),), "ω", "E"))
+    z = 2 * np.pi * (500 + 20j)
+    A = (z * z * T["M"] + T["K"] + z * 1e15 * T["C"] + 0.8 * np.exp(-1j * z * 3e-4) * T["Q"] + z * E).tocsr()
+    for r in (1, 3, 8, 16, 33):
+        X = rng.standard_normal((d, r)) + 1j * rng.standard_normal((d, r))
+        assert relerr(Lp(z) @ X, A @ X) < 1e-13
+        assert relerr(Lp(z).H @ X, A.conj().T @ X) < 1e-13
+    fam = Lp.device()
+    Tn = len(Lp.terms)
+    Xm = rng.standard_normal((d, Tn)) + 1j * rng.standard_normal((d, Tn))
+    cs = rng.standard_normal(Tn) + 1j * rng.standard_normal(Tn)
+    want = sum(cs[k] * (sp.csr_matrix(Lp.terms[k].coeff) @ Xm[:, k]) for k in range(Tn))
+    assert relerr(fam.spmv_multi(cs, Xm), want) < 1e-13
+    Lp.solver_ref = 2 * np.pi * 500.0
+    B = rng.standard_normal((d, 4)) + 1j * rng.standard_normal((d, 4))
+    import scipy.sparse.linalg as spla
+    Xs = Lp(z).H.solve(B, tol=1e-12)
+    assert relerr(Xs, spla.splu(A.conj().T.tocsc()).solve(B)) < 1e-7
+    Lp._drop_device()

@@ -24,6 +24,46 @@ __device__ __forceinline__ cplx cdiv(cplx a, cplx b) {
     return cplx{(a.x * b.x + a.y * b.y) * s, (a.y * b.x - a.x * b.y) * s};
 }
 
+// Long rows (OpDev): long_acc[i][b] = sum over the entries of long row i of pc[sys(b)][slot] * val * X[col][b].  One workgroup
+// per (long row, 8-column chunk): 32 lanes stride over the entries, 8 lanes across the columns; fixed-order LDS reduction.
+__global__ __launch_bounds__(256) void spmv_long_kernel(OpDev op, const cplx *__restrict__ pc, int cps, const cplx *__restrict__ X, int nb,
+                                                        const unsigned char *__restrict__ cmask) {
+    __shared__ cplx red[256];
+    const int li = blockIdx.x, ch = blockIdx.y;
+    if (cmask && !cmask[ch]) return;
+    const int tid = threadIdx.x, c = tid & 7, seg = tid >> 3;
+    const int b = ch * 8 + c;
+    const int bb = b < nb ? b : nb - 1;
+    const int npl = op.nplanes_total;
+    const cplx *mypc = pc + (size_t)(bb / cps) * npl;
+    const double sg = op.long_conj ? -1.0 : 1.0;
+    cplx acc = {0.0, 0.0};
+    for (int p = op.long_ptr[li] + seg; p < op.long_ptr[li + 1]; p += 32) {
+        cplx a = op.long_val[p];
+        a.y *= sg;
+        const cplx m = cmul(mypc[op.long_slot[p]], a);
+        cfma(acc, m, X[(size_t)op.long_col[p] * nb + bb]);
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int off = 128; off >= 8; off >>= 1) {
+        if (tid < off) { red[tid].x += red[tid + off].x; red[tid].y += red[tid + off].y; }
+        __syncthreads();
+    }
+    if (tid < 8 && b < nb) op.long_acc[(size_t)li * nb + b] = red[tid];
+}
+// position of `row` in the sorted long-row list, or -1
+__device__ __forceinline__ int long_row_index(const OpDev &op, int64_t row) {
+    int lo = 0, hi = op.nlong - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const int v = op.long_rows[mid];
+        if (v == row) return mid;
+        if (v < row) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // fused multi-term CSR SpMV / SpMM:   Y = f( sum_q pc[sys(b)][q] * plane_q * X )   for nb columns
 //
@@ -133,6 +173,10 @@ __global__ __launch_bounds__(256) void spmv_kernel(OpDev op, const cplx *__restr
         acc.y += __shfl_xor(acc.y, off);
     }
     if (s != 0 || !active) return;
+    if (op.nlong) {                                          // this row's long part was summed by spmv_long_kernel
+        const int li = long_row_index(op, row);
+        if (li >= 0) { const cplx t = op.long_acc[(size_t)li * nb + b]; acc.x += t.x; acc.y += t.y; }
+    }
     const size_t e = (size_t)row * nb + b;
     cplx out;
     if (mode == MODE_AX) {
@@ -304,10 +348,12 @@ __global__ __launch_bounds__(256, 4) void spmv_lds_kernel(OpDev op, const cplx *
         }
     }
     if (!valid) return;
+    const int li_long = op.nlong ? long_row_index(op, row) : -1;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         if (!act[k]) continue;
         const int b = col0 + k * C + c;
+        if (li_long >= 0) { const cplx t = op.long_acc[(size_t)li_long * nb + b]; acc[k].x += t.x; acc[k].y += t.y; }
         const cplx *mypc = spc + (k * C + c) * npl;
         const size_t e = (size_t)row * nb + b;
         cplx out;
@@ -683,6 +729,12 @@ void launch_spmv(const OpDev &op, const cplx *pc, int cps, const cplx *X, cplx *
         launch_spmv_tile(op, *op.tiles, pc, cps, X, Y, B, jac_w, nb, mode, st, cmask);
         return;
     }
+    if (op.nlong) {
+        if (nb > 256) throw WaeError(WAE_ERR_INVALID, "launch_spmv: batch wider than 256 columns");
+        hipLaunchKernelGGL(spmv_long_kernel, dim3((unsigned)op.nlong, (unsigned)((nb + 7) / 8)), dim3(256), 0, st, op, pc, cps, X, nb,
+                           nb >= 8 ? cmask : (const unsigned char *)nullptr);
+        HIP_CHECK(hipGetLastError());
+    }
     if (mode == MODE_AX_J0 && !(C == 8 && S == 1 && env_int("WAE_SPMV_LDS", 1))) {   // only the wide fine-level kernel fuses the sweep
         launch_spmv(op, pc, cps, X, Y, nullptr, 0.0, nb, MODE_AX, st, cmask);
         launch_jacobi0(op, pc, cps, Y, const_cast<cplx *>(B), jac_w, nb, st, cmask);
@@ -833,6 +885,16 @@ __global__ __launch_bounds__(256) void spmv_multi_kernel(OpDev op, const cplx *_
                 cfma(acc, m, X[(size_t)j * nb + plane_col[G.plane0 + q]]);
             }
         }
+    }
+    if (op.nlong) {                                          // long rows live outside the groups' arrays: walk them here
+        const int li = long_row_index(op, row);
+        if (li >= 0)
+            for (int p = op.long_ptr[li] + s; p < op.long_ptr[li + 1]; p += S) {
+                cplx a = op.long_val[p];
+                if (op.long_conj) a.y = -a.y;
+                const int slot = op.long_slot[p];
+                cfma(acc, cmul(pc[slot], a), X[(size_t)op.long_col[p] * nb + plane_col[slot]]);
+            }
     }
     for (int off = 1; off < S; off <<= 1) {
         acc.x += __shfl_xor(acc.x, off);

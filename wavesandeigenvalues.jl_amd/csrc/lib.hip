@@ -6,6 +6,7 @@
 #include <cmath>
 #include <map>
 #include <memory>
+#include <tuple>
 
 #include "amg.h"
 #include "tiles.h"
@@ -26,6 +27,13 @@ OpDev LevelOp::dev(int op) const {
     o.diag = diag.p;
     o.conj_diag = (op == WAE_OP_C) ? 1 : 0;
     o.tiles = (tiles.ready && (op == WAE_OP_N || tiles.all_symmetric)) ? &tiles.dev : nullptr;
+    {
+        const LongRows &LR = (op == WAE_OP_N) ? long_n : long_t;
+        o.nlong = LR.n;
+        o.long_rows = LR.rows.p; o.long_ptr = LR.ptr.p; o.long_col = LR.col.p; o.long_slot = LR.slot.p;
+        o.long_val = LR.val.p; o.long_acc = LR.acc.p;
+        o.long_conj = (op == WAE_OP_C) ? 1 : 0;
+    }
     for (size_t g = 0; g < groups.size(); ++g) {
         const GroupHost &G = groups[g];
         GroupDev &D = o.g[g];
@@ -52,6 +60,7 @@ static OpDev transfer_dev(const DevBuf<int> &ptr, const DevBuf<int> &col, const 
     o.g[0].nplanes = 1;
     o.g[0].is_real = 1;
     o.tiles = nullptr;
+    o.nlong = 0;
     return o;
 }
 OpDev Transfer::devP() const { return transfer_dev(p_ptr, p_col, p_val, nf); }
@@ -145,6 +154,13 @@ static std::vector<int> build_levelop(LevelOp &L, const std::vector<CsrZ> &plane
     std::vector<int> slot_plane;
     L.groups.clear();
     L.groups.resize(grps.size());
+    struct LongEntries {
+        std::map<int, std::vector<std::tuple<int, int, zc>>> rows;      // row -> (column, slot, value)
+        void add(int r, int c, int slot, zc v) { rows[r].emplace_back(c, slot, v); }
+    };
+    LongEntries long_n, long_t;
+    L.long_n = LongRows();
+    L.long_t = LongRows();
     for (size_t gi = 0; gi < grps.size(); ++gi) {
         const Grp &g = grps[gi];
         GroupHost &G = L.groups[gi];
@@ -166,13 +182,35 @@ static std::vector<int> build_levelop(LevelOp &L, const std::vector<CsrZ> &plane
                     else { out[((size_t)p * np + k) * 2] = v.real(); out[((size_t)p * np + k) * 2 + 1] = v.imag(); }
                 }
         };
-        std::vector<const CsrZ *> mats;
-        for (int q : g.members) mats.push_back(&planes[q]);
-        std::vector<double> packed;
-        pack(mats, packed);
-        G.rowptr.upload(A0.ptr.data(), A0.ptr.size(), st);
-        G.col.upload(A0.col.data(), A0.col.size(), st);
-        G.vals.upload(packed.data(), packed.size(), st);
+        // long rows go to the level's long-row store (OpDev) and leave the group's CSR arrays
+        auto strip = [&](const std::vector<CsrZ> &src, std::vector<CsrZ> &kept, LongEntries &LE) {
+            kept.clear();
+            std::vector<char> is_long(src[0].n, 0);
+            bool any = false;
+            const int limit = getenv("WAE_LONG_ROW") ? std::max(1, atoi(getenv("WAE_LONG_ROW"))) : WAE_LONG_ROW;   // (tests lower it)
+            for (int64_t i = 0; i < src[0].n; ++i)
+                if (src[0].ptr[i + 1] - src[0].ptr[i] > limit) { is_long[i] = 1; any = true; }
+            if (!any) return false;
+            for (size_t k = 0; k < src.size(); ++k) {
+                const CsrZ &A = src[k];
+                CsrZ B;
+                B.n = A.n; B.m = A.m;
+                B.ptr.assign(A.n + 1, 0);
+                for (int64_t i = 0; i < A.n; ++i) {
+                    if (is_long[i]) {
+                        for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) LE.add((int)i, A.col[p], G.plane0 + (int)k, A.val[p]);
+                    } else {
+                        B.col.insert(B.col.end(), A.col.begin() + A.ptr[i], A.col.begin() + A.ptr[i + 1]);
+                        B.val.insert(B.val.end(), A.val.begin() + A.ptr[i], A.val.begin() + A.ptr[i + 1]);
+                    }
+                    B.ptr[i + 1] = (int)B.col.size();
+                }
+                kept.push_back(std::move(B));
+            }
+            return true;
+        };
+        std::vector<CsrZ> own;
+        for (int q : g.members) own.push_back(planes[q]);
         // transpose orientation (exact symmetry test: bitwise)
         std::vector<CsrZ> tr;
         bool sym = (A0.n == A0.m);
@@ -181,17 +219,52 @@ static std::vector<int> build_levelop(LevelOp &L, const std::vector<CsrZ> &plane
             if (sym && !(tr.back().ptr == planes[q].ptr && tr.back().col == planes[q].col && tr.back().val == planes[q].val)) sym = false;
         }
         G.symmetric = sym;
+        std::vector<CsrZ> kept;
+        const bool stripped_n = strip(own, kept, long_n);
+        if (stripped_n && sym) {                             // the T orientation aliases these arrays: same rows, same entries
+            std::vector<CsrZ> dummy;
+            strip(own, dummy, long_t);
+        }
+        const std::vector<CsrZ> &src_n = stripped_n ? kept : own;
+        std::vector<const CsrZ *> mats;
+        for (const CsrZ &M : src_n) mats.push_back(&M);
+        std::vector<double> packed;
+        pack(mats, packed);
+        G.rowptr.upload(src_n[0].ptr.data(), src_n[0].ptr.size(), st);
+        G.col.upload(src_n[0].col.data(), src_n[0].col.size(), st);
+        G.vals.upload(packed.data(), packed.size(), st);
+        std::vector<CsrZ> kept_t;
         if (!sym) {
+            const bool stripped_t = strip(tr, kept_t, long_t);
+            const std::vector<CsrZ> &src_t = stripped_t ? kept_t : tr;
             std::vector<const CsrZ *> tm;
-            for (auto &t : tr) tm.push_back(&t);
+            for (const CsrZ &t : src_t) tm.push_back(&t);
             std::vector<double> tp;
             pack(tm, tp);
-            G.rowptr_t.upload(tr[0].ptr.data(), tr[0].ptr.size(), st);
-            G.col_t.upload(tr[0].col.data(), tr[0].col.size(), st);
+            G.rowptr_t.upload(src_t[0].ptr.data(), src_t[0].ptr.size(), st);
+            G.col_t.upload(src_t[0].col.data(), src_t[0].col.size(), st);
             G.vals_t.upload(tp.data(), tp.size(), st);
         }
         HIP_CHECK(hipStreamSynchronize(st));   // host staging buffers die at scope end
     }
+    auto upload_long = [&](const LongEntries &LE, LongRows &LR) {
+        LR.n = (int)LE.rows.size();
+        if (!LR.n) return;
+        std::vector<int> rows, ptr(1, 0), col, slot;
+        std::vector<cplx> val;
+        for (const auto &kv : LE.rows) {
+            rows.push_back(kv.first);
+            for (const auto &e : kv.second) { col.push_back(std::get<0>(e)); slot.push_back(std::get<1>(e)); val.push_back(cplx{std::get<2>(e).real(), std::get<2>(e).imag()}); }
+            ptr.push_back((int)col.size());
+        }
+        LR.rows.upload(rows.data(), rows.size(), st); LR.ptr.upload(ptr.data(), ptr.size(), st);
+        LR.col.upload(col.data(), col.size(), st); LR.slot.upload(slot.data(), slot.size(), st);
+        LR.val.upload(val.data(), val.size(), st);
+        LR.acc.alloc((size_t)LR.n * 256);                     // batch widths up to 256 columns
+        HIP_CHECK(hipStreamSynchronize(st));
+    };
+    upload_long(long_n, L.long_n);
+    upload_long(long_t, L.long_t);
     // diagonals [n][nplanes] in slot order
     std::vector<cplx> dg((size_t)L.n * L.nplanes, cplx{0.0, 0.0});
     for (int s = 0; s < L.nplanes; ++s) {

@@ -92,7 +92,19 @@ struct OpDev {
     const cplx *diag;               // [n][nplanes_total] diagonal of every plane (for Jacobi), may be null
     int conj_diag;                  // op = C: use conj(diag) (coefficients arrive already conjugated)
     const TileDev *tiles;           // HOST pointer (read by launch_spmv only): tile-local storage valid for this orientation, or null
+    // Long rows (more than WAE_LONG_ROW entries in a group: e.g. the reference nodes' rows of the transposed flame term, one
+    // entry per flame node) are taken out of the groups' CSR arrays: a team of 8 lanes walking 5 000 dependent gathers held
+    // the whole launch (100 ms per Krylov iteration of an adjoint solve at 1M DoF).  A pre-kernel sums them with a whole
+    // workgroup per row into long_acc; the row kernels add that in.
+    int nlong;
+    const int *long_rows;           // sorted
+    const int *long_ptr;            // nlong+1 offsets into the entries
+    const int *long_col, *long_slot;   // per entry: column, plane slot (coefficient index)
+    const cplx *long_val;           // per entry: value
+    cplx *long_acc;                 // [nlong][nb max] scratch filled by launch_spmv's pre-kernel
+    int long_conj;                  // conjugate the entry values (op = C on complex planes)
 };
+constexpr int WAE_LONG_ROW = 256;
 
 // device buffer: owns its allocation (freed on destruction, so an exception that leaves a C-ABI entry through guarded()
 // releases every function-local buffer); movable, not copyable
@@ -144,12 +156,19 @@ struct TileStore {                  // device arrays behind a TileDev
     bool all_symmetric = false;     // every group symmetric: the N-orientation tiles serve op = T/C as well
 };
 
+struct LongRows {                   // device arrays of the long rows of one orientation (see OpDev)
+    int n = 0;
+    DevBuf<int> rows, ptr, col, slot;
+    DevBuf<cplx> val, acc;
+};
+
 struct LevelOp {                    // sum_q pc[q] * plane_q  at one multigrid level
     int64_t n = 0;
     int nplanes = 0;
     std::vector<GroupHost> groups;
     DevBuf<cplx> diag;              // [n][nplanes]
     TileStore tiles;
+    LongRows long_n, long_t;        // long rows in N orientation / in T orientation
     OpDev dev(int op) const;        // op: WAE_OP_N / T / C
     // host copies of the planes (kept for Galerkin products and dense coarse assembly)
     std::vector<CsrZ> planes;
