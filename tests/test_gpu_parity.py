@@ -740,13 +740,17 @@ print(json.dumps({"its": i["iters_total"], "unconv": i["n_unconverged"], "sum": 
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
-    for name, extra in (("default", {}), ("guard", {"WAE_LAZY_LIMIT": "3"}), ("explicit", {"WAE_LAZY": "0"})):
+    # "host": the recurrence (Hessenberg / Givens / flags) on the host with a synchronisation per iteration, as in round 1;
+    # the default keeps it on the device (gmres_wide) and looks at the status words every 4 iterations, "sync1" every iteration
+    for name, extra in (("default", {}), ("guard", {"WAE_LAZY_LIMIT": "3"}), ("explicit", {"WAE_LAZY": "0"}),
+                        ("host", {"WAE_GMRES_DEVICE": "0"}), ("host_guard", {"WAE_GMRES_DEVICE": "0", "WAE_LAZY_LIMIT": "3"}),
+                        ("sync1", {"WAE_GMRES_SYNC": "1"})):
         env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         import json
         out[name] = json.loads(r.stdout.strip().splitlines()[-1])
-    for name in ("guard", "explicit"):
+    for name in ("guard", "explicit", "host", "host_guard", "sync1"):
         assert out[name]["unconv"] == 0 and out["default"]["unconv"] == 0
         assert abs(out[name]["its"] - out["default"]["its"]) <= 0.02 * out["default"]["its"]
         assert np.allclose(out[name]["sum"], out["default"]["sum"], rtol=1e-8)

@@ -1668,6 +1668,174 @@ void launch_beyn_accum(const cplx *Xi, int nb, int64_t d, int l, int nsys, const
     HIP_CHECK(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The small-matrix half of the lock-step GMRES on the device (lib.hip gmres_wide): one thread per column keeps that column's
+// Hessenberg column, Givens rotations, residual estimate and convergence flags in HBM, so that no iteration ends in a
+// device-to-host copy + stream synchronisation (round 1: 51 us of host turnaround per lock-step iteration).  The arithmetic is
+// the host loop's, statement for statement (same rotations, same tests), hence the same iterates.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gmres_init_kernel(GmresDev S, const cplx *__restrict__ beta, const unsigned char *__restrict__ done, int use_mask) {
+    __shared__ int act[256];
+    const int b = threadIdx.x;
+    int a = 0;
+    if (b < S.nb) {
+        S.g[b] = cplx{beta[b].x, 0.0};
+        S.sv[b] = 1.0;
+        S.vsq[b] = cplx{1.0, 0.0};
+        S.conv[b] = done[b] ? 1 : 0;
+        S.steps[b] = 0;
+        a = done[b] ? 0 : 1;
+    }
+    act[b] = a;
+    __syncthreads();
+    if (b < (S.nb + 7) / 8) {
+        int any = 0;
+        for (int k = 0; k < 8; ++k) any |= act[b * 8 + k];
+        S.cmask[b] = use_mask ? (unsigned char)any : (unsigned char)1;
+    }
+    if (b == 0) {
+        int n = 0;
+        for (int k = 0; k < S.nb; ++k) n += act[k];
+        S.status[0] = n; S.status[1] = 0; S.status[2] = 0;
+    }
+}
+
+// after Arnoldi step j: hd[i][b], i <= j: s_i^2-scaled dots of the new vector against the unnormalised basis; hd[j+1][b].x: norm of
+// the orthogonalised vector (lib.hip: "lazy" basis).  Produces the Hessenberg column of the normalised recurrence, rotates it,
+// updates g, the residual estimate and the flags; marks vectors whose running scale left [1/lim, lim] for renormalisation.
+__global__ __launch_bounds__(256) void gmres_step_kernel(GmresDev S, const cplx *__restrict__ hd, int j, double tol, double lim, int use_mask) {
+    __shared__ int act[256];
+    const int b = threadIdx.x;
+    const int nb = S.nb, m = S.m;
+    int a = 0;
+    if (b < nb) {
+        const int nvj = j + 1;
+        const double sj = S.sv[(size_t)j * nb + b];
+        const double r = hd[(size_t)nvj * nb + b].x;
+        double svn = r > 0.0 ? 1.0 / r : 0.0;
+        const bool resc = svn > lim || (svn > 0.0 && svn < 1.0 / lim);
+        S.rescale[b] = resc ? cplx{r, 0.0} : cplx{0.0, 0.0};
+        if (resc) {                                          // the vector is normalised in place by gmres_rescale_kernel
+            S.vsq[(size_t)nvj * nb + b] = cplx{svn > 0.0 ? 1.0 : 0.0, 0.0};
+            svn = svn > 0.0 ? 1.0 : 0.0;
+            atomicOr(&S.status[2], 1);
+        }
+        S.sv[(size_t)nvj * nb + b] = svn;
+        if (!S.conv[b]) {
+            cplx *Hc = S.R + (size_t)j * (m + 1) * nb;       // column j: entries i = 0..j+1 at Hc[i*nb + b]
+            for (int i = 0; i <= j; ++i) {
+                const double si = S.sv[(size_t)i * nb + b];
+                const double f = si > 0.0 ? sj / si : 0.0;
+                const cplx c = hd[(size_t)i * nb + b];
+                Hc[(size_t)i * nb + b] = cplx{c.x * f, c.y * f};
+            }
+            Hc[(size_t)(j + 1) * nb + b] = cplx{sj * r, 0.0};
+            for (int i = 0; i < j; ++i) {
+                const cplx aa = Hc[(size_t)i * nb + b], bb = Hc[(size_t)(i + 1) * nb + b];
+                const double c = S.cs[(size_t)i * nb + b];
+                const cplx sn = S.sn[(size_t)i * nb + b];
+                const cplx sb = cmul(sn, bb), ca = cmul(cconj(sn), aa);
+                Hc[(size_t)i * nb + b] = cplx{c * aa.x + sb.x, c * aa.y + sb.y};
+                Hc[(size_t)(i + 1) * nb + b] = cplx{-ca.x + c * bb.x, -ca.y + c * bb.y};
+            }
+            const cplx av = Hc[(size_t)j * nb + b];
+            const double bv = Hc[(size_t)(j + 1) * nb + b].x;
+            const double aabs = hypot(av.x, av.y);
+            const double t = sqrt(aabs * aabs + bv * bv);
+            if (!(t > 0.0) || isnan(t)) {
+                S.conv[b] = 1;
+                if (isnan(t)) atomicOr(&S.status[1], 1);
+            } else {
+                double c;
+                cplx sn;
+                if (aabs == 0.0) { c = 0.0; sn = cplx{1.0, 0.0}; }
+                else { c = aabs / t; const double q = bv / t; sn = cplx{av.x / aabs * q, av.y / aabs * q}; }
+                S.cs[(size_t)j * nb + b] = c;
+                S.sn[(size_t)j * nb + b] = sn;
+                Hc[(size_t)j * nb + b] = cplx{c * av.x + sn.x * bv, c * av.y + sn.y * bv};
+                Hc[(size_t)(j + 1) * nb + b] = cplx{0.0, 0.0};
+                const cplx gj = S.g[(size_t)j * nb + b];
+                const cplx gn = cmul(cconj(sn), gj);
+                S.g[(size_t)(j + 1) * nb + b] = cplx{-gn.x, -gn.y};
+                S.g[(size_t)j * nb + b] = cplx{c * gj.x, c * gj.y};
+                S.steps[b] = j + 1;
+                S.iters[b] += 1;
+                const double rr = hypot(gn.x, gn.y) / S.bnorm[b];
+                S.relres[b] = rr;
+                if (isnan(rr)) atomicOr(&S.status[1], 1);
+                const int hs = S.histlen[b];
+                if (hs < S.histcap) { S.hist[(size_t)hs * nb + b] = rr; S.histlen[b] = hs + 1; }
+                const int hn = hs + 1;
+                if (rr <= 0.7 * tol) S.conv[b] = 1;
+                else if (hn > 60 && hs < S.histcap && rr > 0.9 * S.hist[(size_t)(hn - 31) * nb + b]) { S.conv[b] = 1; S.stalled[b] = 1; }   // attainable accuracy reached
+                else a = 1;
+            }
+        }
+    }
+    act[b] = a;
+    __syncthreads();
+    if (b < (nb + 7) / 8 && use_mask) {
+        int any = 0;
+        for (int k = 0; k < 8; ++k) any |= act[b * 8 + k];
+        S.cmask[b] = (unsigned char)any;
+    }
+    if (b == 0) {
+        int n = 0;
+        for (int k = 0; k < nb; ++k) n += act[k];
+        S.status[0] = n;
+    }
+}
+
+// y = R^-1 g per column over that column's steps; out[i][b] = s_i y_i (coefficients against the unnormalised basis), 0 beyond
+__global__ __launch_bounds__(256) void gmres_solve_y_kernel(GmresDev S, int ju, cplx *__restrict__ out) {
+    const int b = threadIdx.x;
+    const int nb = S.nb, m = S.m;
+    if (b >= nb) return;
+    const int k = S.steps[b];
+    for (int i = k; i < ju; ++i) out[(size_t)i * nb + b] = cplx{0.0, 0.0};
+    for (int i = k - 1; i >= 0; --i) {
+        cplx sacc = S.g[(size_t)i * nb + b];
+        for (int q = i + 1; q < k; ++q) {
+            const cplx hq = S.R[((size_t)q * (m + 1) + i) * nb + b];
+            const cplx yq = out[(size_t)q * nb + b];
+            sacc.x -= hq.x * yq.x - hq.y * yq.y;
+            sacc.y -= hq.x * yq.y + hq.y * yq.x;
+        }
+        const cplx dg = S.R[((size_t)i * (m + 1) + i) * nb + b];
+        out[(size_t)i * nb + b] = (dg.x != 0.0 || dg.y != 0.0) ? cdiv(sacc, dg) : cplx{0.0, 0.0};
+    }
+    for (int i = 0; i < k; ++i) {
+        const double f = S.sv[(size_t)i * nb + b];
+        cplx y = out[(size_t)i * nb + b];
+        out[(size_t)i * nb + b] = cplx{f * y.x, f * y.y};
+    }
+}
+
+// columns flagged by gmres_step_kernel: V[row][b] /= factor[b]  (every workgroup leaves at once when no column is flagged)
+__global__ __launch_bounds__(256) void gmres_rescale_kernel(cplx *__restrict__ V, const cplx *__restrict__ factor, const int *__restrict__ status, size_t total, int nb) {
+    if (!status[2]) return;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const double f = factor[e % nb].x;
+        if (f > 0.0) { const cplx x = V[e]; V[e] = cplx{x.x / f, x.y / f}; }
+    }
+}
+__global__ void gmres_clear_rescale_kernel(int *status) { status[2] = 0; }
+
+void launch_gmres_init(const GmresDev &S, const cplx *beta, const unsigned char *done, int use_mask, hipStream_t st) {
+    hipLaunchKernelGGL(gmres_init_kernel, dim3(1), dim3(256), 0, st, S, beta, done, use_mask);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_gmres_step(const GmresDev &S, const cplx *hd, int j, double tol, double lim, int use_mask, cplx *Vnew, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(gmres_step_kernel, dim3(1), dim3(256), 0, st, S, hd, j, tol, lim, use_mask);
+    hipLaunchKernelGGL(gmres_rescale_kernel, dim3(512), dim3(256), 0, st, Vnew, S.rescale, S.status, (size_t)n * S.nb, S.nb);
+    hipLaunchKernelGGL(gmres_clear_rescale_kernel, dim3(1), dim3(1), 0, st, S.status);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_gmres_solve_y(const GmresDev &S, int ju, cplx *out, hipStream_t st) {
+    hipLaunchKernelGGL(gmres_solve_y_kernel, dim3(1), dim3(256), 0, st, S, ju, out);
+    HIP_CHECK(hipGetLastError());
+}
+
 // X[row][t] = sum_i G[i][t] * V_i[row]   (tall-skinny product of the perturbation regrouping; V_i = V + i*stride)
 __global__ __launch_bounds__(256) void gemv_multi_kernel(const cplx *__restrict__ V, size_t stride, int k, const cplx *__restrict__ G,
                                                          cplx *__restrict__ X, int64_t d, int T) {

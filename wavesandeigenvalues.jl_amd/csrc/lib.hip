@@ -110,6 +110,11 @@ struct wae_family {
     RbState rb;                      // the snapshot basis and its projected terms
     DevBuf<int> plane_col_dev;
     DevBuf<unsigned char> cmask;     // one byte per 8-column chunk of the current batch (0 = converged)
+    // device-resident recurrence of the wide-batch GMRES (gmres_wide)
+    DevBuf<cplx> gs_R, gs_sn, gs_g, gs_rescale;
+    DevBuf<double> gs_cs, gs_sv, gs_relres, gs_bnorm, gs_hist;
+    DevBuf<int> gs_int;              // conv | steps | iters | histlen | stalled | status(4)
+    DevBuf<unsigned char> gs_done;
     // penalty (Dirichlet-like) rows found at set-up: their sub-block as a small operator of its own (see penalty_polish)
     int64_t n_penalty = 0;
     LevelOp pen_op;
@@ -517,6 +522,174 @@ static void penalty_polish(wae_family *h, const Batch &bt, const cplx *B, cplx *
     launch_scatter_add_rows(x, h->pen_rows.p, nbk, nb, X, st);
 }
 
+// ----------------------------------------------------------------------------------------------------
+// wide-batch GMRES with the recurrence on the device
+// ----------------------------------------------------------------------------------------------------
+// The same left-preconditioned, lock-step, unnormalised-basis GMRES(m) as `gmres` below (its "lazy" branch), with the
+// per-column Hessenberg / Givens / convergence bookkeeping in kernels (kernels.hip gmres_*_kernel): an iteration is a chain of
+// launches with no device-to-host copy; the host looks at three status words every WAE_GMRES_SYNC iterations (default 4) and at
+// the per-column figures once per restart cycle.  Columns that converge between two looks are masked on the device at once
+// (their 8-column chunks are skipped by every kernel), so the overshoot costs launches, not traffic.
+static int gmres_wide(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double tol, int maxit, wae_solve_info *info, bool have_x0) {
+    hipStream_t st = h->stream;
+    const int nb = bt.nb;
+    const int64_t n = h->d;
+    const size_t vec = (size_t)n * nb;
+    const int m = (int)std::min<size_t>(150, h->V.n / vec - 1);
+    const OpDev A = h->ops[0].dev(bt.op);
+    const cplx *pc = pc_level(h, 0);
+    cplx *hp = h->h_pinned;
+    static const int ksync = getenv("WAE_GMRES_SYNC") ? std::max(1, atoi(getenv("WAE_GMRES_SYNC"))) : 4;
+    static const double lim = getenv("WAE_LAZY_LIMIT") ? atof(getenv("WAE_LAZY_LIMIT")) : 1e100;
+    static const char *env_mask = getenv("WAE_MASK");
+    const bool use_mask = env_mask ? atoi(env_mask) != 0 : have_x0;
+    const int nch = (nb + 7) / 8;
+    const int histcap = maxit + m + 8;
+    // device state
+    auto ens = [](auto &buf, size_t cnt) { if (buf.n < cnt) buf.alloc(cnt); };
+    ens(h->gs_R, (size_t)m * (m + 1) * nb); ens(h->gs_sn, (size_t)m * nb); ens(h->gs_g, (size_t)(m + 1) * nb); ens(h->gs_rescale, (size_t)nb);
+    ens(h->gs_cs, (size_t)m * nb); ens(h->gs_sv, (size_t)(m + 2) * nb); ens(h->gs_relres, (size_t)nb); ens(h->gs_bnorm, (size_t)nb);
+    ens(h->gs_hist, (size_t)histcap * nb); ens(h->gs_int, (size_t)5 * nb + 4); ens(h->gs_done, (size_t)nb);
+    if (h->cmask.n < (size_t)nch) h->cmask.alloc(nch);
+    if (h->vsq.n < (size_t)(m + 2) * nb) h->vsq.alloc((size_t)(m + 2) * nb);
+    GmresDev S;
+    S.nb = nb; S.m = m; S.histcap = histcap;
+    S.R = h->gs_R.p; S.cs = h->gs_cs.p; S.sn = h->gs_sn.p; S.g = h->gs_g.p; S.sv = h->gs_sv.p; S.vsq = h->vsq.p;
+    S.conv = h->gs_int.p; S.steps = S.conv + nb; S.iters = S.steps + nb; S.histlen = S.iters + nb; S.stalled = S.histlen + nb; S.status = S.stalled + nb;
+    S.relres = h->gs_relres.p; S.bnorm = h->gs_bnorm.p; S.hist = h->gs_hist.p; S.rescale = h->gs_rescale.p; S.cmask = h->cmask.p;
+    HIP_CHECK(hipMemsetAsync(h->gs_int.p, 0, ((size_t)5 * nb + 4) * sizeof(int), st));
+    if (!have_x0) launch_fill_zero(X, vec, st);
+    {
+        const cplx *zb = vcycle(h, bt, 0, B);
+        launch_norms(zb, n, nb, h->partial.p, h->hdev.p, st);
+    }
+    HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<double> bnorm(nb), relres(nb, 0.0);
+    std::vector<int> iters(nb, 0), hostint((size_t)5 * nb + 4);
+    std::vector<unsigned char> done(nb, 0);
+    std::vector<char> stalled(nb, 0);
+    for (int b = 0; b < nb; ++b) { bnorm[b] = hp[b].x; if (!(bnorm[b] > 0.0)) done[b] = 1; }
+    {
+        std::vector<double> bn(bnorm);
+        for (double &v : bn) if (!(v > 0.0)) v = 1.0;
+        HIP_CHECK(hipMemcpyAsync(h->gs_bnorm.p, bn.data(), nb * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    int total_it = 0;
+    bool first = !have_x0, x0_unchecked = have_x0, nan_seen = false;
+    double r0max = 0.0;
+    while (true) {
+        cplx *z0;
+        if (first) {
+            z0 = vcycle(h, bt, 0, B);
+        } else {
+            launch_spmv(A, pc, bt.cps, X, h->W.p, B, 0.0, nb, MODE_RES, st);
+            z0 = vcycle(h, bt, 0, h->W.p);
+        }
+        first = false;
+        launch_norms(z0, n, nb, h->partial.p, h->hdev.p, st);
+        HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, (size_t)nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (x0_unchecked) {
+            // a guess that is worse than no guess (an ill-conditioned projected system) is dropped, column by column
+            x0_unchecked = false;
+            std::vector<cplx> keep(nb, cplx{1.0, 0.0});
+            bool any_bad = false;
+            for (int b = 0; b < nb; ++b)
+                if (bnorm[b] > 0.0 && !(hp[b].x / bnorm[b] <= 1.0)) { keep[b] = cplx{0.0, 0.0}; any_bad = true; }
+            if (any_bad) {
+                h->ydev.upload(keep.data(), nb, st);
+                launch_mask_cols(X, h->ydev.p, n, nb, st);
+                HIP_CHECK(hipStreamSynchronize(st));
+                continue;
+            }
+        }
+        bool all_done = true;
+        for (int b = 0; b < nb; ++b) {
+            if (bnorm[b] > 0.0) {
+                relres[b] = hp[b].x / bnorm[b];
+                if (std::isnan(relres[b])) nan_seen = true;
+                done[b] = relres[b] <= tol || stalled[b];
+            }
+            if (!done[b]) all_done = false;
+        }
+        if (all_done || total_it >= maxit || nan_seen) break;
+        launch_scale_inv(z0, h->hdev.p, h->V.p, n, nb, st);                       // V0 = M^-1 r / beta
+        HIP_CHECK(hipMemcpyAsync(h->gs_done.p, done.data(), nb, hipMemcpyHostToDevice, st));
+        launch_gmres_init(S, h->hdev.p, h->gs_done.p, use_mask ? 1 : 0, st);
+        HIP_CHECK(hipStreamSynchronize(st));                                       // (`done` is reused by the host below)
+        const unsigned char *mk = (use_mask && nb >= 8) ? h->cmask.p : nullptr;
+        int j = 0;
+        int status[4] = {1, 0, 0, 0};
+        for (; j < m && total_it < maxit;) {
+            const cplx *vj = h->V.p + (size_t)j * vec;
+            const int nvj = j + 1;
+            const bool fuse0 = h->ops.size() > 1;
+            launch_spmv(A, pc, bt.cps, vj, h->W.p, fuse0 ? h->lx[0].p : nullptr, fuse0 ? h->jac_w : 0.0, nb, fuse0 ? MODE_AX_J0 : MODE_AX, st, mk);
+            cplx *w = vcycle(h, bt, 0, h->W.p, mk, fuse0);
+            launch_dots_scaled(h->V.p, vec, nvj, w, n, nb, h->partial.p, h->hdev.p, h->vsq.p, st, mk);
+            launch_axpy_neg_norm(h->V.p, vec, nvj, h->hdev.p, h->V.p + (size_t)nvj * vec, n, nb, h->partial.p, h->hdev.p + (size_t)nvj * nb, st, mk,
+                                 w, h->vsq.p + (size_t)nvj * nb);
+            launch_gmres_step(S, h->hdev.p, j, tol, lim, use_mask ? 1 : 0, h->V.p + (size_t)nvj * vec, n, st);
+            ++j;
+            ++total_it;
+            if (j % ksync == 0 || j == m || total_it >= maxit) {
+                HIP_CHECK(hipMemcpyAsync(status, S.status, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                if (status[1]) nan_seen = true;
+                if (status[0] == 0 || nan_seen) break;
+            }
+        }
+        // x += V y on the device, then the per-column figures of this cycle
+        if (j > 0) {
+            launch_gmres_solve_y(S, j, h->ydev.p, st);
+            launch_lincomb_add(h->V.p, vec, j, h->ydev.p, X, n, nb, st);
+        }
+        HIP_CHECK(hipMemcpyAsync(hostint.data(), h->gs_int.p, ((size_t)5 * nb + 4) * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(hp, h->gs_relres.p, nb * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        bool any_stalled_now = false;
+        const double *rr = (const double *)hp;
+        for (int b = 0; b < nb; ++b) {
+            iters[b] = hostint[(size_t)2 * nb + b];
+            stalled[b] = (char)hostint[(size_t)4 * nb + b];
+            any_stalled_now = any_stalled_now || stalled[b];
+            if (hostint[(size_t)nb + b] > 0 && bnorm[b] > 0.0) relres[b] = rr[b];      // columns that took steps in this cycle
+        }
+        if (hostint[(size_t)5 * nb + 1]) nan_seen = true;
+        if (nan_seen) break;
+        if (j <= 12 && !any_stalled_now) {
+            bool all_est = true;
+            for (int b = 0; b < nb; ++b) if (bnorm[b] > 0.0 && !(relres[b] <= tol)) all_est = false;
+            if (all_est) break;
+        }
+    }
+    if (have_x0 && !nan_seen) penalty_polish(h, bt, B, X);
+    static const bool dbg = getenv("WAE_GMRES_DEBUG") && atoi(getenv("WAE_GMRES_DEBUG"));
+    if (dbg) fprintf(stderr, "[gmres] nb=%d x0=%d lockstep_its=%d (device recurrence) r0 %.1e\n", nb, (int)have_x0, total_it, r0max);
+    if (info) {
+        int imax = 0, itot = 0, nun = 0;
+        double rmax = 0.0;
+        for (int b = 0; b < nb; ++b) {
+            imax = std::max(imax, iters[b]);
+            itot += iters[b];
+            if (bnorm[b] > 0.0) {
+                if (!(relres[b] <= tol)) ++nun;
+                rmax = std::max(rmax, relres[b]);
+            }
+        }
+        info->iters_max = std::max(info->iters_max, imax);
+        info->iters_total += itot;
+        info->n_unconverged += nun;
+        for (int b = 0; b < nb; ++b) if (stalled[b] && !(relres[b] <= tol)) info->levels |= 1 << 16;
+        info->relres_max = std::max(info->relres_max, rmax);
+        info->levels = (info->levels & (1 << 16)) | (int)h->ops.size();
+    }
+    if (nan_seen) throw WaeError(WAE_ERR_NAN, "NaN in GMRES");
+    return total_it;
+}
+
 // returns the number of lock-step iterations
 static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double tol, int maxit, wae_solve_info *info,
                  const cplx *guess_dir = nullptr, bool have_x0 = false) {
@@ -549,6 +722,8 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
     static const bool lazy_on = !(getenv("WAE_LAZY") && atoi(getenv("WAE_LAZY")) == 0);
     const size_t nslots = (size_t)m + off + 2;             // basis slots incl. the deflation vector and the newest vector
     const bool lazy = lazy_on && !reorth && nslots * nb <= 4096 && nslots * nb <= h->vsq.n;   // 4096: coefficients of one axpy launch
+    static const bool dev_rec = !(getenv("WAE_GMRES_DEVICE") && atoi(getenv("WAE_GMRES_DEVICE")) == 0);
+    if (dev_rec && lazy && !guess_dir && nb > 8 && nb <= 256) return gmres_wide(h, bt, B, X, tol, maxit, info, have_x0);
     std::vector<std::vector<double>> sv(lazy ? nslots : 0, std::vector<double>(nb, 1.0));
     const OpDev A = h->ops[0].dev(bt.op);
     const cplx *pc = pc_level(h, 0);

@@ -252,5 +252,24 @@ void launch_beyn_accum(const cplx *Xi, int nb, int64_t d, int l, int nsys, const
                        int lA = 0, int c0 = 0, const int *perm = nullptr);
 // X[row][t] = sum_i G[i][t] V_i[row], V_i = V + i*stride (single vectors), X interleaved with leading dimension T
 void launch_gemv_multi(const cplx *V, size_t stride, int k, const cplx *G, cplx *X, int64_t d, int T, hipStream_t s);
+// device-resident state of the lock-step GMRES recurrence (one thread per column, kernels.hip gmres_*_kernel)
+struct GmresDev {
+    int nb, m, histcap;
+    cplx *R;                // [m][m+1][nb]: rotated Hessenberg columns
+    double *cs;             // [m][nb]
+    cplx *sn;               // [m][nb]
+    cplx *g;                // [m+1][nb]
+    double *sv;             // [m+2][nb]: 1/norm of the unnormalised basis vectors (running products)
+    cplx *vsq;              // [m+2][nb]: 1/||v_i||^2 (read by dots_scaled)
+    int *conv, *steps, *iters, *histlen, *stalled;   // [nb]
+    double *relres, *bnorm; // [nb]
+    double *hist;           // [histcap][nb] residual history (stagnation test)
+    cplx *rescale;          // [nb] factor of a pending renormalisation (0 = none)
+    int *status;            // [0] active columns, [1] NaN seen, [2] renormalisation pending
+    unsigned char *cmask;   // per 8-column chunk: any active column
+};
+void launch_gmres_init(const GmresDev &S, const cplx *beta, const unsigned char *done, int use_mask, hipStream_t s);
+void launch_gmres_step(const GmresDev &S, const cplx *hd, int j, double tol, double lim, int use_mask, cplx *Vnew, int64_t n, hipStream_t s);
+void launch_gmres_solve_y(const GmresDev &S, int ju, cplx *out, hipStream_t s);
 // triad for bandwidth measurement
 void launch_triad(double *a, const double *b, const double *c, double s_, int64_t n, hipStream_t s);
