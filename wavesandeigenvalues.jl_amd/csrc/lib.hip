@@ -458,7 +458,9 @@ static cplx *vcycle(wae_family *h, const Batch &bt, int l, const cplx *b, const 
     launch_spmv(h->xfer[l].devR(), h->one_dev.p, 1 << 30, t, h->lb[l + 1].p, nullptr, 0.0, bt.nb, MODE_AX, st, cm);
     const cplx *xc = vcycle(h, bt, l + 1, h->lb[l + 1].p, cm);
     launch_prolong_add(h->xfer[l].p_ptr.p, h->xfer[l].p_col.p, h->xfer[l].p_val.p, h->xfer[l].nf, xc, x, bt.nb, st, cm);
-    for (int s = 0; s < h->nsweeps; ++s) {
+    static const int post_coarse = getenv("WAE_VC_POST_COARSE") ? atoi(getenv("WAE_VC_POST_COARSE")) : 1;
+    const int npost = (l >= 1 && !post_coarse) ? 0 : h->nsweeps;
+    for (int s = 0; s < npost; ++s) {
         launch_spmv(A, pc, bt.cps, x, t, b, h->jac_w, bt.nb, MODE_JAC, st, cm);
         std::swap(x, t);
     }
@@ -621,7 +623,7 @@ static int gmres_wide(wae_family *h, const Batch &bt, const cplx *B, cplx *X, do
         HIP_CHECK(hipStreamSynchronize(st));                                       // (`done` is reused by the host below)
         const unsigned char *mk = (use_mask && nb >= 8) ? h->cmask.p : nullptr;
         int j = 0;
-        int status[4] = {1, 0, 0, 0};
+        int status[4] = {nb, 0, 0, 0};
         for (; j < m && total_it < maxit;) {
             const cplx *vj = h->V.p + (size_t)j * vec;
             const int nvj = j + 1;
@@ -634,7 +636,9 @@ static int gmres_wide(wae_family *h, const Batch &bt, const cplx *B, cplx *X, do
             launch_gmres_step(S, h->hdev.p, j, tol, lim, use_mask ? 1 : 0, h->V.p + (size_t)nvj * vec, n, st);
             ++j;
             ++total_it;
-            if (j % ksync == 0 || j == m || total_it >= maxit) {
+            // look at the status words every ksync iterations -- every iteration once few columns are left (the end of the
+            // cycle is near: an overshoot iteration is ~25 launches of fully masked kernels)
+            if (j % ksync == 0 || j == m || total_it >= maxit || status[0] <= nb / 4) {
                 HIP_CHECK(hipMemcpyAsync(status, S.status, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
                 HIP_CHECK(hipStreamSynchronize(st));
                 if (status[1]) nan_seen = true;
