@@ -532,8 +532,10 @@ static void penalty_polish(wae_family *h, const Batch &bt, const cplx *B, cplx *
 // launches with no device-to-host copy; the host looks at three status words every WAE_GMRES_SYNC iterations (default 4) and at
 // the per-column figures once per restart cycle.  Columns that converge between two looks are masked on the device at once
 // (their 8-column chunks are skipped by every kernel), so the overshoot costs launches, not traffic.
+static double now_s();
 static int gmres_wide(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double tol, int maxit, wae_solve_info *info, bool have_x0) {
     hipStream_t st = h->stream;
+    const double t_dbg0 = now_s();
     const int nb = bt.nb;
     const int64_t n = h->d;
     const size_t vec = (size_t)n * nb;
@@ -580,7 +582,6 @@ static int gmres_wide(wae_family *h, const Batch &bt, const cplx *B, cplx *X, do
     }
     int total_it = 0;
     bool first = !have_x0, x0_unchecked = have_x0, nan_seen = false;
-    double r0max = 0.0;
     while (true) {
         cplx *z0;
         if (first) {
@@ -623,7 +624,8 @@ static int gmres_wide(wae_family *h, const Batch &bt, const cplx *B, cplx *X, do
         HIP_CHECK(hipStreamSynchronize(st));                                       // (`done` is reused by the host below)
         const unsigned char *mk = (use_mask && nb >= 8) ? h->cmask.p : nullptr;
         int j = 0;
-        int status[4] = {nb, 0, 0, 0};
+        int status[4] = {0, 0, 0, 0};
+        for (int b = 0; b < nb; ++b) status[0] += done[b] ? 0 : 1;              // columns still to converge at the start of this cycle
         for (; j < m && total_it < maxit;) {
             const cplx *vj = h->V.p + (size_t)j * vec;
             const int nvj = j + 1;
@@ -671,7 +673,13 @@ static int gmres_wide(wae_family *h, const Batch &bt, const cplx *B, cplx *X, do
     }
     if (have_x0 && !nan_seen) penalty_polish(h, bt, B, X);
     static const bool dbg = getenv("WAE_GMRES_DEBUG") && atoi(getenv("WAE_GMRES_DEBUG"));
-    if (dbg) fprintf(stderr, "[gmres] nb=%d x0=%d lockstep_its=%d (device recurrence) r0 %.1e\n", nb, (int)have_x0, total_it, r0max);
+    if (dbg) {
+        HIP_CHECK(hipStreamSynchronize(st));
+        int itot = 0;
+        for (int b = 0; b < nb; ++b) itot += iters[b];
+        fprintf(stderr, "[gmres] nb=%d x0=%d lockstep_its=%d column_its=%d %.1f ms (device recurrence)\n", nb, (int)have_x0, total_it, itot,
+                (now_s() - t_dbg0) * 1e3);
+    }
     if (info) {
         int imax = 0, itot = 0, nun = 0;
         double rmax = 0.0;
