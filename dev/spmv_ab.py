@@ -4,6 +4,9 @@ import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 import wae_amd  # noqa
+from wae_amd import _lib
+if os.environ.get("WAE_AB_LIB"):
+    _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ab", os.environ["WAE_AB_LIB"])
 from wae_amd.helmholtz.family import annulus_family
 preset = sys.argv[1] if len(sys.argv) > 1 else "C2"
 rs = [int(x) for x in sys.argv[2:]] or [64]

@@ -388,282 +388,508 @@ __global__ __launch_bounds__(256, 4) void spmv_lds_kernel(OpDev op, const cplx *
     }
 }
 
+// Side rows of the tile path (TileDev): side_acc[i][b] = sum over the entries of side row i of pc[sys(b)][slot] * val * X[col][b].
+// Thread = (side row, column): 8 lanes read one 128-B segment of an X row.
+__global__ __launch_bounds__(256) void spmv_side_kernel(TileDev td, int npl, int conj, const cplx *__restrict__ pc, int cps,
+                                                        const cplx *__restrict__ X, int nb, const unsigned char *__restrict__ cmask) {
+    const int ch = blockIdx.y;
+    if (cmask && !cmask[ch]) return;
+    const int i = blockIdx.x * 32 + (threadIdx.x >> 3), b = ch * 8 + (threadIdx.x & 7);
+    if (i >= td.nside || b >= nb) return;
+    const cplx *mypc = pc + (size_t)(b / cps) * npl;
+    const double sg = conj ? -1.0 : 1.0;
+    cplx acc = {0.0, 0.0};
+    const int beg = td.side_ptr[i], end = td.side_ptr[i + 1];
+    for (int p0 = beg; p0 < end; p0 += 8) {                  // eight entries at a time: three memory latencies per batch (entry,
+        int c[8], sl[8];                                     // operand, -) instead of two per entry
+        cplx a[8], x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + u < end ? p0 + u : end - 1;
+            c[u] = td.side_col[p]; sl[u] = td.side_slot[p]; a[u] = td.side_val[p];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = X[(size_t)c[u] * nb + b];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (p0 + u < end) { a[u].y *= sg; cfma(acc, cmul(mypc[sl[u]], a[u]), x[u]); }
+    }
+    td.side_acc[(size_t)i * nb + b] = acc;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Tile kernel for batch widths >= 8 on a reordered fine-level operator (tiles.h).
 //
-// One workgroup = one tile (<= 256 consecutive rows forming a compact brick of the mesh graph) x one chunk of 8 batch
-// columns.  Phase 1 loads the tile's window -- the ~2x256 distinct X rows its rows touch, 128 B each for this chunk --
-// into LDS, coalesced, ONCE; phase 2 is lane = row: every lane walks its own row in the tile-local storage (entries of a
-// 64-row slice interleaved so that the loads of a wavefront are contiguous; 16-bit window positions) and reads its
-// operands from LDS; phase 3 transposes the 256 x 8 results through LDS so that B / Y are touched as 128-B row segments.
-// Against spmv_lds_kernel: ~2 window rows loaded per matrix row instead of ~15 gathered (L2 -> L1 traffic / 7), no
-// cross-lane traffic for the matrix entries, one coefficient product per nonzero instead of one per nonzero and column.
-// LDS reads: lane l reads the columns in the rotated order (s + l) mod 8, s = 0..7, so that the 16 lanes a ds_read_b128
-// serves per cycle spread over all bank groups (two lanes share a group only if their window rows have equal parity).
+// One PERSISTENT workgroup of 8 wavefronts = one tile (<= 256 consecutive rows forming a compact brick of the mesh graph); it
+// walks the tile's chunks of 8 batch columns.
+//  * The matrix slice of its rows is loaded ONCE into registers and serves every chunk.  Wavefront w owns rows 32 w .. 32 w + 31;
+//    the two lanes of a row split its entries (lane 2 i + h: entries h, h + 2, ...; 8 register-resident entries per lane cover
+//    16 per row, longer rows stream the rest).
+//  * The tile's window -- the ~2 x 256 distinct X rows its rows touch, 128 B each per chunk -- is gathered into LDS by LDS-DMA
+//    (global_load_lds_dwordx4: the per-lane source address makes it a row gather, no VGPR round trip).  Two window buffers
+//    alternate: the gather of chunk c+1 is issued piece by piece between the entries of chunk c.
+//  * Compute: per entry one coefficient product and 8 x (ds_read_b128 + complex FMA), software-pipelined by hand (operands of
+//    entry u+1 requested before the FMAs of entry u).  Both lanes of a row read the columns in the rotated order (s + i) mod 8,
+//    so that the 16 lanes a ds_read_b128 serves per LDS cycle (8 lane pairs) spread over all bank groups; the two lanes of a
+//    pair share a group only if their window slots have equal parity, which the entry order avoids (tiles.cpp).
+//  * The two partial sums of a row meet through a DPP lane swap -- no LDS staging, no second barrier -- and each lane writes
+//    four of the row's eight results (the two lanes of a row complete one 128-B segment): ONE barrier per chunk, and the
+//    stores of chunk c drain under the compute of chunk c+1.
 // UNI: the 8 columns of a chunk belong to one system (columns per system a multiple of 8): one coefficient set per chunk.
+// History (C3, r = 64): one workgroup per (tile, chunk) 1805 us; persistent + matrix in registers, 4 wavefronts 1699 us;
+// 8 wavefronts with the entries split between wavefronts w and w+4 and the partial sums staged through LDS 984 us (three
+// barriers per chunk; hipcc put s_waitcnt vmcnt(0) between the builtin LDS-DMA and the next ds_read of the OTHER buffer, and
+// issued half of the ds_reads two at a time); asm LDS-DMA + pipelined entries 872 us; this version: see DESIGN.md 4b.
 // ---------------------------------------------------------------------------------------------------
-// Structure: one PERSISTENT workgroup of 8 wavefronts per tile walks the tile's column chunks.  The matrix slice of its rows
-// is loaded ONCE into registers and serves every chunk; two window buffers alternate, so the LDS-DMA gather of chunk c+1
-// (global_load_lds_dwordx4: the per-lane source address makes it a row gather, no VGPR round trip) runs under the LDS + FMA
-// work of chunk c, which issues no global load at all.  Wavefronts w and w+4 share the 64 rows of slice w and split their
-// entries by parity (partial sums meet in the staging tile): two wavefronts per SIMD, so one's LDS latency hides under the
-// other's FMAs -- with one wavefront per SIMD hipcc serialised every ds_read behind an s_waitcnt (15 k cycles per chunk).
-// (First version: one workgroup per (tile, chunk), two per CU, phases back to back -- the waves sat in s_waitcnt 80 % of the
-// time and the matrix tile crossed L2 -> L1 once per chunk: 1396 us at 1M DoF against 1175 us for spmv_lds_kernel.)
 #ifdef WAE_TILE_STAMPS
-__device__ unsigned long long wae_tile_stamps[8 * 64];     // diagnostic build only: s_memtime at the phase boundaries of one workgroup
-#define TILE_STAMP(k) do { if (blockIdx.x == 808 && tid == 0 && ch < 8) wae_tile_stamps[ch * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long wae_tile_stamps[8 * 64 + 8]; // diagnostic build only: s_memtime at the phase boundaries of one workgroup
+#ifndef TILE_STAMP_WG
+#define TILE_STAMP_WG 101
+#endif
+__device__ unsigned long long wae_tile_wglog[1024 * 4];    // per workgroup: start, end (100-MHz clock), chunks done, HW_ID | XCC_ID << 32
+#ifndef TILE_STAMP_FIRST
+#define TILE_STAMP_FIRST 21        /* chunks 21..28 of that workgroup: with 8 chunks per tile, the switch from its 3rd to its 4th tile is among them */
+#endif
+#define TILE_STAMP(k) do { if (blockIdx.x == TILE_STAMP_WG && tid == 0 && nstamp >= TILE_STAMP_FIRST && nstamp < TILE_STAMP_FIRST + 8) { \
+                               wae_tile_stamps[(nstamp - TILE_STAMP_FIRST) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+                               if ((k) == 0) wae_tile_stamps[(nstamp - TILE_STAMP_FIRST) * 8 + 7] = __builtin_amdgcn_s_memrealtime(); } } while (0)   /* [7]: the 100-MHz clock */
 #else
 #define TILE_STAMP(k) do { } while (0)
 #endif
+__device__ __forceinline__ double lane_swap1(double v) {     // the value held by lane ^ 1 (DPP quad_perm [1,0,3,2])
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
 template <bool UNI>
 __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td, const cplx *__restrict__ pc, int cps,
                                                           const cplx *__restrict__ X, cplx *Y, const cplx *B, double jac_w,
                                                           int nb, int mode, const unsigned char *__restrict__ cmask, int spc_all, int csplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
     const int tid = threadIdx.x;
+#ifdef WAE_TILE_STAMPS
+    if (blockIdx.x == TILE_STAMP_WG && tid == 0) wae_tile_stamps[64] = __builtin_amdgcn_s_memtime();      // kernel entry
+    if (tid == 0 && blockIdx.x < 1024) {
+        wae_tile_wglog[blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime();
+        wae_tile_wglog[blockIdx.x * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+    }
+#endif
     const int nch_all = (nb + 7) >> 3;
-    const int tpx = (td.ntiles + 7) >> 3;                   // workgroup ids are dealt round-robin over the 8 XCDs: XCD k takes the
-    const int jx = (int)(blockIdx.x >> 3);                  // k-th contiguous eighth of the tiles (shared halos hit its L2).
-    const int tile = (int)(blockIdx.x & 7u) * tpx + jx / csplit;    // csplit > 1 (few tiles per CU): a tile's chunks are shared out
-    const int part = jx - (jx / csplit) * csplit;           // between csplit workgroups that follow each other on the same XCD
-    if (tile >= td.ntiles) return;
-    const int ch_begin = part * nch_all / csplit;
-    const int nch = (part + 1) * nch_all / csplit;          // (end of this workgroup's chunk range)
     const int npl = op.nplanes_total;
     const int wslots = ((td.wmax > 512 ? td.wmax : 512) + 7) & ~7;
     cplx *const smem = (cplx *)tile_smem;                   // two window buffers [window slot][8 columns] (offsets, not a pointer
     cplx *spc0 = smem + (size_t)wslots * 16;                // table: the accesses must stay provably LDS), then the coefficients:
                                                             // [8][npl] of the current chunk, or (spc_all) [nb][npl] staged once
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: branches on it are uniform)
-    const int half = wv >> 2, sl = wv & 3;                   // this wavefront: entries of parity `half` of the rows of slice `sl`
-    auto next_active = [&](int c) { while (c < nch && cmask && !cmask[c]) ++c; return c; };
-    int ch = next_active(ch_begin);
-    if (ch >= nch) return;
-    // this lane's share of its row of the bulk group -> registers: entries half, half+2, ... (the first KR of them)
-    constexpr int KR = 8;
+    const int hl = lane & 1;                                 // which half of its row's entries (and of its results) this lane takes
+    const int rot = (lane >> 1) & 7;                         // (the same for the two lanes of a row: their partial sums line up)
+    // Work list.  The workgroups are PERSISTENT: the grid has one per CU, dealt round-robin over the 8 XCDs by the hardware.
+    // XCD k owns the k-th contiguous eighth of the (virtual) tiles; its workgroups take the first of them statically and then
+    // draw the next position of the share from a counter (td.counters[k]), so that they walk the share side by side --
+    // neighbouring tiles (shared halo rows) are in flight on one L2 at about the same time -- at their own pace: the time per
+    // chunk differs by up to 1.6 x between CUs and XCDs (measured, identical work).  A workgroup whose share is used up draws
+    // from the other shares.  A virtual tile = (tile, part): with fewer tiles than CUs (csplit > 1) a tile's chunks are shared
+    // out between csplit workgroups.  The last workgroup to leave zeroes the counters for the next launch (launches that use
+    // one operator are ordered by its stream).
+    const int nvt = td.ntiles * csplit;
+    const int vpx = (nvt + 7) >> 3;
+    const int xcd = (int)(blockIdx.x & 7u), gpx = (int)(gridDim.x >> 3);
+    auto next_active = [&](int c, int end) { while (c < end && cmask && !cmask[c]) ++c; return c; };
+    auto decode = [&](int vt, int &tile_, int &ch_, int &end_) {      // -> has an active chunk
+        tile_ = vt / csplit;
+        const int part = vt - tile_ * csplit;
+        end_ = (part + 1) * nch_all / csplit;
+        ch_ = next_active(part * nch_all / csplit, end_);
+        return ch_ < end_;
+    };
+    auto share_size = [&](int x) { const int left = nvt - x * vpx; return left < vpx ? (left > 0 ? left : 0) : vpx; };
+    auto draw = [&](int pend) {                              // (one thread) next virtual tile with work, or -1; pend: position already
+        int t_, c_, e_;                                      // drawn from the own share, or -1
+        if (pend >= 0 && pend < share_size(xcd) && decode(xcd * vpx + pend, t_, c_, e_)) return xcd * vpx + pend;
+        for (int a = 0; a < 8; ++a) {
+            const int x2 = (xcd + a) & 7, lim = share_size(x2);
+            while (gpx < lim) {
+                const int p = gpx + (int)atomicAdd(td.counters + x2, 1u);
+                if (p >= lim) break;
+                if (decode(x2 * vpx + p, t_, c_, e_)) return x2 * vpx + p;
+            }
+        }
+        return -1;
+    };
+    int *const vt_slot = (int *)(spc0 + (size_t)(spc_all ? nch_all * 8 : 8) * npl);   // LDS word: the next virtual tile of this workgroup
+    auto leave = [&]() {                                     // (every workgroup, once)
+        if (tid == 0 && atomicAdd(td.counters + 8, 1u) == gridDim.x - 1)
+            for (int i = 0; i < 9; ++i) atomicExch(td.counters + i, 0u);
+    };
+    int tile, ch, ch_end;
+    {
+        const int p0 = (int)(blockIdx.x >> 3);
+        bool ok = p0 < share_size(xcd) && decode(xcd * vpx + p0, tile, ch, ch_end);
+        if (!ok) {                                           // (no static tile, or none of its chunks active)
+            if (tid == 0) *vt_slot = draw(-1);
+            __syncthreads();
+            const int vt = *vt_slot;
+            __syncthreads();
+            ok = vt >= 0 && decode(vt, tile, ch, ch_end);
+        }
+        if (!ok) { leave(); return; }
+    }
+    constexpr int KR = 8;                                    // register-resident entries per lane (16 per row)
+    constexpr int NW = 10;                                   // 64 window rows per workgroup step: windows up to 640 rows in one sweep
     const GroupDev G0 = op.g[0];
-    const TileGroupDev T0 = td.g[0];
-    const bool fast0 = G0.is_real && G0.nplanes == 2;
-    const int s00 = T0.sptr[tile * 4 + sl];
-    const int n0 = (T0.sptr[tile * 4 + sl + 1] - s00) >> 6;
+    const TileGroupDev T0 = td.g0;
+    // ---- per-tile state
+    int s00, n0, w0, W, r0, nrows;
+    int side;                                                // this lane's row in the side-row list (the other groups' part), or -1
     unsigned ixr[KR];
     double2 avr[KR];
+    int gr[NW];                                              // window row list: wave instruction u moves the window rows wv*8 + 64*u .. +7
+    // (two steps: the loads are requested in one place and turned into scalars in another, a memory latency later)
+    auto request_scalars = [&](int t, int (&raw)[6]) {
+        raw[0] = T0.sptr[t * 8 + wv]; raw[1] = T0.sptr[t * 8 + wv + 1];
+        raw[2] = td.win_ptr[t]; raw[3] = td.win_ptr[t + 1];
+        raw[4] = td.row_ptr[t]; raw[5] = td.row_ptr[t + 1];
+    };
+    auto take_scalars = [&](const int (&raw)[6], int &s00_, int &n0_, int &w0_, int &W_, int &r0_, int &nrows_) {
+        s00_ = __builtin_amdgcn_readfirstlane(raw[0]); n0_ = __builtin_amdgcn_readfirstlane((raw[1] - raw[0]) >> 6);
+        w0_ = __builtin_amdgcn_readfirstlane(raw[2]); W_ = __builtin_amdgcn_readfirstlane(raw[3] - raw[2]);
+        r0_ = __builtin_amdgcn_readfirstlane(raw[4]); nrows_ = __builtin_amdgcn_readfirstlane(raw[5] - raw[4]);
+    };
+    auto load_scalars = [&](int t, int &s00_, int &n0_, int &w0_, int &W_, int &r0_, int &nrows_) {
+        int raw[6];
+        request_scalars(t, raw);
+        take_scalars(raw, s00_, n0_, w0_, W_, r0_, nrows_);
+    };
+    auto load_list = [&](int (&g_)[NW], int w0_, int W_) {
+        const int *wl = td.win_cols + w0_;
 #pragma unroll
-    for (int u = 0; u < KR; ++u) { ixr[u] = 0; avr[u] = double2{0.0, 0.0}; }
-    if (fast0) {
+        for (int u = 0; u < NW; ++u) { const int i = wv * 8 + 64 * u + (lane >> 3); g_[u] = wl[i < W_ ? i : W_ - 1]; }
+    };
+    auto load_matrix = [&]() {                               // this lane's share of its row of the bulk group -> registers
+#pragma unroll
+        for (int u = 0; u < KR; ++u) { ixr[u] = 0; avr[u] = double2{0.0, 0.0}; }
         const unsigned short *__restrict__ si = T0.sidx;
         const double2 *__restrict__ v2 = (const double2 *)T0.svals;
 #pragma unroll
-        for (int u = 0; u < KR; ++u) {
-            const int k = 2 * u + half;
-            if (k < n0) { const int e = s00 + lane + 64 * k; ixr[u] = si[e]; avr[u] = v2[e]; }   // (uniform; absent entries stay (0, 0.0))
-        }
-    }
-    // window row list: wave instruction u of wavefront wv moves the window rows wv*8 + 64*u .. +7
-    const int w0 = td.win_ptr[tile], W = td.win_ptr[tile + 1] - w0;
-    constexpr int NW = 10;                                   // 64 rows per workgroup step: windows up to 640 rows in one sweep
-    int gr[NW];
-    {
-        const int *wl = td.win_cols + w0;
-#pragma unroll
-        for (int u = 0; u < NW; ++u) { const int i = wv * 8 + 64 * u + (lane >> 3); gr[u] = wl[i < W ? i : W - 1]; }
-    }
-    auto issue_window = [&](int c, cplx *dst) {              // LDS-DMA gather of chunk c's window (rows past W duplicate the last one
-        int bc = c * 8 + (lane & 7);                         // into the slack of the 8-row granule: no per-lane predicate)
+        for (int u = 0; u < KR; ++u)
+            if (u < n0) { const int e = s00 + lane + 64 * u; ixr[u] = si[e]; avr[u] = v2[e]; }   // (uniform; absent entries stay (0, 0.0))
+        const int lr = wv * 32 + (lane >> 1);
+        side = (td.nside && lr < nrows) ? td.side_of_row[r0 + lr] : -1;
+    };
+    // The LDS-DMA is issued from an asm statement, NOT through __builtin_amdgcn_global_load_lds: hipcc counts the builtin as a
+    // pending write to LDS and puts s_waitcnt vmcnt(0) before the next ds_read of ANY address -- the wavefront that had just
+    // issued the gather of chunk c+1 sat out its whole HBM round trip before it read chunk c's window (the other buffer).
+    // Hidden from that bookkeeping, the gather completes under the compute phase; its completion is waited for explicitly
+    // (TILE_DMA_WAIT; vector-memory operations complete in order).  M0 = LDS destination of lane 0, saved and restored in the
+    // statement (compiler-reserved register).
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)tile_smem);
+    auto glds16 = [&](const cplx *src, unsigned lds_byte) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(lds_byte) : "memory");
+    };
+#define TILE_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+    // Gather of a window into buffer b, piece by piece (rows past W duplicate the last one into the slack of the 8-row granule:
+    // no per-lane predicate).  The pieces of the NEXT window are issued between the entries of the compute phase: a wavefront
+    // that issues its ten pieces back to back sits in the issue queue for ~1.2 k cycles.
+    auto window_src = [&](int c) {
+        int bc = c * 8 + (lane & 7);
         if (bc >= nb) bc = nb - 1;
-        const cplx *Xc = X + bc;
-#pragma unroll
-        for (int u = 0; u < NW; ++u) {
-            const int r = wv * 8 + 64 * u;
-            if (r < W)                                       // (uniform)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Xc + (size_t)gr[u] * nb),
-                                                 (__attribute__((address_space(3))) void *)(dst + (size_t)r * 8), 16, 0, 0);
-        }
-        for (int rb = wv * 8 + 64 * NW; rb < W; rb += 64) {  // (windows beyond NW sweeps: only with WAE_TILE_WCAP > 640)
+        return X + bc;
+    };
+    auto issue_piece = [&](const cplx *Xc, int b, const int (&g_)[NW], int W_, int u) {   // u: compile-time piece number
+        const int r = wv * 8 + 64 * u;
+        if (r < W_) glds16(Xc + (size_t)g_[u] * nb, lds_base + (unsigned)b * (unsigned)wslots * 128u + (unsigned)r * 128u);   // (uniform)
+    };
+    auto issue_rest = [&](const cplx *Xc, int b, int w0_, int W_) {   // (windows beyond NW sweeps: only with WAE_TILE_WCAP > 640)
+        for (int rb = wv * 8 + 64 * NW; rb < W_; rb += 64) {
             const int i = rb + (lane >> 3);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Xc + (size_t)td.win_cols[w0 + (i < W ? i : W - 1)] * nb),
-                                             (__attribute__((address_space(3))) void *)(dst + (size_t)rb * 8), 16, 0, 0);
+            glds16(Xc + (size_t)td.win_cols[w0_ + (i < W_ ? i : W_ - 1)] * nb, lds_base + (unsigned)b * (unsigned)wslots * 128u + (unsigned)rb * 128u);
         }
     };
-    const int r0 = td.row_ptr[tile], nrows = td.row_ptr[tile + 1] - r0;
-    const int rot = lane & 7;
-    const int lrow = sl * 64 + lane;                         // this lane's row inside the tile
+    auto issue_window = [&](int c, int b, const int (&g_)[NW], int w0_, int W_) {
+        const cplx *Xc = window_src(c);
+#pragma unroll
+        for (int u = 0; u < NW; ++u) issue_piece(Xc, b, g_, W_, u);
+        issue_rest(Xc, b, w0_, W_);
+    };
+    // ---- first tile: everything in sequence (the only exposed prologue of this workgroup)
+    load_scalars(tile, s00, n0, w0, W, r0, nrows);
+    load_list(gr, w0, W);
+    load_matrix();
     int buf = 0;
-    issue_window(ch, smem);
+    issue_window(ch, 0, gr, w0, W);
     if (spc_all)
         for (int i = tid; i < nch_all * 8 * npl; i += 512) {
             const int cc = i / npl, q = i - cc * npl;
             spc0[i] = pc[(size_t)((cc < nb ? cc : nb - 1) / cps) * npl + q];
         }
-    while (ch < nch) {
-        const int chn = next_active(ch + 1);
+    // ---- the pipeline over tiles.  The NEXT tile is known from the start of a tile (tile_n: drawn during the tile before); the one
+    // after it is drawn during this tile's first chunk (nx = 1: asked, 2: published in LDS, taken over at the switch).  The next
+    // tile's scalars are requested at the top of the first chunk and known at its end; its window list replaces this tile's at
+    // the end of the second-to-last chunk, so that the last chunk gathers the next tile's first window.
+    int nx = 0;
+    unsigned pend = 0;                                       // (thread 0) the returning atomic of the draw
+    bool pub_fresh = false;                                  // published at the end of this very chunk (no barrier since)
+    int tile_n = 0, ch_n = 0, ch_end_n = 0;
+    bool has_next = false;
+    {                                                        // the first "next": drawn here, in the shadow of the first window
+        if (tid == 0) *vt_slot = draw(-1);
+        __syncthreads();
+        const int vt = *vt_slot;
+        has_next = vt >= 0 && decode(vt, tile_n, ch_n, ch_end_n);
+    }
+    int s00_n = 0, n0_n = 0, w0_n = 0, W_n = 0, r0_n = 0, nrows_n = 0;
+    bool sc_ready = false;                                   // the scalars of tile_n are known
+    bool pre_ready = false;                                  // gr holds the window list of tile_n (from the end of this tile's
+                                                             // second-to-last chunk on: its own list is not needed any more)
+    bool pre_asked = false;                                  // its scalars have been requested (pre_raw)
+    int pre_raw[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) pre_raw[u] = 0;
+    TILE_DMA_WAIT();
+#ifdef WAE_TILE_STAMPS
+    if (blockIdx.x == TILE_STAMP_WG && tid == 0) wae_tile_stamps[65] = __builtin_amdgcn_s_memtime();      // prologue done (own share of window 0 landed)
+    int nstamp = 0;
+#endif
+    while (true) {
+        const int chn = next_active(ch + 1, ch_end);
+        const bool same = chn < ch_end;                      // the next chunk belongs to this tile
+        const bool more = same || (has_next && pre_ready);   // a next window can be gathered under this chunk
         const int col0 = ch * 8;
         TILE_STAMP(0);
         cplx *spc = spc0 + (spc_all ? (size_t)col0 * npl : 0);
-        if (!spc_all)
+        __syncthreads();                                     // everybody's share of this chunk's window has landed (each wavefront
+                                                             // waited for its own before its last stores); every wavefront is done
+        if (!spc_all) {                                      // with the other buffer (the previous window) and the previous coefficients
             for (int i = tid; i < 8 * npl; i += 512) {
                 const int cc = i / npl, q = i - cc * npl;
                 int bb = col0 + cc;
                 if (bb >= nb) bb = nb - 1;
                 spc[i] = pc[(size_t)(bb / cps) * npl + q];
             }
-        __syncthreads();                                     // window of chunk ch has landed (hipcc drains the LDS-DMA before a barrier);
-        cplx *win = smem + (size_t)buf * wslots * 8;         // the other buffer's last reader (previous epilogue) is done
+            __syncthreads();
+        }
+        cplx *win = smem + (size_t)buf * wslots * 8;
         TILE_STAMP(1);
-        // The gather of the next window costs ~200 issue cycles per wave instruction: the two wavefronts of a SIMD (w, w+4)
-        // issue theirs at different times -- one before its entries, the other half-way through -- so that one of them computes
-        if (chn < nch && half == 0) issue_window(chn, smem + (size_t)(buf ^ 1) * wslots * 8);
+        pub_fresh = false;
+        if (nx == 0) {                                       // (first chunk of a tile) draw the tile after the next one, and request
+            if (has_next) {                                  // the next one's scalars: both answers land under this chunk
+                if (tid == 0 && gpx < share_size(xcd)) pend = atomicAdd(td.counters + xcd, 1u);
+                request_scalars(tile_n, pre_raw);
+                pre_asked = true;
+            }
+            nx = 1;
+        }
+        const cplx *Xn = window_src(same ? chn : ch_n);
+        const int Wd = same ? W : W_n;                       // rows of the window gathered under this chunk
         TILE_STAMP(2);
         cplx acc[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) acc[s] = cplx{0.0, 0.0};
-        if (fast0 && n0 > 0) {                               // the bulk group: mass + stiffness on one pattern, 16 B + 2 B per nonzero
+        if (n0 > 0) {                                        // the bulk group: mass + stiffness on one pattern, 16 B + 2 B per nonzero
             const cplx c0 = spc[G0.plane0], c1 = spc[G0.plane0 + 1];
-            auto entry = [&](unsigned ix, double2 a) {
+            auto fetch = [&](cplx (&x)[8], unsigned ix) {    // the 8 operands of one entry: 8 ds_read_b128, rotated column order
                 const cplx *wr = win + ix * 8;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) x[s] = wr[(s + rot) & 7];
+            };
+            auto apply = [&](const cplx (&x)[8], double2 a) {
                 cplx m = {fma(c0.x, a.x, c1.x * a.y), fma(c0.y, a.x, c1.y * a.y)};
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    const int cs = (s + rot) & 7;
                     if (!UNI) {
+                        const int cs = (s + rot) & 7;
                         const cplx d0 = spc[cs * npl + G0.plane0], d1 = spc[cs * npl + G0.plane0 + 1];
                         m = cplx{fma(d0.x, a.x, d1.x * a.y), fma(d0.y, a.x, d1.y * a.y)};
                     }
-#if defined(TILE_ABL_NOLDS)
-                    cfma(acc[s], m, cplx{1.0 + cs, 2.0});
-#elif defined(TILE_ABL_NOFMA)
-                    { const cplx xx = wr[cs]; acc[s].x += xx.x; acc[s].y += xx.y; }
-#else
-                    cfma(acc[s], m, wr[cs]);
-#endif
+                    cfma(acc[s], m, x[s]);
                 }
             };
-            // register-resident part: straight-line code, absent entries are (slot 0, 0.0); the scheduling fences keep two
-            // entries' operands in flight (hipcc would otherwise hoist all 64 LDS reads and spill)
-#ifndef TILE_FENCE
-#define TILE_FENCE 4
-#endif
+            // register-resident part, software-pipelined by hand: the operands of entry u+1 are requested before the FMAs of
+            // entry u, two operand sets alternate; absent entries are (slot 0, 0.0).  The scheduling fences pin that order --
+            // left alone hipcc hoists 32 reads, runs out of registers and then issues the rest two at a time behind
+            // s_waitcnt lgkmcnt(0).
+            cplx xa[8], xb[8];
+            fetch(xa, ixr[0]);
 #pragma unroll
             for (int u = 0; u < KR; ++u) {
-                entry(ixr[u], avr[u]);
-                if ((u + 1) % TILE_FENCE == 0) __builtin_amdgcn_sched_barrier(0);
-                if (u == KR / 2 - 1 && chn < nch && half == 1) issue_window(chn, smem + (size_t)(buf ^ 1) * wslots * 8);
+                if (u + 1 < KR) { if (u & 1) fetch(xa, ixr[u + 1]); else fetch(xb, ixr[u + 1]); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (u & 1) apply(xb, avr[u]); else apply(xa, avr[u]);
+                // (the FMAs are pure arithmetic: only an operand dependence keeps them from sinking below the later reads)
+                asm volatile("" : "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[1].x), "+v"(acc[1].y), "+v"(acc[2].x), "+v"(acc[2].y),
+                                  "+v"(acc[3].x), "+v"(acc[3].y), "+v"(acc[4].x), "+v"(acc[4].y), "+v"(acc[5].x), "+v"(acc[5].y),
+                                  "+v"(acc[6].x), "+v"(acc[6].y), "+v"(acc[7].x), "+v"(acc[7].y) : : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && 2 * u < NW) {                    // the next window, two pieces per entry: all under way by the middle
+                    issue_piece(Xn, buf ^ 1, gr, Wd, 2 * u); // of the phase, landed (mostly) by its end
+                    if (2 * u + 1 < NW) issue_piece(Xn, buf ^ 1, gr, Wd, 2 * u + 1);
+                }
             }
+            if (more) issue_rest(Xn, buf ^ 1, same ? w0 : w0_n, Wd);
             const unsigned short *__restrict__ si = T0.sidx;
             const double2 *__restrict__ v2 = (const double2 *)T0.svals;
 #pragma unroll 1
-            for (int k = 2 * KR + half; k < n0; k += 2) {    // rows longer than 2 KR entries: streamed
+            for (int k = KR; k < n0; ++k) {                  // rows longer than 2 KR entries: streamed
                 const int e = s00 + lane + 64 * k;
-                entry(si[e], v2[e]);
+                cplx x[8];
+                fetch(x, si[e]);
+                apply(x, v2[e]);
             }
-        }
-        if (!(fast0 && n0 > 0) && chn < nch && half == 1) issue_window(chn, smem + (size_t)(buf ^ 1) * wslots * 8);
-#pragma unroll 1
-        for (int g = fast0 ? 1 : 0; g < op.ngroups; ++g) {   // the other groups (boundary, flame, ... : few entries, most tiles have none)
-            const TileGroupDev TG = td.g[g];
-            const int s0 = TG.sptr[tile * 4 + sl], s1 = TG.sptr[tile * 4 + sl + 1];
-            if (s0 == s1) continue;                          // (uniform per wavefront)
-            const GroupDev G = op.g[g];
-            const int np = G.nplanes;
-            const double *__restrict__ vr = (const double *)TG.svals;
-            const cplx *__restrict__ vc = (const cplx *)TG.svals;
-            const double sg = G.conj_vals ? -1.0 : 1.0;
-#pragma unroll 1
-            for (int e = s0 + lane + 64 * half; e < s1; e += 128) {
-                const cplx *wr = win + (unsigned)TG.sidx[e] * 8;
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    const int cs = (s + rot) & 7;
-                    const cplx *gpc = spc + (UNI ? 0 : cs * npl) + G.plane0;
-                    cplx m = {0.0, 0.0};
-                    if (G.is_real) {
-                        for (int q = 0; q < np; ++q) { const double av = vr[(size_t)e * np + q]; m.x = fma(gpc[q].x, av, m.x); m.y = fma(gpc[q].y, av, m.y); }
-                    } else {
-                        for (int q = 0; q < np; ++q) { cplx av = vc[(size_t)e * np + q]; av.y *= sg; cfma(m, gpc[q], av); }
-                    }
-                    cfma(acc[s], m, wr[cs]);
-                }
-            }
+        } else if (more) {
+            issue_window(same ? chn : ch_n, buf ^ 1, gr, same ? w0 : w0_n, Wd);
         }
         TILE_STAMP(3);
-        __syncthreads();                                     // every wavefront is done with this window: reuse it as two staging tiles
-        TILE_STAMP(4);
-        {
-            cplx *stage = win + (size_t)half * 2048;         // [256 rows][8 columns] per half
+        // the two halves of a row meet; afterwards lane 2 i + h keeps the results of positions 4 h .. 4 h + 3, i.e. of the
+        // columns (4 h + j + rot) mod 8
+        cplx res[4];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) stage[lrow * 8 + ((s + rot) & 7)] = acc[s];
+        for (int j = 0; j < 4; ++j) {
+            const cplx lo = {acc[j].x + lane_swap1(acc[j].x), acc[j].y + lane_swap1(acc[j].y)};
+            const cplx hi = {acc[j + 4].x + lane_swap1(acc[j + 4].x), acc[j + 4].y + lane_swap1(acc[j + 4].y)};
+            res[j] = hl ? hi : lo;
         }
-        __syncthreads();
-        TILE_STAMP(5);
-        // epilogue: thread = (row, column) -> 8 lanes write one 128-B row segment; the two halves' partial sums meet here
-        const int c = tid & 7;
-        const int b = col0 + c;
-        if (b < nb) {
-            const cplx *mypc = spc + c * npl;
-            const int rl = tid >> 3;
+        TILE_STAMP(4);
+        // Epilogue.  Loads first, then the wait for this wavefront's pieces of the NEXT window (vector-memory operations complete
+        // in order, so the wait sits before the stores: those drain under the next chunk), then the stores.
+        const int lrow = wv * 32 + (lane >> 1);              // this lane's row inside the tile
+        const bool live = lrow < nrows;
+        const int64_t row = r0 + (live ? lrow : 0);
+        const bool need_b = mode == MODE_RES || mode == MODE_ADD || mode == MODE_RES_DS || mode == MODE_JAC;
+        const bool need_d = !(mode == MODE_AX || mode == MODE_RES || mode == MODE_ADD);
+        cplx bv[4], xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                       // right-hand sides of the fused modes: requested together
+            const int c = (4 * hl + j + rot) & 7;
+            const int b = col0 + c < nb ? col0 + c : nb - 1;
+            const size_t e = (size_t)row * nb + b;
+            bv[j] = need_b ? B[e] : cplx{0.0, 0.0};
+            xv[j] = mode == MODE_JAC ? X[e] : cplx{0.0, 0.0};
+        }
+        if (side >= 0) {                                     // the other groups' part of this row (spmv_side_kernel)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = (4 * hl + j + rot) & 7;
+                const int b = col0 + c < nb ? col0 + c : nb - 1;
+                const cplx sv = td.side_acc[(size_t)side * nb + b];
+                res[j].x += sv.x; res[j].y += sv.y;
+            }
+        }
+        cplx dgu = {1.0, 0.0};
+        const double dsg = op.conj_diag ? -1.0 : 1.0;
+        if (UNI && need_d) {                                 // one diagonal per row and chunk
+            dgu = cplx{0.0, 0.0};
+            for (int q = 0; q < npl; ++q) { cplx dq = op.diag[(size_t)row * npl + q]; dq.y *= dsg; cfma(dgu, spc[q], dq); }
+        }
+        cplx out[4], b2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = (4 * hl + j + rot) & 7;
+            const cplx av = res[j];
+            b2[j] = cplx{0.0, 0.0};
             if (mode == MODE_AX) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int rr = rl + 64 * u;
-                    if (rr < nrows) {
-                        const cplx a0 = win[rr * 8 + c], a1 = win[2048 + rr * 8 + c];
-                        Y[(size_t)(r0 + rr) * nb + b] = cplx{a0.x + a1.x, a0.y + a1.y};
-                    }
-                }
+                out[j] = av;
+            } else if (mode == MODE_RES) {
+                out[j] = cplx{bv[j].x - av.x, bv[j].y - av.y};
+            } else if (mode == MODE_ADD) {
+                out[j] = cplx{bv[j].x + av.x, bv[j].y + av.y};
             } else {
-                cplx bv[4], xv[4];
-                const bool need_b = mode == MODE_RES || mode == MODE_ADD || mode == MODE_RES_DS || mode == MODE_JAC;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int rr = rl + 64 * u;
-                    const size_t e = (size_t)(r0 + (rr < nrows ? rr : 0)) * nb + b;
-                    bv[u] = need_b ? B[e] : cplx{0.0, 0.0};
-                    xv[u] = mode == MODE_JAC ? X[e] : cplx{0.0, 0.0};
+                cplx dg = dgu;
+                if (!UNI) {
+                    const cplx *mypc = spc + c * npl;
+                    dg = cplx{0.0, 0.0};
+                    for (int q = 0; q < npl; ++q) { cplx dq = op.diag[(size_t)row * npl + q]; dq.y *= dsg; cfma(dg, mypc[q], dq); }
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int rr = rl + 64 * u;
-                    if (rr >= nrows) continue;
-                    const cplx a0 = win[rr * 8 + c], a1 = win[2048 + rr * 8 + c];
-                    const cplx av = {a0.x + a1.x, a0.y + a1.y};
-                    const int64_t row = r0 + rr;
-                    const size_t e = (size_t)row * nb + b;
-                    cplx out;
-                    if (mode == MODE_RES) {
-                        out = cplx{bv[u].x - av.x, bv[u].y - av.y};
-                    } else if (mode == MODE_ADD) {
-                        out = cplx{bv[u].x + av.x, bv[u].y + av.y};
-                    } else {
-                        cplx dg = {0.0, 0.0};
-                        const double dsg = op.conj_diag ? -1.0 : 1.0;
-                        for (int q = 0; q < npl; ++q) { cplx dq = op.diag[(size_t)row * npl + q]; dq.y *= dsg; cfma(dg, mypc[q], dq); }
-                        if (mode == MODE_AX_J0) {
-                            out = av;
-                            const cplx r = cdiv(av, dg);
-                            const_cast<cplx *>(B)[e] = cplx{jac_w * r.x, jac_w * r.y};
-                        } else if (mode == MODE_AX_DS) {
-                            out = cdiv(av, dg);
-                        } else if (mode == MODE_RES_DS) {
-                            out = cdiv(cplx{bv[u].x - av.x, bv[u].y - av.y}, dg);
-                        } else {
-                            const cplx r = cdiv(cplx{bv[u].x - av.x, bv[u].y - av.y}, dg);
-                            out = cplx{xv[u].x + jac_w * r.x, xv[u].y + jac_w * r.y};
-                        }
-                    }
-                    Y[e] = out;
+                if (mode == MODE_AX_J0) {
+                    out[j] = av;
+                    const cplx r = cdiv(av, dg);
+                    b2[j] = cplx{jac_w * r.x, jac_w * r.y};
+                } else if (mode == MODE_AX_DS) {
+                    out[j] = cdiv(av, dg);
+                } else if (mode == MODE_RES_DS) {
+                    out[j] = cdiv(cplx{bv[j].x - av.x, bv[j].y - av.y}, dg);
+                } else {
+                    const cplx r = cdiv(cplx{bv[j].x - av.x, bv[j].y - av.y}, dg);
+                    out[j] = cplx{xv[j].x + jac_w * r.x, xv[j].y + jac_w * r.y};
                 }
+            }
+        }
+        TILE_STAMP(5);
+        TILE_DMA_WAIT();
+        if (nx == 1) {                                       // the draw has come back: publish it (read at the tile switch)
+            if (tid == 0 && has_next) *vt_slot = draw(gpx < share_size(xcd) ? gpx + (int)pend : -1);
+            nx = 2;
+            pub_fresh = true;
+        }
+        if (pre_asked) {
+            take_scalars(pre_raw, s00_n, n0_n, w0_n, W_n, r0_n, nrows_n);
+            pre_asked = false;
+            sc_ready = true;
+        }
+        if (sc_ready && !pre_ready && same && next_active(chn + 1, ch_end) >= ch_end) {   // end of the second-to-last chunk: this
+            load_list(gr, w0_n, W_n);                        // tile's own list has served (the last window is on its way); the
+            pre_ready = true;                                // next tile's list is requested (no wait: used in the last chunk)
+        }
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int b = col0 + ((4 * hl + j + rot) & 7);
+                if (b >= nb) continue;
+#ifdef TILE_ABL_BLOCKED
+                const size_t e = ((size_t)ch * op.n + row) * 8 + (b & 7);
+#else
+                const size_t e = (size_t)row * nb + b;
+#endif
+                Y[e] = out[j];
+                if (mode == MODE_AX_J0) const_cast<cplx *>(B)[e] = b2[j];
             }
         }
         TILE_STAMP(6);
+#ifdef WAE_TILE_STAMPS
+        ++nstamp;
+#endif
         buf ^= 1;
-        ch = chn;
+        if (same) {
+            ch = chn;
+        } else {                                             // ---- tile switch
+            if (!has_next) break;
+            if (!pre_ready) {                                // (single-chunk tiles: the list could not be prefetched)
+                if (!sc_ready) load_scalars(tile_n, s00_n, n0_n, w0_n, W_n, r0_n, nrows_n);
+                load_list(gr, w0_n, W_n);
+            }
+            const bool had_window = more;                    // the first window of the next tile was gathered under this chunk
+            tile = tile_n; ch = ch_n; ch_end = ch_end_n;
+            s00 = s00_n; n0 = n0_n; w0 = w0_n; W = W_n; r0 = r0_n; nrows = nrows_n;
+            load_matrix();                                   // (lands under the barrier and the first reads of the next chunk)
+            pre_ready = false;
+            sc_ready = false;
+            if (pub_fresh) __syncthreads();                  // (single-chunk tiles: published a moment ago)
+            {
+                const int vt = *vt_slot;
+                has_next = vt >= 0 && decode(vt, tile_n, ch_n, ch_end_n);
+            }
+            nx = 0;
+            if (!had_window) {                               // gather it now, exposed
+                __syncthreads();                             // (the other buffer's last readers are done)
+                issue_window(ch, buf, gr, w0, W);
+                TILE_DMA_WAIT();
+            }
+        }
     }
+    leave();
+#ifdef WAE_TILE_STAMPS
+    if (blockIdx.x == TILE_STAMP_WG && tid == 0) { TILE_DMA_WAIT(); wae_tile_stamps[66] = __builtin_amdgcn_s_memtime(); }   // last stores done
+    if (tid == 0 && blockIdx.x < 1024) { wae_tile_wglog[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime(); wae_tile_wglog[blockIdx.x * 4 + 2] = nstamp; }
+#endif
 }
 
 #ifdef WAE_TILE_STAMPS
+extern "C" int wae_debug_tile_wglog(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wae_tile_wglog), sizeof(unsigned long long) * 1024 * 4);
+}
 extern "C" int wae_debug_tile_stamps(unsigned long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wae_tile_stamps), sizeof(unsigned long long) * 8 * 64);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wae_tile_stamps), sizeof(unsigned long long) * (8 * 64 + 8));
 }
 #endif
 static void launch_spmv_tile(const OpDev &op, const TileDev &td, const cplx *pc, int cps, const cplx *X, cplx *Y, const cplx *B, double jac_w,
@@ -671,24 +897,39 @@ static void launch_spmv_tile(const OpDev &op, const TileDev &td, const cplx *pc,
     static bool attr_set = false;
     const size_t wslots = (size_t)(((td.wmax > 512 ? td.wmax : 512) + 7) & ~7);
     const int nch8 = ((nb + 7) / 8) * 8;
-    size_t shm = 2 * wslots * 8 * sizeof(cplx) + (size_t)nch8 * op.nplanes_total * sizeof(cplx);   // coefficients of all chunks staged once ...
-    const int spc_all = shm <= 160 * 1024;
-    if (!spc_all) shm = 2 * wslots * 8 * sizeof(cplx) + (size_t)8 * op.nplanes_total * sizeof(cplx);   // ... or chunk by chunk
+    size_t shm = 2 * wslots * 8 * sizeof(cplx) + (size_t)nch8 * op.nplanes_total * sizeof(cplx) + 16;   // coefficients of all chunks staged once ...
+    const int spc_all = shm <= 160 * 1024;                   // (+ 16: the word through which a workgroup learns its next tile)
+    if (!spc_all) shm = 2 * wslots * 8 * sizeof(cplx) + (size_t)8 * op.nplanes_total * sizeof(cplx) + 16;   // ... or chunk by chunk
     if (shm > 160 * 1024) throw WaeError(WAE_ERR_INVALID, "tile windows do not fit LDS (WAE_TILE_WCAP too large)");
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    const unsigned tpx = (unsigned)((td.ntiles + 7) / 8);
-    // one workgroup per tile unless there are fewer tiles than CUs: then the chunks of a tile are shared out.  (Sharing them
-    // out as soon as a CU had fewer than 8 tiles was measured and is slower -- 200k DoF, 780 tiles: 229 -> 259 us; 500k DoF:
-    // 519 -> 547 us: the matrix slice is re-loaded and the window pipeline restarts per workgroup.)
+    // Persistent workgroups, one per CU (157 KB of LDS each: the hardware cannot place two on a CU), walking the tiles of
+    // their XCD.  With fewer tiles than CUs the chunks of a tile are shared out between csplit workgroups.  (Sharing them out
+    // as soon as a CU had fewer than 8 tiles was measured and is slower -- 200k DoF, 780 tiles: 229 -> 259 us: the matrix
+    // slice is re-loaded and the window pipeline restarts per part.)
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        HIP_CHECK(hipGetDevice(&dev));
+        HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        if (getenv("WAE_TILE_GRID")) ncu = atoi(getenv("WAE_TILE_GRID"));
+        ncu = ncu < 8 ? 8 : ncu & ~7;
+    }
     const int nchunks = (nb + 7) / 8;
-    int csplit = (int)((256 + td.ntiles - 1) / td.ntiles);
+    int csplit = (int)((ncu + td.ntiles - 1) / td.ntiles);
     if (csplit > nchunks) csplit = nchunks;
     if (csplit < 1) csplit = 1;
-    const dim3 grid(8u * tpx * (unsigned)csplit);
+    const unsigned vpx = (unsigned)((td.ntiles * csplit + 7) / 8);
+    const dim3 grid(8u * std::min(vpx, (unsigned)(ncu / 8)));
+    if (td.nside) {
+        if (nb > 256) throw WaeError(WAE_ERR_INVALID, "launch_spmv: batch wider than 256 columns");
+        hipLaunchKernelGGL(spmv_side_kernel, dim3((unsigned)((td.nside + 31) / 32), (unsigned)nchunks), dim3(256), 0, st, td, op.nplanes_total,
+                           op.conj_diag, pc, cps, X, nb, cmask);
+        HIP_CHECK(hipGetLastError());
+    }
     if (cps % 8 == 0) hipLaunchKernelGGL(spmv_tile_kernel<true>, grid, dim3(512), shm, st, op, td, pc, cps, X, Y, B, jac_w, nb, mode, cmask, spc_all, csplit);
     else hipLaunchKernelGGL(spmv_tile_kernel<false>, grid, dim3(512), shm, st, op, td, pc, cps, X, Y, B, jac_w, nb, mode, cmask, spc_all, csplit);
     HIP_CHECK(hipGetLastError());

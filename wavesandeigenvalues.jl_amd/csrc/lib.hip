@@ -289,6 +289,7 @@ static void build_level_tiles(LevelOp &L, const std::vector<CsrZ> &planes, const
     TileStore &T = L.tiles;
     T = TileStore();
     if (row_ptr.size() < 2) return;
+    if (L.groups.empty() || !L.groups[0].is_real || L.groups[0].nplanes != 2) return;   // the tile kernel's bulk group: two real planes
     const Pattern U = union_pattern(planes);
     const TileWindows W = build_windows(U, row_ptr);
     const int nt = (int)row_ptr.size() - 1;
@@ -299,29 +300,83 @@ static void build_level_tiles(LevelOp &L, const std::vector<CsrZ> &planes, const
     T.win_ptr.upload(W.win_ptr.data(), W.win_ptr.size(), st);
     T.win_cols.upload(W.win_cols.data(), W.win_cols.size(), st);
     const size_t ng = L.groups.size();
-    T.sptr.resize(ng); T.sidx.resize(ng); T.svals.resize(ng);
     memset(&T.dev, 0, sizeof(T.dev));
     T.all_symmetric = true;
-    for (size_t g = 0; g < ng; ++g) {
-        const GroupHost &G = L.groups[g];
+    for (size_t g = 0; g < ng; ++g) T.all_symmetric = T.all_symmetric && L.groups[g].symmetric;
+    {
+        const GroupHost &G = L.groups[0];
         std::vector<const CsrZ *> mats;
         for (int q = 0; q < G.nplanes; ++q) mats.push_back(&planes[slot_plane[G.plane0 + q]]);
         const TileGroupHost H = build_tile_group(mats, G.is_real, row_ptr, W);
-        T.sptr[g].upload(H.sptr.data(), H.sptr.size(), st);
-        T.sidx[g].upload(H.sidx.data(), H.sidx.size(), st);
-        T.svals[g].upload(H.svals.data(), H.svals.size(), st);
-        HIP_CHECK(hipStreamSynchronize(st));                 // H dies at the end of this iteration
-        T.dev.g[g].sptr = T.sptr[g].p;
-        T.dev.g[g].sidx = T.sidx[g].p;
-        T.dev.g[g].svals = T.svals[g].p;
-        T.all_symmetric = T.all_symmetric && G.symmetric;
+        T.sptr.upload(H.sptr.data(), H.sptr.size(), st);
+        T.sidx.upload(H.sidx.data(), H.sidx.size(), st);
+        T.svals.upload(H.svals.data(), H.svals.size(), st);
+        HIP_CHECK(hipStreamSynchronize(st));                 // H dies at the end of this scope
+        T.dev.g0.sptr = T.sptr.p;
+        T.dev.g0.sidx = T.sidx.p;
+        T.dev.g0.svals = T.svals.p;
+        if (getenv("WAE_SETUP_DEBUG")) {
+            int over = 0;                                    // slices longer than the 8 register-resident entries per lane
+            for (size_t i = 0; i + 1 < H.sptr.size(); ++i) over += (H.sptr[i + 1] - H.sptr[i]) / 64 > 8;
+            fprintf(stderr, "[tiles] bulk group: %lld nonzeros in %lld slots (%.3f filled), %d of %zu slices stream entries\n",
+                    (long long)mats[0]->ptr.back(), (long long)H.sptr.back(), (double)mats[0]->ptr.back() / (double)std::max(1, H.sptr.back()),
+                    over, H.sptr.size() - 1);
+        }
     }
+    {   // side rows: every entry of the other groups, row by row (level numbering), plane slot and complex value per entry
+        const int64_t n = L.n;
+        std::vector<int> count((size_t)n, 0);
+        for (size_t g = 1; g < ng; ++g)
+            for (int q = 0; q < L.groups[g].nplanes; ++q) {
+                const CsrZ &A = planes[slot_plane[L.groups[g].plane0 + q]];
+                for (int64_t i = 0; i < n; ++i) count[(size_t)i] += A.ptr[i + 1] - A.ptr[i];
+            }
+        std::vector<int> of_row((size_t)n, -1), ptr(1, 0);
+        for (int64_t i = 0; i < n; ++i)
+            if (count[(size_t)i]) { of_row[(size_t)i] = (int)ptr.size() - 1; ptr.push_back(ptr.back() + count[(size_t)i]); }
+        const int nside = (int)ptr.size() - 1;
+        std::vector<int> col((size_t)ptr.back()), slot((size_t)ptr.back()), fill(ptr.begin(), ptr.end() - 1);
+        std::vector<cplx> val((size_t)ptr.back());
+        for (size_t g = 1; g < ng; ++g)
+            for (int q = 0; q < L.groups[g].nplanes; ++q) {
+                const CsrZ &A = planes[slot_plane[L.groups[g].plane0 + q]];
+                for (int64_t i = 0; i < n; ++i)
+                    for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) {
+                        const int e = fill[(size_t)of_row[(size_t)i]]++;
+                        col[(size_t)e] = A.col[p]; slot[(size_t)e] = L.groups[g].plane0 + q; val[(size_t)e] = cplx{A.val[p].real(), A.val[p].imag()};
+                    }
+            }
+        T.side_of_row.upload(of_row.data(), of_row.size(), st);
+        T.side_ptr.upload(ptr.data(), ptr.size(), st);
+        if (nside) {
+            T.side_col.upload(col.data(), col.size(), st);
+            T.side_slot.upload(slot.data(), slot.size(), st);
+            T.side_val.upload(val.data(), val.size(), st);
+            T.side_acc.alloc((size_t)nside * 256);           // batch widths up to 256 columns
+        }
+        HIP_CHECK(hipStreamSynchronize(st));
+        T.dev.nside = nside;
+        T.dev.side_of_row = T.side_of_row.p;
+        T.dev.side_ptr = T.side_ptr.p; T.dev.side_col = T.side_col.p; T.dev.side_slot = T.side_slot.p;
+        T.dev.side_val = T.side_val.p; T.dev.side_acc = T.side_acc.p;
+        if (getenv("WAE_SETUP_DEBUG"))
+            fprintf(stderr, "[tiles] %d side rows with %d entries of the other %zu groups\n", nside, ptr.back(), ng - 1);
+    }
+    const std::vector<unsigned> zero(16, 0u);
+    T.counters.upload(zero.data(), zero.size(), st);
     HIP_CHECK(hipStreamSynchronize(st));
+    if (getenv("WAE_SETUP_DEBUG")) {
+        int full = 0;
+        for (int t = 0; t < nt; ++t) full += row_ptr[t + 1] - row_ptr[t] == 256;
+        fprintf(stderr, "[tiles] %d tiles, %.1f rows and %.1f window rows per tile on average, %d tiles with 256 rows, largest window %d\n", nt,
+                (double)row_ptr[nt] / nt, (double)W.win_ptr[nt] / nt, full, wmax);
+    }
     T.dev.ntiles = nt;
     T.dev.wmax = wmax;
     T.dev.row_ptr = T.row_ptr.p;
     T.dev.win_ptr = T.win_ptr.p;
     T.dev.win_cols = T.win_cols.p;
+    T.dev.counters = T.counters.p;
     T.ready = true;
 }
 

@@ -25,10 +25,12 @@ TilePlan plan_tiles(const Pattern &U, int tile_rows, int wcap, int thick);
 // B = P A P^T with P the permutation new -> old (columns re-sorted)
 CsrZ permute_symmetric(const CsrZ &A, const std::vector<int> &perm, const std::vector<int> &iperm);
 
-// Tile-local storage of one pattern group: per (tile, wavefront) a slice of 64 rows padded to the longest row of the slice,
-// stored entry-major ([k][lane]) so that lane = row reads coalesced; column indices are 16-bit positions in the tile's window.
+// Tile-local storage of one pattern group: per (tile, wavefront) a slice of 32 rows, two lanes per row (lane 2 i + h holds
+// the entries h, h + 2, ... of row i), padded to half the longest row of the slice and stored entry-major ([k][lane]) so that
+// the lanes read coalesced; column indices are 16-bit positions in the tile's window.
+constexpr int TILE_SLICES = 8;                 // wavefronts per tile (= 256 rows / 32)
 struct TileGroupHost {
-    std::vector<int> sptr;                 // 4*ntiles + 1 entry offsets (multiples of 64)
+    std::vector<int> sptr;                 // TILE_SLICES*ntiles + 1 entry offsets (multiples of 64)
     std::vector<unsigned short> sidx;      // local column index per entry
     std::vector<double> svals;             // [entry][nplanes] doubles (real group) or [entry][nplanes][2]
 };

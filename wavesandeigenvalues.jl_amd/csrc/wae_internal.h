@@ -72,7 +72,7 @@ struct GroupDev {                   // one sparsity pattern shared by `nplanes` 
 // tile-local storage of an operator (tiles.h): rows renumbered so that <= 256 consecutive rows form a compact brick of the
 // mesh graph whose distinct columns (the "window") fit LDS
 struct TileGroupDev {
-    const int *sptr;                // 4*ntiles+1: entry offset of the slice of (tile, wavefront)
+    const int *sptr;                // 8*ntiles+1: entry offset of the slice of (tile, wavefront)
     const unsigned short *sidx;     // window-local column of every entry ([k][lane] inside a slice)
     const void *svals;              // [entry][nplanes] double or double2, same value layout as GroupDev::vals
 };
@@ -82,7 +82,15 @@ struct TileDev {
     const int *row_ptr;             // ntiles+1
     const int *win_ptr;             // ntiles+1
     const int *win_cols;            // global (new) column of every window slot, ascending per tile
-    TileGroupDev g[WAE_MAXG];
+    unsigned *counters;             // 16 words, zero between launches: [k] next position of share k, [8] workgroups that have left
+    TileGroupDev g0;                // the bulk group (two real planes on one pattern)
+    // Every other group (boundary, flame, ... : a few entries in a few per cent of the rows) stays out of the tile kernel: a
+    // pre-kernel sums their rows ("side rows") into side_acc, the tile kernel adds that in.
+    int nside;
+    const int *side_of_row;         // [n]: position in the side-row list, or -1
+    const int *side_ptr, *side_col, *side_slot;      // CSR over the side rows; slot = plane index in the coefficient table
+    const cplx *side_val;
+    cplx *side_acc;                 // [nside][nb]
 };
 struct OpDev {
     int ngroups;
@@ -148,9 +156,12 @@ struct GroupHost {                  // a pattern group held on device, N and T o
 
 struct TileStore {                  // device arrays behind a TileDev
     DevBuf<int> row_ptr, win_ptr, win_cols;
-    std::vector<DevBuf<int>> sptr;
-    std::vector<DevBuf<unsigned short>> sidx;
-    std::vector<DevBuf<double>> svals;
+    DevBuf<unsigned> counters;
+    DevBuf<int> sptr;
+    DevBuf<unsigned short> sidx;
+    DevBuf<double> svals;
+    DevBuf<int> side_of_row, side_ptr, side_col, side_slot;
+    DevBuf<cplx> side_val, side_acc;
     TileDev dev;
     bool ready = false;
     bool all_symmetric = false;     // every group symmetric: the N-orientation tiles serve op = T/C as well
