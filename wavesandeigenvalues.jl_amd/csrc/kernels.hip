@@ -456,12 +456,14 @@ __device__ unsigned long long wae_tile_wglog[1024 * 4];    // per workgroup: sta
 #else
 #define TILE_STAMP(k) do { } while (0)
 #endif
-__device__ __forceinline__ double lane_swap1(double v) {     // the value held by lane ^ 1 (DPP quad_perm [1,0,3,2])
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xF, 0xF, true);
+template <int CTRL> __device__ __forceinline__ double lane_quad(double v) {     // DPP quad_perm CTRL: a value from another lane of the quad
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
-template <bool UNI>
+// LPR = lanes per row: 2 (rows of up to 16 register-resident entries, 256-row tiles: the fine level) or 4 (up to 48, 128-row
+// tiles: the first coarse level, whose windows allow ~64 rows per tile anyway).
+template <bool UNI, int LPR>
 __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td, const cplx *__restrict__ pc, int cps,
                                                           const cplx *__restrict__ X, cplx *Y, const cplx *B, double jac_w,
                                                           int nb, int mode, const unsigned char *__restrict__ cmask, int spc_all, int csplit) {
@@ -481,8 +483,16 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
     cplx *spc0 = smem + (size_t)wslots * 16;                // table: the accesses must stay provably LDS), then the coefficients:
                                                             // [8][npl] of the current chunk, or (spc_all) [nb][npl] staged once
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: branches on it are uniform)
-    const int hl = lane & 1;                                 // which half of its row's entries (and of its results) this lane takes
-    const int rot = (lane >> 1) & 7;                         // (the same for the two lanes of a row: their partial sums line up)
+    constexpr int RPW = 64 / LPR;                            // rows per wavefront
+    constexpr int NOUT = 8 / LPR;                            // results per lane and chunk
+    const int sub = lane & (LPR - 1);                        // which share of its row's entries (and of its results) this lane takes
+    // Column order of the LDS reads.  LPR = 2: rotated by the row number, the same for the two lanes of a row (their partial
+    // sums line up position by position; they share a bank group only if their window slots have equal parity, which the
+    // entry order avoids).  LPR = 4: lane q of a row starts 2 q further on, rows alternate between the even and the odd
+    // columns: position s of lane q is column s + rot, and the four partial sums of a column sit at positions that differ by 2
+    // from lane to lane -- a reduce-scatter through three quad rotations leaves each lane with the two columns it stores.
+    const int rot = LPR == 2 ? (lane >> 1) & 7 : (((lane >> 2) & 1) + 2 * sub) & 7;
+    const int rot_out = LPR == 2 ? (rot + 4 * sub) & 7 : rot;    // column of this lane's first result
     // Work list.  The workgroups are PERSISTENT: the grid has one per CU, dealt round-robin over the 8 XCDs by the hardware.
     // XCD k owns the k-th contiguous eighth of the (virtual) tiles; its workgroups take the first of them statically and then
     // draw the next position of the share from a counter (td.counters[k]), so that they walk the share side by side --
@@ -534,7 +544,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
         }
         if (!ok) { leave(); return; }
     }
-    constexpr int KR = 8;                                    // register-resident entries per lane (16 per row)
+    constexpr int KR = LPR == 2 ? 8 : 12;                    // register-resident entries per lane (16 / 48 per row)
     constexpr int NW = 10;                                   // 64 window rows per workgroup step: windows up to 640 rows in one sweep
     const GroupDev G0 = op.g[0];
     const TileGroupDev T0 = td.g0;
@@ -573,7 +583,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
 #pragma unroll
         for (int u = 0; u < KR; ++u)
             if (u < n0) { const int e = s00 + lane + 64 * u; ixr[u] = si[e]; avr[u] = v2[e]; }   // (uniform; absent entries stay (0, 0.0))
-        const int lr = wv * 32 + (lane >> 1);
+        const int lr = wv * RPW + lane / LPR;
         side = (td.nside && lr < nrows) ? td.side_of_row[r0 + lr] : -1;
     };
     // The LDS-DMA is issued from an asm statement, NOT through __builtin_amdgcn_global_load_lds: hipcc counts the builtin as a
@@ -688,7 +698,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
 #pragma unroll
         for (int s = 0; s < 8; ++s) acc[s] = cplx{0.0, 0.0};
         if (n0 > 0) {                                        // the bulk group: mass + stiffness on one pattern, 16 B + 2 B per nonzero
-            const cplx c0 = spc[G0.plane0], c1 = spc[G0.plane0 + 1];
+            const cplx c0 = td.unit ? cplx{1.0, 0.0} : spc[G0.plane0], c1 = td.unit ? cplx{0.0, 0.0} : spc[G0.plane0 + 1];
             auto fetch = [&](cplx (&x)[8], unsigned ix) {    // the 8 operands of one entry: 8 ds_read_b128, rotated column order
                 const cplx *wr = win + ix * 8;
 #pragma unroll
@@ -698,7 +708,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
                 cplx m = {fma(c0.x, a.x, c1.x * a.y), fma(c0.y, a.x, c1.y * a.y)};
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    if (!UNI) {
+                    if (!UNI && !td.unit) {
                         const int cs = (s + rot) & 7;
                         const cplx d0 = spc[cs * npl + G0.plane0], d1 = spc[cs * npl + G0.plane0 + 1];
                         m = cplx{fma(d0.x, a.x, d1.x * a.y), fma(d0.y, a.x, d1.y * a.y)};
@@ -710,6 +720,13 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
             // entry u, two operand sets alternate; absent entries are (slot 0, 0.0).  The scheduling fences pin that order --
             // left alone hipcc hoists 32 reads, runs out of registers and then issues the rest two at a time behind
             // s_waitcnt lgkmcnt(0).
+            const unsigned short *__restrict__ si = T0.sidx;
+            const double2 *__restrict__ v2 = (const double2 *)T0.svals;
+            // rows longer than LPR * KR entries: the rest is streamed from L2, one entry ahead; the first of them is requested here,
+            // ahead of the window pieces (vector-memory operations complete in order)
+            unsigned ixs = 0;
+            double2 avs = {0.0, 0.0};
+            if (n0 > KR) { const int e = s00 + lane + 64 * KR; ixs = si[e]; avs = v2[e]; }
             cplx xa[8], xb[8];
             fetch(xa, ixr[0]);
 #pragma unroll
@@ -728,40 +745,46 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
                 }
             }
             if (more) issue_rest(Xn, buf ^ 1, same ? w0 : w0_n, Wd);
-            const unsigned short *__restrict__ si = T0.sidx;
-            const double2 *__restrict__ v2 = (const double2 *)T0.svals;
 #pragma unroll 1
-            for (int k = KR; k < n0; ++k) {                  // rows longer than 2 KR entries: streamed
-                const int e = s00 + lane + 64 * k;
+            for (int k = KR; k < n0; ++k) {
+                const unsigned ixc = ixs;
+                const double2 avc = avs;
+                if (k + 1 < n0) { const int e = s00 + lane + 64 * (k + 1); ixs = si[e]; avs = v2[e]; }
                 cplx x[8];
-                fetch(x, si[e]);
-                apply(x, v2[e]);
+                fetch(x, ixc);
+                apply(x, avc);
             }
         } else if (more) {
             issue_window(same ? chn : ch_n, buf ^ 1, gr, same ? w0 : w0_n, Wd);
         }
         TILE_STAMP(3);
-        // the two halves of a row meet; afterwards lane 2 i + h keeps the results of positions 4 h .. 4 h + 3, i.e. of the
-        // columns (4 h + j + rot) mod 8
-        cplx res[4];
+        // the partial sums of a row meet; afterwards each lane keeps NOUT results: those of the columns (rot_out + j) mod 8
+        cplx res[NOUT];
+        if (LPR == 2) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const cplx lo = {acc[j].x + lane_swap1(acc[j].x), acc[j].y + lane_swap1(acc[j].y)};
-            const cplx hi = {acc[j + 4].x + lane_swap1(acc[j + 4].x), acc[j + 4].y + lane_swap1(acc[j + 4].y)};
-            res[j] = hl ? hi : lo;
+            for (int j = 0; j < NOUT; ++j) {
+                const cplx lo = {acc[j].x + lane_quad<0xB1>(acc[j].x), acc[j].y + lane_quad<0xB1>(acc[j].y)};
+                const cplx hi = {acc[j + 4].x + lane_quad<0xB1>(acc[j + 4].x), acc[j + 4].y + lane_quad<0xB1>(acc[j + 4].y)};
+                res[j] = sub ? hi : lo;
+            }
+        } else {                                             // lane q takes positions j + 2 d from lane q - d, d = 0..3
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j)
+                res[j] = cplx{acc[j].x + lane_quad<0x93>(acc[j + 2].x) + lane_quad<0x4E>(acc[j + 4].x) + lane_quad<0x39>(acc[j + 6].x),
+                              acc[j].y + lane_quad<0x93>(acc[j + 2].y) + lane_quad<0x4E>(acc[j + 4].y) + lane_quad<0x39>(acc[j + 6].y)};
         }
         TILE_STAMP(4);
         // Epilogue.  Loads first, then the wait for this wavefront's pieces of the NEXT window (vector-memory operations complete
         // in order, so the wait sits before the stores: those drain under the next chunk), then the stores.
-        const int lrow = wv * 32 + (lane >> 1);              // this lane's row inside the tile
+        const int lrow = wv * RPW + lane / LPR;              // this lane's row inside the tile
         const bool live = lrow < nrows;
         const int64_t row = r0 + (live ? lrow : 0);
         const bool need_b = mode == MODE_RES || mode == MODE_ADD || mode == MODE_RES_DS || mode == MODE_JAC;
         const bool need_d = !(mode == MODE_AX || mode == MODE_RES || mode == MODE_ADD);
-        cplx bv[4], xv[4];
+        cplx bv[NOUT], xv[NOUT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                       // right-hand sides of the fused modes: requested together
-            const int c = (4 * hl + j + rot) & 7;
+        for (int j = 0; j < NOUT; ++j) {                    // right-hand sides of the fused modes: requested together
+            const int c = (rot_out + j) & 7;
             const int b = col0 + c < nb ? col0 + c : nb - 1;
             const size_t e = (size_t)row * nb + b;
             bv[j] = need_b ? B[e] : cplx{0.0, 0.0};
@@ -769,8 +792,8 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
         }
         if (side >= 0) {                                     // the other groups' part of this row (spmv_side_kernel)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = (4 * hl + j + rot) & 7;
+            for (int j = 0; j < NOUT; ++j) {
+                const int c = (rot_out + j) & 7;
                 const int b = col0 + c < nb ? col0 + c : nb - 1;
                 const cplx sv = td.side_acc[(size_t)side * nb + b];
                 res[j].x += sv.x; res[j].y += sv.y;
@@ -782,10 +805,10 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
             dgu = cplx{0.0, 0.0};
             for (int q = 0; q < npl; ++q) { cplx dq = op.diag[(size_t)row * npl + q]; dq.y *= dsg; cfma(dgu, spc[q], dq); }
         }
-        cplx out[4], b2[4];
+        cplx out[NOUT], b2[NOUT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = (4 * hl + j + rot) & 7;
+        for (int j = 0; j < NOUT; ++j) {
+            const int c = (rot_out + j) & 7;
             const cplx av = res[j];
             b2[j] = cplx{0.0, 0.0};
             if (mode == MODE_AX) {
@@ -833,8 +856,8 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
         }
         if (live) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int b = col0 + ((4 * hl + j + rot) & 7);
+            for (int j = 0; j < NOUT; ++j) {
+                const int b = col0 + ((rot_out + j) & 7);
                 if (b >= nb) continue;
 #ifdef TILE_ABL_BLOCKED
                 const size_t e = ((size_t)ch * op.n + row) * 8 + (b & 7);
@@ -902,8 +925,10 @@ static void launch_spmv_tile(const OpDev &op, const TileDev &td, const cplx *pc,
     if (!spc_all) shm = 2 * wslots * 8 * sizeof(cplx) + (size_t)8 * op.nplanes_total * sizeof(cplx) + 16;   // ... or chunk by chunk
     if (shm > 160 * 1024) throw WaeError(WAE_ERR_INVALID, "tile windows do not fit LDS (WAE_TILE_WCAP too large)");
     if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     // Persistent workgroups, one per CU (157 KB of LDS each: the hardware cannot place two on a CU), walking the tiles of
@@ -930,8 +955,10 @@ static void launch_spmv_tile(const OpDev &op, const TileDev &td, const cplx *pc,
                            op.conj_diag, pc, cps, X, nb, cmask);
         HIP_CHECK(hipGetLastError());
     }
-    if (cps % 8 == 0) hipLaunchKernelGGL(spmv_tile_kernel<true>, grid, dim3(512), shm, st, op, td, pc, cps, X, Y, B, jac_w, nb, mode, cmask, spc_all, csplit);
-    else hipLaunchKernelGGL(spmv_tile_kernel<false>, grid, dim3(512), shm, st, op, td, pc, cps, X, Y, B, jac_w, nb, mode, cmask, spc_all, csplit);
+#define WAE_TILE_LAUNCH(U, L) hipLaunchKernelGGL((spmv_tile_kernel<U, L>), grid, dim3(512), shm, st, op, td, pc, cps, X, Y, B, jac_w, nb, mode, cmask, spc_all, csplit)
+    if (td.lpr == 4) { if (cps % 8 == 0) WAE_TILE_LAUNCH(true, 4); else WAE_TILE_LAUNCH(false, 4); }
+    else { if (cps % 8 == 0) WAE_TILE_LAUNCH(true, 2); else WAE_TILE_LAUNCH(false, 2); }
+#undef WAE_TILE_LAUNCH
     HIP_CHECK(hipGetLastError());
 }
 

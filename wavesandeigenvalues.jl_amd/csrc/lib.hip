@@ -64,7 +64,11 @@ static OpDev transfer_dev(const DevBuf<int> &ptr, const DevBuf<int> &col, const 
     return o;
 }
 OpDev Transfer::devP() const { return transfer_dev(p_ptr, p_col, p_val, nf); }
-OpDev Transfer::devR() const { return transfer_dev(r_ptr, r_col, r_val, nc); }
+OpDev Transfer::devR() const {
+    OpDev o = transfer_dev(r_ptr, r_col, r_val, nc);
+    o.tiles = r_tiles.ready ? &r_tiles.dev : nullptr;
+    return o;
+}
 
 struct RbState {                     // snapshot basis of wae_beyn_moments_rb (one per handle)
     cplx *Q = nullptr;               // store: cap snapshots of d x l (interleaved [row][column]); slots < S are orthonormal per column
@@ -283,31 +287,23 @@ static std::vector<int> build_levelop(LevelOp &L, const std::vector<CsrZ> &plane
     return slot_plane;
 }
 
-// tile-local storage of a level operator whose rows have been renumbered into tiles (tiles.h); planes in the level's numbering
-static void build_level_tiles(LevelOp &L, const std::vector<CsrZ> &planes, const std::vector<int> &slot_plane, const std::vector<int> &row_ptr,
-                              hipStream_t st) {
-    TileStore &T = L.tiles;
+// tile-local storage of an operator whose rows have been cut into tiles (tiles.h): windows and the bulk group (two real planes on
+// one pattern).  U: pattern that defines the windows (every column any plane of the operator touches).
+static bool build_tiles_core(TileStore &T, const std::vector<const CsrZ *> &bulk, const Pattern &U, const std::vector<int> &row_ptr, int lpr,
+                             hipStream_t st, const char *what) {
     T = TileStore();
-    if (row_ptr.size() < 2) return;
-    if (L.groups.empty() || !L.groups[0].is_real || L.groups[0].nplanes != 2) return;   // the tile kernel's bulk group: two real planes
-    const Pattern U = union_pattern(planes);
+    if (row_ptr.size() < 2) return false;
     const TileWindows W = build_windows(U, row_ptr);
     const int nt = (int)row_ptr.size() - 1;
     int wmax = 0;
     for (int t = 0; t < nt; ++t) wmax = std::max(wmax, W.win_ptr[t + 1] - W.win_ptr[t]);
-    if (wmax > 65535) return;
+    if (wmax > 65535) return false;
     T.row_ptr.upload(row_ptr.data(), row_ptr.size(), st);
     T.win_ptr.upload(W.win_ptr.data(), W.win_ptr.size(), st);
     T.win_cols.upload(W.win_cols.data(), W.win_cols.size(), st);
-    const size_t ng = L.groups.size();
     memset(&T.dev, 0, sizeof(T.dev));
-    T.all_symmetric = true;
-    for (size_t g = 0; g < ng; ++g) T.all_symmetric = T.all_symmetric && L.groups[g].symmetric;
     {
-        const GroupHost &G = L.groups[0];
-        std::vector<const CsrZ *> mats;
-        for (int q = 0; q < G.nplanes; ++q) mats.push_back(&planes[slot_plane[G.plane0 + q]]);
-        const TileGroupHost H = build_tile_group(mats, G.is_real, row_ptr, W);
+        const TileGroupHost H = build_tile_group(bulk, true, row_ptr, W, lpr);
         T.sptr.upload(H.sptr.data(), H.sptr.size(), st);
         T.sidx.upload(H.sidx.data(), H.sidx.size(), st);
         T.svals.upload(H.svals.data(), H.svals.size(), st);
@@ -316,13 +312,43 @@ static void build_level_tiles(LevelOp &L, const std::vector<CsrZ> &planes, const
         T.dev.g0.sidx = T.sidx.p;
         T.dev.g0.svals = T.svals.p;
         if (getenv("WAE_SETUP_DEBUG")) {
-            int over = 0;                                    // slices longer than the 8 register-resident entries per lane
-            for (size_t i = 0; i + 1 < H.sptr.size(); ++i) over += (H.sptr[i + 1] - H.sptr[i]) / 64 > 8;
-            fprintf(stderr, "[tiles] bulk group: %lld nonzeros in %lld slots (%.3f filled), %d of %zu slices stream entries\n",
-                    (long long)mats[0]->ptr.back(), (long long)H.sptr.back(), (double)mats[0]->ptr.back() / (double)std::max(1, H.sptr.back()),
+            int over = 0, full = 0;                          // slices longer than the register-resident entries per lane
+            for (size_t i = 0; i + 1 < H.sptr.size(); ++i) over += (H.sptr[i + 1] - H.sptr[i]) / 64 > (lpr == 2 ? 8 : 12);
+            for (int t = 0; t < nt; ++t) full += row_ptr[t + 1] - row_ptr[t] == 512 / lpr;
+            fprintf(stderr, "[tiles] %s: %d tiles (%d lanes per row), %.1f rows and %.1f window rows per tile on average, %d full tiles, largest window %d\n", what,
+                    nt, lpr, (double)row_ptr[nt] / nt, (double)W.win_ptr[nt] / nt, full, wmax);
+            fprintf(stderr, "[tiles] %s: %lld nonzeros in %lld slots (%.3f filled), %d of %zu slices stream entries\n", what,
+                    (long long)bulk[0]->ptr.back(), (long long)H.sptr.back(), (double)bulk[0]->ptr.back() / (double)std::max(1, H.sptr.back()),
                     over, H.sptr.size() - 1);
         }
     }
+    const std::vector<unsigned> zero(16, 0u);
+    T.counters.upload(zero.data(), zero.size(), st);
+    HIP_CHECK(hipStreamSynchronize(st));
+    T.dev.ntiles = nt;
+    T.dev.wmax = wmax;
+    T.dev.lpr = lpr;
+    T.dev.row_ptr = T.row_ptr.p;
+    T.dev.win_ptr = T.win_ptr.p;
+    T.dev.win_cols = T.win_cols.p;
+    T.dev.counters = T.counters.p;
+    return true;
+}
+// ... of a level operator; planes in the level's numbering
+static void build_level_tiles(LevelOp &L, const std::vector<CsrZ> &planes, const std::vector<int> &slot_plane, const std::vector<int> &row_ptr,
+                              hipStream_t st, int lpr = 2) {
+    TileStore &T = L.tiles;
+    T = TileStore();
+    if (L.groups.empty() || !L.groups[0].is_real || L.groups[0].nplanes != 2) return;   // the tile kernel's bulk group: two real planes
+    const size_t ng = L.groups.size();
+    {
+        const GroupHost &G = L.groups[0];
+        std::vector<const CsrZ *> mats;
+        for (int q = 0; q < G.nplanes; ++q) mats.push_back(&planes[slot_plane[G.plane0 + q]]);
+        if (!build_tiles_core(T, mats, union_pattern(planes), row_ptr, lpr, st, "operator")) return;
+    }
+    T.all_symmetric = true;
+    for (size_t g = 0; g < ng; ++g) T.all_symmetric = T.all_symmetric && L.groups[g].symmetric;
     {   // side rows: every entry of the other groups, row by row (level numbering), plane slot and complex value per entry
         const int64_t n = L.n;
         std::vector<int> count((size_t)n, 0);
@@ -362,21 +388,6 @@ static void build_level_tiles(LevelOp &L, const std::vector<CsrZ> &planes, const
         if (getenv("WAE_SETUP_DEBUG"))
             fprintf(stderr, "[tiles] %d side rows with %d entries of the other %zu groups\n", nside, ptr.back(), ng - 1);
     }
-    const std::vector<unsigned> zero(16, 0u);
-    T.counters.upload(zero.data(), zero.size(), st);
-    HIP_CHECK(hipStreamSynchronize(st));
-    if (getenv("WAE_SETUP_DEBUG")) {
-        int full = 0;
-        for (int t = 0; t < nt; ++t) full += row_ptr[t + 1] - row_ptr[t] == 256;
-        fprintf(stderr, "[tiles] %d tiles, %.1f rows and %.1f window rows per tile on average, %d tiles with 256 rows, largest window %d\n", nt,
-                (double)row_ptr[nt] / nt, (double)W.win_ptr[nt] / nt, full, wmax);
-    }
-    T.dev.ntiles = nt;
-    T.dev.wmax = wmax;
-    T.dev.row_ptr = T.row_ptr.p;
-    T.dev.win_ptr = T.win_ptr.p;
-    T.dev.win_cols = T.win_cols.p;
-    T.dev.counters = T.counters.p;
     T.ready = true;
 }
 
@@ -435,6 +446,40 @@ static bool proportional(const CsrZ &A, const CsrZ &P, zc &s) {
     for (int64_t p = 0; p < P.nnz(); ++p)
         if (A.val[p] != s * P.val[p]) return false;
     return true;
+}
+
+// ... of the restriction R (rows: the coarse level's tile numbering, columns: the fine level's): consecutive rows are cut into tiles
+// whose fine-level window fits LDS
+static void build_restriction_tiles(Transfer &X, const CsrD &R, int wcap, hipStream_t st) {
+    X.r_tiles = TileStore();
+    CsrZ Rz, Zz;                                             // plane 0 = R, plane 1 = 0 (the kernel's bulk group has two planes)
+    Rz.n = R.n; Rz.m = R.m; Rz.ptr = R.ptr; Rz.col = R.col;
+    Rz.val.resize(R.val.size());
+    for (size_t i = 0; i < R.val.size(); ++i) Rz.val[i] = zc(R.val[i], 0.0);
+    Zz.n = R.n; Zz.m = R.m; Zz.ptr = R.ptr; Zz.col = R.col;
+    Zz.val.assign(R.val.size(), zc(0.0, 0.0));
+    Pattern U;
+    U.n = R.n; U.ptr = R.ptr; U.col = R.col;
+    std::vector<int> row_ptr(1, 0), stamp((size_t)R.m, -1);
+    int rows = 0, win = 0;
+    for (int64_t i = 0; i < R.n; ++i) {
+        if (R.ptr[i + 1] - R.ptr[i] > wcap) return;          // (a row that does not fit a window)
+        int fresh = 0;
+        const int t = (int)row_ptr.size() - 1;
+        for (int p = R.ptr[i]; p < R.ptr[i + 1]; ++p) fresh += stamp[(size_t)R.col[p]] != t;
+        if (rows == 128 || win + fresh > wcap) {
+            row_ptr.push_back((int)i);
+            rows = 0; win = 0;
+        }
+        const int t2 = (int)row_ptr.size() - 1;
+        for (int p = R.ptr[i]; p < R.ptr[i + 1]; ++p)
+            if (stamp[(size_t)R.col[p]] != t2) { stamp[(size_t)R.col[p]] = t2; ++win; }
+        ++rows;
+    }
+    row_ptr.push_back((int)R.n);
+    if (!build_tiles_core(X.r_tiles, {&Rz, &Zz}, U, row_ptr, 4, st, "restriction")) return;
+    X.r_tiles.dev.unit = 1;
+    X.r_tiles.ready = true;
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -1674,6 +1719,49 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
             }
         }
         hipStream_t st = h->stream;
+        // Level 1 renumbered into tiles as well (the numbering of a coarse level is nobody's business but the hierarchy's): its
+        // operator -- ~48 nonzeros per row, gathered from L2 at 1 KB per nonzero and launch -- then runs through the tile kernel.
+        // P of level 0 changes its columns, R its rows; the transfer to level 2 the other way round.
+        std::vector<int> tile1_row_ptr;
+        static const int tile1 = getenv("WAE_TILE_LEVEL1") ? atoi(getenv("WAE_TILE_LEVEL1")) : 1;
+        if (tile1 && lv.size() >= 2 && !h->tile_row_ptr.empty()) {
+            const double tq0 = now_s();
+            static const int wcap = getenv("WAE_TILE_WCAP") ? atoi(getenv("WAE_TILE_WCAP")) : 608;
+            static const int thick = getenv("WAE_TILE_THICK") ? atoi(getenv("WAE_TILE_THICK")) : 6;
+            TilePlan plan = plan_tiles(union_pattern(lv[0].coarse_planes), 128, wcap, thick);
+            if (!plan.perm.empty()) {
+                const std::vector<int> &pm = plan.perm, &ip = plan.iperm;
+                for (CsrZ &A : lv[0].coarse_planes) A = permute_symmetric(A, pm, ip);
+                auto rename_cols = [&](CsrD &A) {            // column c -> ip[c], rows re-sorted
+                    std::vector<std::pair<int, double>> row;
+                    for (int64_t i = 0; i < A.n; ++i) {
+                        row.clear();
+                        for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) row.emplace_back(ip[A.col[p]], A.val[p]);
+                        std::sort(row.begin(), row.end(), [](const std::pair<int, double> &x, const std::pair<int, double> &y) { return x.first < y.first; });
+                        for (int p = A.ptr[i], k = 0; p < A.ptr[i + 1]; ++p, ++k) { A.col[p] = row[k].first; A.val[p] = row[k].second; }
+                    }
+                };
+                auto permute_rows = [&](CsrD &A) {           // new row i = old row pm[i]
+                    CsrD B;
+                    B.n = A.n; B.m = A.m;
+                    B.ptr.assign(A.n + 1, 0);
+                    B.col.reserve(A.col.size()); B.val.reserve(A.val.size());
+                    for (int64_t i = 0; i < A.n; ++i) {
+                        const int o = pm[i];
+                        B.col.insert(B.col.end(), A.col.begin() + A.ptr[o], A.col.begin() + A.ptr[o + 1]);
+                        B.val.insert(B.val.end(), A.val.begin() + A.ptr[o], A.val.begin() + A.ptr[o + 1]);
+                        B.ptr[i + 1] = (int)B.col.size();
+                    }
+                    A = std::move(B);
+                };
+                rename_cols(lv[0].P); permute_rows(lv[0].R);
+                permute_rows(lv[1].P); rename_cols(lv[1].R);
+                tile1_row_ptr = plan.row_ptr;
+            }
+            if (getenv("WAE_SETUP_DEBUG"))
+                fprintf(stderr, "[setup] level 1 tile plan + permutation %.3f s (%zu tiles, largest window %d)\n", now_s() - tq0,
+                        plan.row_ptr.empty() ? (size_t)0 : plan.row_ptr.size() - 1, plan.wmax);
+        }
         {   // the penalty rows' own sub-block, plane by plane (compact numbering)
             std::vector<int> rows, loc(pen.size(), -1);
             for (size_t i = 0; i < pen.size(); ++i)
@@ -1718,6 +1806,7 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
         h->xfer.resize(lv.size());
         for (size_t l = 0; l < lv.size(); ++l) {
             h->slot_plane[l + 1] = build_levelop(h->ops[l + 1], lv[l].coarse_planes, st);
+            if (l == 0 && !tile1_row_ptr.empty()) build_level_tiles(h->ops[1], lv[0].coarse_planes, h->slot_plane[1], tile1_row_ptr, st, 4);
             Transfer &X = h->xfer[l];
             X.nf = lv[l].P.n; X.nc = lv[l].P.m;
             X.p_ptr.upload(lv[l].P.ptr.data(), lv[l].P.ptr.size(), st);
@@ -1727,6 +1816,11 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
             X.r_col.upload(lv[l].R.col.data(), lv[l].R.col.size(), st);
             X.r_val.upload(lv[l].R.val.data(), lv[l].R.val.size(), st);
             HIP_CHECK(hipStreamSynchronize(st));
+            if (l == 0 && !tile1_row_ptr.empty()) {
+                static const int wcap = getenv("WAE_TILE_WCAP") ? atoi(getenv("WAE_TILE_WCAP")) : 608;
+                static const int tile_r = getenv("WAE_TILE_RESTRICT") ? atoi(getenv("WAE_TILE_RESTRICT")) : 1;
+                if (tile_r) build_restriction_tiles(X, lv[0].R, wcap, st);
+            }
         }
         // dense planes of the coarsest level (plane order, row-major)
         const std::vector<CsrZ> &last = lv.empty() ? h->planes0 : lv.back().coarse_planes;

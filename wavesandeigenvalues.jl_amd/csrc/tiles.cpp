@@ -278,19 +278,20 @@ TileWindows build_windows(const Pattern &U, const std::vector<int> &row_ptr) {
     return W;
 }
 
-TileGroupHost build_tile_group(const std::vector<const CsrZ *> &mats, bool is_real, const std::vector<int> &row_ptr, const TileWindows &W) {
+TileGroupHost build_tile_group(const std::vector<const CsrZ *> &mats, bool is_real, const std::vector<int> &row_ptr, const TileWindows &W, int lpr) {
     TileGroupHost T;
     const CsrZ &A = *mats[0];
     const int np = (int)mats.size();
     const int wpe = is_real ? np : 2 * np;                    // doubles per entry
     const size_t nt = row_ptr.size() - 1;
-    // slice (tile, wavefront w) = rows 32 w .. 32 w + 31 of the tile; lane 2 i + h holds the entries k = h, h + 2, ... of row i
+    const int rpw = 64 / lpr;                                 // rows per wavefront
+    // slice (tile, wavefront w) = rows rpw w .. rpw (w + 1) - 1 of the tile; lane lpr i + h holds the entries k = h, h + lpr, ... of row i
     T.sptr.assign(TILE_SLICES * nt + 1, 0);
     for (size_t t = 0; t < nt; ++t)
         for (int w = 0; w < TILE_SLICES; ++w) {
             int len = 0;
-            for (int r = row_ptr[t] + 32 * w; r < std::min(row_ptr[t] + 32 * (w + 1), row_ptr[t + 1]); ++r) len = std::max(len, A.ptr[r + 1] - A.ptr[r]);
-            T.sptr[TILE_SLICES * t + w + 1] = T.sptr[TILE_SLICES * t + w] + 64 * ((len + 1) / 2);
+            for (int r = row_ptr[t] + rpw * w; r < std::min(row_ptr[t] + rpw * (w + 1), row_ptr[t + 1]); ++r) len = std::max(len, A.ptr[r + 1] - A.ptr[r]);
+            T.sptr[TILE_SLICES * t + w + 1] = T.sptr[TILE_SLICES * t + w] + 64 * ((len + lpr - 1) / lpr);
         }
     const size_t total = (size_t)T.sptr.back();
     T.sidx.assign(total, 0);
@@ -301,15 +302,17 @@ TileGroupHost build_tile_group(const std::vector<const CsrZ *> &mats, bool is_re
         const int *wc = W.win_cols.data() + W.win_ptr[t];
         const int wn = W.win_ptr[t + 1] - W.win_ptr[t];
         for (int r = row_ptr[t]; r < row_ptr[t + 1]; ++r) {
-            const int lr = r - row_ptr[t], w = lr >> 5, lane0 = (lr & 31) * 2;
+            const int lr = r - row_ptr[t], w = lr / rpw, riw = lr % rpw, lane0 = riw * lpr;
             const size_t s0 = (size_t)T.sptr[TILE_SLICES * t + w];
-            // Entry order inside a row is free.  The two lanes of a row read, at the same time and in the same rotated column
-            // order, the window rows of entries 2 j and 2 j + 1; a ds_read_b128 serves them in the same LDS cycle, and they
-            // share a bank group exactly when the two window slots have equal parity.  So even positions take the row's
-            // even-slot entries and odd positions its odd-slot entries as far as they pair up; the surplus of one kind goes last.
+            // Entry order inside a row is free; it decides which window slots the lanes of an LDS cycle read together, and two
+            // lanes that read the same column position share a bank group exactly when their window slots have equal parity.
+            // lpr = 2: the two lanes of a row read the same position at the same time, entries 2 j and 2 j + 1: even positions
+            // take the row's even-slot entries and odd positions its odd-slot entries as far as they pair up.
+            // lpr = 4: the partner of lane (row i, q) is lane (row i', q) of a row whose number differs in bit 1 (kernel: rot);
+            // rows with that bit clear list their even-slot entries first, the others their odd-slot entries.
             ent.clear();
             for (int p = A.ptr[r]; p < A.ptr[r + 1]; ++p) ent.emplace_back((int)(std::lower_bound(wc, wc + wn, A.col[p]) - wc), p);
-            if (parity_sort) {
+            if (parity_sort && lpr == 2) {
                 ev.clear(); od.clear();
                 for (const auto &e : ent) (e.first & 1 ? od : ev).push_back(e);
                 const size_t pairs = std::min(ev.size(), od.size());
@@ -317,10 +320,15 @@ TileGroupHost build_tile_group(const std::vector<const CsrZ *> &mats, bool is_re
                 for (size_t j = 0; j < pairs; ++j) { ent.push_back(ev[j]); ent.push_back(od[j]); }
                 for (size_t j = pairs; j < ev.size(); ++j) ent.push_back(ev[j]);
                 for (size_t j = pairs; j < od.size(); ++j) ent.push_back(od[j]);
+            } else if (parity_sort) {
+                const int first = (riw >> 1) & 1;
+                std::stable_sort(ent.begin(), ent.end(), [first](const std::pair<int, int> &x, const std::pair<int, int> &y) {
+                    return ((x.first & 1) ^ first) < ((y.first & 1) ^ first);
+                });
             }
             for (size_t k = 0; k < ent.size(); ++k) {
                 const int p = ent[k].second;
-                const size_t e = s0 + (k >> 1) * 64 + lane0 + (k & 1);
+                const size_t e = s0 + (k / lpr) * 64 + lane0 + (k % lpr);
                 T.sidx[e] = (unsigned short)ent[k].first;
                 for (int q = 0; q < np; ++q) {
                     const zc v = mats[q]->val[p];

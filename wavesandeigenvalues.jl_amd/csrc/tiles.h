@@ -25,10 +25,10 @@ TilePlan plan_tiles(const Pattern &U, int tile_rows, int wcap, int thick);
 // B = P A P^T with P the permutation new -> old (columns re-sorted)
 CsrZ permute_symmetric(const CsrZ &A, const std::vector<int> &perm, const std::vector<int> &iperm);
 
-// Tile-local storage of one pattern group: per (tile, wavefront) a slice of 32 rows, two lanes per row (lane 2 i + h holds
-// the entries h, h + 2, ... of row i), padded to half the longest row of the slice and stored entry-major ([k][lane]) so that
-// the lanes read coalesced; column indices are 16-bit positions in the tile's window.
-constexpr int TILE_SLICES = 8;                 // wavefronts per tile (= 256 rows / 32)
+// Tile-local storage of one pattern group: per (tile, wavefront) a slice of 64 / lpr rows, lpr lanes per row (lane lpr i + h
+// holds the entries h, h + lpr, ... of row i), padded to 1 / lpr of the longest row of the slice and stored entry-major
+// ([k][lane]) so that the lanes read coalesced; column indices are 16-bit positions in the tile's window.
+constexpr int TILE_SLICES = 8;                 // wavefronts per tile
 struct TileGroupHost {
     std::vector<int> sptr;                 // TILE_SLICES*ntiles + 1 entry offsets (multiples of 64)
     std::vector<unsigned short> sidx;      // local column index per entry
@@ -39,4 +39,4 @@ struct TileWindows {
 };
 TileWindows build_windows(const Pattern &U, const std::vector<int> &row_ptr);
 // mats: the planes of one pattern group (same pattern); is_real: store real parts only
-TileGroupHost build_tile_group(const std::vector<const CsrZ *> &mats, bool is_real, const std::vector<int> &row_ptr, const TileWindows &W);
+TileGroupHost build_tile_group(const std::vector<const CsrZ *> &mats, bool is_real, const std::vector<int> &row_ptr, const TileWindows &W, int lpr);

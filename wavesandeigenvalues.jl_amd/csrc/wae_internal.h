@@ -72,13 +72,15 @@ struct GroupDev {                   // one sparsity pattern shared by `nplanes` 
 // tile-local storage of an operator (tiles.h): rows renumbered so that <= 256 consecutive rows form a compact brick of the
 // mesh graph whose distinct columns (the "window") fit LDS
 struct TileGroupDev {
-    const int *sptr;                // 8*ntiles+1: entry offset of the slice of (tile, wavefront)
+    const int *sptr;                // 8*ntiles+1: entry offset of the slice of (tile, wavefront): 64/lpr rows, lpr lanes per row
     const unsigned short *sidx;     // window-local column of every entry ([k][lane] inside a slice)
     const void *svals;              // [entry][nplanes] double or double2, same value layout as GroupDev::vals
 };
 struct TileDev {
     int ntiles;
     int wmax;                       // largest window
+    int lpr;                        // lanes per row: 2 (tiles of up to 256 rows) or 4 (up to 128 rows)
+    int unit;                       // the operator is plane 0 itself (coefficients 1, 0: the restriction), no coefficient table is read
     const int *row_ptr;             // ntiles+1
     const int *win_ptr;             // ntiles+1
     const int *win_cols;            // global (new) column of every window slot, ascending per tile
@@ -189,6 +191,7 @@ struct Transfer {                   // P (n_fine x n_coarse) and R = P^T as sing
     int64_t nf = 0, nc = 0;
     DevBuf<int> p_ptr, p_col, r_ptr, r_col;
     DevBuf<double> p_val, r_val;
+    TileStore r_tiles;              // R in tile-local storage (both levels renumbered into tiles): unit coefficient, no side rows
     OpDev devP() const;
     OpDev devR() const;
 };
