@@ -1702,6 +1702,18 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
             plane_coeffs(h, cs.data(), WAE_OP_N, pc_shape);
         }
         const double t_amg0 = now_s();
+        // The Krylov basis -- (restart + 1) vectors of d x NB complex numbers, 42 GB at 1M unknowns -- takes the driver about a
+        // second to map: it is requested now, on a helper thread, and is there when the host part of the set-up is done.
+        std::future<void> basis_job;
+        {
+            const size_t vec = (size_t)h->d * h->NB, need = vec * (size_t)(h->restart + 1);
+            if (h->V.n != need)
+                basis_job = std::async(std::launch::async, [h, need]() {
+                    HIP_CHECK(hipSetDevice(h->device));
+                    h->V.alloc(need);
+                });
+        }
+        struct Join { std::future<void> &f; ~Join() { if (f.valid()) f.wait(); } } basis_join{basis_job};     // (also on an exception)
         // fine-level aggregation in the caller's node order (iperm[o] = internal index of the caller's node o)
         std::vector<int> visit0;
         if (!h->perm_h.empty()) { visit0.resize(h->perm_h.size()); for (size_t i = 0; i < h->perm_h.size(); ++i) visit0[h->perm_h[i]] = (int)i; }
@@ -1723,11 +1735,11 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
         // operator -- ~48 nonzeros per row, gathered from L2 at 1 KB per nonzero and launch -- then runs through the tile kernel.
         // P of level 0 changes its columns, R its rows; the transfer to level 2 the other way round.
         std::vector<int> tile1_row_ptr;
-        static const int tile1 = getenv("WAE_TILE_LEVEL1") ? atoi(getenv("WAE_TILE_LEVEL1")) : 1;
+        const int tile1 = getenv("WAE_TILE_LEVEL1") ? atoi(getenv("WAE_TILE_LEVEL1")) : 1;      // (read per call: the tests switch it)
         if (tile1 && lv.size() >= 2 && !h->tile_row_ptr.empty()) {
             const double tq0 = now_s();
-            static const int wcap = getenv("WAE_TILE_WCAP") ? atoi(getenv("WAE_TILE_WCAP")) : 608;
-            static const int thick = getenv("WAE_TILE_THICK") ? atoi(getenv("WAE_TILE_THICK")) : 6;
+            const int wcap = getenv("WAE_TILE_WCAP") ? atoi(getenv("WAE_TILE_WCAP")) : 608;
+            const int thick = getenv("WAE_TILE_THICK") ? atoi(getenv("WAE_TILE_THICK")) : 6;
             TilePlan plan = plan_tiles(union_pattern(lv[0].coarse_planes), 128, wcap, thick);
             if (!plan.perm.empty()) {
                 const std::vector<int> &pm = plan.perm, &ip = plan.iperm;
@@ -1817,8 +1829,8 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
             X.r_val.upload(lv[l].R.val.data(), lv[l].R.val.size(), st);
             HIP_CHECK(hipStreamSynchronize(st));
             if (l == 0 && !tile1_row_ptr.empty()) {
-                static const int wcap = getenv("WAE_TILE_WCAP") ? atoi(getenv("WAE_TILE_WCAP")) : 608;
-                static const int tile_r = getenv("WAE_TILE_RESTRICT") ? atoi(getenv("WAE_TILE_RESTRICT")) : 1;
+                const int wcap = getenv("WAE_TILE_WCAP") ? atoi(getenv("WAE_TILE_WCAP")) : 608;
+                const int tile_r = getenv("WAE_TILE_RESTRICT") ? atoi(getenv("WAE_TILE_RESTRICT")) : 1;
                 if (tile_r) build_restriction_tiles(X, lv[0].R, wcap, st);
             }
         }
@@ -1849,7 +1861,8 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
             h->lx[l].alloc(cnt); h->lb[l].alloc(cnt); h->lt[l].alloc(cnt);
         }
         const size_t vec = (size_t)h->d * NB;
-        h->V.alloc(vec * (m + 1));
+        if (basis_job.valid()) basis_job.get();                      // (rethrows an allocation failure)
+        if (h->V.n != vec * (m + 1)) h->V.alloc(vec * (m + 1));
         h->W.alloc(vec); h->Xs.alloc(vec); h->Bs.alloc(vec); h->U.alloc(vec);
         // masked (converged) columns keep stale data: make sure "stale" is never an uninitialised NaN pattern
         HIP_CHECK(hipMemsetAsync(h->V.p, 0, vec * (m + 1) * sizeof(cplx), st));
