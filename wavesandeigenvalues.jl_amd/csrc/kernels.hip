@@ -463,7 +463,7 @@ template <int CTRL> __device__ __forceinline__ double lane_quad(double v) {     
 }
 // LPR = lanes per row: 2 (rows of up to 16 register-resident entries, 256-row tiles: the fine level) or 4 (up to 48, 128-row
 // tiles: the first coarse level, whose windows allow ~64 rows per tile anyway).
-template <bool UNI, int LPR>
+template <bool UNI, int LPR, int NBUF>
 __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td, const cplx *__restrict__ pc, int cps,
                                                           const cplx *__restrict__ X, cplx *Y, const cplx *B, double jac_w,
                                                           int nb, int mode, const unsigned char *__restrict__ cmask, int spc_all, int csplit) {
@@ -478,9 +478,9 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
 #endif
     const int nch_all = (nb + 7) >> 3;
     const int npl = op.nplanes_total;
-    const int wslots = ((td.wmax > 512 ? td.wmax : 512) + 7) & ~7;
-    cplx *const smem = (cplx *)tile_smem;                   // two window buffers [window slot][8 columns] (offsets, not a pointer
-    cplx *spc0 = smem + (size_t)wslots * 16;                // table: the accesses must stay provably LDS), then the coefficients:
+    const int wslots = (td.wmax + 7) & ~7;
+    cplx *const smem = (cplx *)tile_smem;                   // NBUF window buffers [window slot][8 columns] (offsets, not a pointer
+    cplx *spc0 = smem + (size_t)wslots * 8 * NBUF;          // table: the accesses must stay provably LDS), then the coefficients:
                                                             // [8][npl] of the current chunk, or (spc_all) [nb][npl] staged once
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: branches on it are uniform)
     constexpr int RPW = 64 / LPR;                            // rows per wavefront
@@ -545,20 +545,25 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
         if (!ok) { leave(); return; }
     }
     constexpr int KR = LPR == 2 ? 8 : 12;                    // register-resident entries per lane (16 / 48 per row)
-    constexpr int NW = 10;                                   // 64 window rows per workgroup step: windows up to 640 rows in one sweep
+    constexpr int NW = NBUF > 2 ? 7 : 10;                    // 64 window rows per workgroup step: windows up to 448 / 640 rows in one sweep
     const GroupDev G0 = op.g[0];
     const TileGroupDev T0 = td.g0;
     // ---- per-tile state
     int s00, n0, w0, W, r0, nrows;
     int side;                                                // this lane's row in the side-row list (the other groups' part), or -1
+    unsigned dslot;                                          // window slot of this lane's own row (the diagonal's column), 0xFFFF: not there
     unsigned ixr[KR];
     double2 avr[KR];
     int gr[NW];                                              // window row list: wave instruction u moves the window rows wv*8 + 64*u .. +7
     // (two steps: the loads are requested in one place and turned into scalars in another, a memory latency later)
+    // (read through the constant address space: uniform addresses, so these are scalar loads -- no vector registers held while
+    // the answers are under way, and no place in the vector-memory queue)
+    typedef const __attribute__((address_space(4))) int *kint_p;
+    const kint_p k_sptr = (kint_p)(uintptr_t)T0.sptr, k_win = (kint_p)(uintptr_t)td.win_ptr, k_row = (kint_p)(uintptr_t)td.row_ptr;
     auto request_scalars = [&](int t, int (&raw)[6]) {
-        raw[0] = T0.sptr[t * 8 + wv]; raw[1] = T0.sptr[t * 8 + wv + 1];
-        raw[2] = td.win_ptr[t]; raw[3] = td.win_ptr[t + 1];
-        raw[4] = td.row_ptr[t]; raw[5] = td.row_ptr[t + 1];
+        raw[0] = k_sptr[t * 8 + wv]; raw[1] = k_sptr[t * 8 + wv + 1];
+        raw[2] = k_win[t]; raw[3] = k_win[t + 1];
+        raw[4] = k_row[t]; raw[5] = k_row[t + 1];
     };
     auto take_scalars = [&](const int (&raw)[6], int &s00_, int &n0_, int &w0_, int &W_, int &r0_, int &nrows_) {
         s00_ = __builtin_amdgcn_readfirstlane(raw[0]); n0_ = __builtin_amdgcn_readfirstlane((raw[1] - raw[0]) >> 6);
@@ -585,6 +590,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
             if (u < n0) { const int e = s00 + lane + 64 * u; ixr[u] = si[e]; avr[u] = v2[e]; }   // (uniform; absent entries stay (0, 0.0))
         const int lr = wv * RPW + lane / LPR;
         side = (td.nside && lr < nrows) ? td.side_of_row[r0 + lr] : -1;
+        dslot = (NBUF > 2 && T0.dslot && lr < nrows) ? T0.dslot[r0 + lr] : 0xFFFFu;
     };
     // The LDS-DMA is issued from an asm statement, NOT through __builtin_amdgcn_global_load_lds: hipcc counts the builtin as a
     // pending write to LDS and puts s_waitcnt vmcnt(0) before the next ds_read of ANY address -- the wavefront that had just
@@ -599,6 +605,24 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
                      : "=&s"(keep) : "v"(src), "s"(lds_byte) : "memory");
     };
 #define TILE_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+    // ... or until at most k vector-memory operations are outstanding: the k youngest -- the pieces of the window gathered for the
+    // chunk after the next one -- may stay in flight
+    auto dma_wait_but = [&](int k) {
+        switch (k) {
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+    };
+    auto pieces_of = [&](int W_) { const int left = W_ - wv * 8; return left <= 0 ? 0 : (left + 63) / 64 <= NW ? (left + 63) / 64 : 99; };
     // Gather of a window into buffer b, piece by piece (rows past W duplicate the last one into the slack of the 8-row granule:
     // no per-lane predicate).  The pieces of the NEXT window are issued between the entries of the compute phase: a wavefront
     // that issues its ten pieces back to back sits in the issue queue for ~1.2 k cycles.
@@ -623,12 +647,12 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
         for (int u = 0; u < NW; ++u) issue_piece(Xc, b, g_, W_, u);
         issue_rest(Xc, b, w0_, W_);
     };
-    // ---- first tile: everything in sequence (the only exposed prologue of this workgroup)
+    // ---- first tile: scalars, window list, matrix slice; its first window is gathered at the top of the loop (w0 = false)
     load_scalars(tile, s00, n0, w0, W, r0, nrows);
     load_list(gr, w0, W);
     load_matrix();
-    int buf = 0;
-    issue_window(ch, 0, gr, w0, W);
+    int buf = 0;                                             // buffer of the current chunk's window; the windows of the chunks that
+    bool wn0 = false, wn1 = false, wn2 = false;              // follow sit in buf + 1, buf + 2 (mod NBUF): wn_k = "has been requested"
     if (spc_all)
         for (int i = tid; i < nch_all * 8 * npl; i += 512) {
             const int cc = i / npl, q = i - cc * npl;
@@ -636,14 +660,14 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
         }
     // ---- the pipeline over tiles.  The NEXT tile is known from the start of a tile (tile_n: drawn during the tile before); the one
     // after it is drawn during this tile's first chunk (nx = 1: asked, 2: published in LDS, taken over at the switch).  The next
-    // tile's scalars are requested at the top of the first chunk and known at its end; its window list replaces this tile's at
-    // the end of the second-to-last chunk, so that the last chunk gathers the next tile's first window.
+    // tile's scalars are requested at the top of the first chunk and known at its end; its window list replaces this tile's (gr)
+    // as soon as this tile has requested its last own window, so that its last chunks gather the next tile's first windows.
     int nx = 0;
     unsigned pend = 0;                                       // (thread 0) the returning atomic of the draw
     bool pub_fresh = false;                                  // published at the end of this very chunk (no barrier since)
     int tile_n = 0, ch_n = 0, ch_end_n = 0;
     bool has_next = false;
-    {                                                        // the first "next": drawn here, in the shadow of the first window
+    {                                                        // the first "next": drawn here
         if (tid == 0) *vt_slot = draw(-1);
         __syncthreads();
         const int vt = *vt_slot;
@@ -651,27 +675,47 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
     }
     int s00_n = 0, n0_n = 0, w0_n = 0, W_n = 0, r0_n = 0, nrows_n = 0;
     bool sc_ready = false;                                   // the scalars of tile_n are known
-    bool pre_ready = false;                                  // gr holds the window list of tile_n (from the end of this tile's
-                                                             // second-to-last chunk on: its own list is not needed any more)
+    bool pre_ready = false;                                  // gr holds the window list of tile_n, not this tile's any more
     bool pre_asked = false;                                  // its scalars have been requested (pre_raw)
     int pre_raw[6];
 #pragma unroll
     for (int u = 0; u < 6; ++u) pre_raw[u] = 0;
-    TILE_DMA_WAIT();
 #ifdef WAE_TILE_STAMPS
-    if (blockIdx.x == TILE_STAMP_WG && tid == 0) wae_tile_stamps[65] = __builtin_amdgcn_s_memtime();      // prologue done (own share of window 0 landed)
+    if (blockIdx.x == TILE_STAMP_WG && tid == 0) wae_tile_stamps[65] = __builtin_amdgcn_s_memtime();      // prologue done
     int nstamp = 0;
 #endif
     while (true) {
-        const int chn = next_active(ch + 1, ch_end);
-        const bool same = chn < ch_end;                      // the next chunk belongs to this tile
-        const bool more = same || (has_next && pre_ready);   // a next window can be gathered under this chunk
+        // the chunks that follow: c1 (next), c2 (the one after); in this tile or (in_n) in the next one
+        const int c1o = next_active(ch + 1, ch_end);
+        const bool same = c1o < ch_end;                      // the next chunk belongs to this tile
+        const bool v1 = same || has_next;
+        const bool n1 = !same;
+        const int c1 = same ? c1o : ch_n;
+        int c2 = 0;
+        bool v2 = false, n2 = false;
+        if (NBUF > 2) {
+            if (same) {
+                const int c2o = next_active(c1o + 1, ch_end);
+                if (c2o < ch_end) { v2 = true; c2 = c2o; }
+                else if (has_next) { v2 = true; n2 = true; c2 = ch_n; }
+            } else if (has_next) {
+                const int c2o = next_active(ch_n + 1, ch_end_n);
+                if (c2o < ch_end_n) { v2 = true; n2 = true; c2 = c2o; }
+            }
+        }
         const int col0 = ch * 8;
         TILE_STAMP(0);
         cplx *spc = spc0 + (spc_all ? (size_t)col0 * npl : 0);
+        if (!wn0) {                                          // this chunk's window has not been requested (first chunk of the workgroup,
+            if (pre_ready) { load_list(gr, w0, W); pre_ready = false; }      // tiles of very few chunks): gather it now, exposed
+            __syncthreads();
+            issue_window(ch, buf, gr, w0, W);
+            TILE_DMA_WAIT();
+            wn0 = true;
+        }
         __syncthreads();                                     // everybody's share of this chunk's window has landed (each wavefront
                                                              // waited for its own before its last stores); every wavefront is done
-        if (!spc_all) {                                      // with the other buffer (the previous window) and the previous coefficients
+        if (!spc_all) {                                      // with the buffer of the previous chunk and the previous coefficients
             for (int i = tid; i < 8 * npl; i += 512) {
                 const int cc = i / npl, q = i - cc * npl;
                 int bb = col0 + cc;
@@ -691,21 +735,73 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
             }
             nx = 1;
         }
-        const cplx *Xn = window_src(same ? chn : ch_n);
-        const int Wd = same ? W : W_n;                       // rows of the window gathered under this chunk
-        TILE_STAMP(2);
+        // this lane's rows and columns in the epilogue
+        const int lrow = wv * RPW + lane / LPR;              // this lane's row inside the tile
+        const bool live = lrow < nrows;
+        const int64_t row = r0 + (live ? lrow : 0);
+        const bool need_b = mode == MODE_RES || mode == MODE_ADD || mode == MODE_RES_DS || mode == MODE_JAC;
+        const bool need_d = !(mode == MODE_AX || mode == MODE_RES || mode == MODE_ADD);
+        const double dsg = op.conj_diag ? -1.0 : 1.0;
+        cplx bv[NOUT], xv[NOUT];
+        cplx dgu = {1.0, 0.0};
+        auto epilogue_loads = [&]() {                        // right-hand sides of the fused modes: requested together
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) {
+                const int c = (rot_out + j) & 7;
+                const int b = col0 + c < nb ? col0 + c : nb - 1;
+                const size_t e = (size_t)row * nb + b;
+                bv[j] = need_b ? B[e] : cplx{0.0, 0.0};
+                xv[j] = (mode == MODE_JAC && (NBUF == 2 || dslot == 0xFFFFu)) ? X[e] : cplx{0.0, 0.0};
+            }
+            if (UNI && need_d) {                             // one diagonal per row and chunk
+                dgu = cplx{0.0, 0.0};
+                for (int q = 0; q < npl; ++q) { cplx dq = op.diag[(size_t)row * npl + q]; dq.y *= dsg; cfma(dgu, spc[q], dq); }
+            }
+        };
+        // With three buffers the window gathered under this chunk belongs to the chunk after the next one and must stay in flight
+        // past this chunk's end: whatever the epilogue loads from memory is requested HERE, ahead of the window's pieces (vector-
+        // memory operations complete in order, and the compiler's wait for a load retires everything older with it).  The
+        // right-hand side goes straight into the accumulators (positions this lane will keep, sign such that they end up holding
+        // A x - b, or A x + b for MODE_ADD): no registers of its own.
         cplx acc[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) acc[s] = cplx{0.0, 0.0};
+        if (NBUF > 2) {
+            epilogue_loads();
+            const double sb = mode == MODE_ADD ? 1.0 : -1.0;
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) {
+                if (LPR == 2) {
+                    acc[j] = cplx{sub == 0 ? sb * bv[j].x : 0.0, sub == 0 ? sb * bv[j].y : 0.0};
+                    acc[j + 4] = cplx{sub == 1 ? sb * bv[j].x : 0.0, sub == 1 ? sb * bv[j].y : 0.0};
+                } else {
+                    acc[j] = cplx{sb * bv[j].x, sb * bv[j].y};
+                }
+            }
+        }
+        // windows to request under this chunk: the one NBUF - 1 chunks ahead; with three buffers also the next one, should it be
+        // missing (start of the pipeline).  A window of this tile needs this tile's list in gr, one of the next tile the other list.
+        if (NBUF > 2 && !wn1 && v1 && (n1 ? pre_ready : !pre_ready)) {
+            issue_window(c1, (buf + 1) % NBUF, gr, n1 ? w0_n : w0, n1 ? W_n : W);
+            wn1 = true;
+        }
+        const bool vt_ = NBUF > 2 ? v2 : v1, nt_ = NBUF > 2 ? n2 : n1;
+        const bool already = NBUF > 2 ? wn2 : wn1;
+        const bool more = vt_ && !already && (nt_ ? pre_ready : !pre_ready);     // a window is gathered under this chunk
+        const int ct = NBUF > 2 ? c2 : c1;
+        const cplx *Xn = window_src(more ? ct : ch);
+        const int Wd = nt_ ? W_n : W;                        // rows of that window
+        const int bt = (buf + NBUF - 1) % NBUF;              // its buffer
+        TILE_STAMP(2);
         if (n0 > 0) {                                        // the bulk group: mass + stiffness on one pattern, 16 B + 2 B per nonzero
-            const cplx c0 = td.unit ? cplx{1.0, 0.0} : spc[G0.plane0], c1 = td.unit ? cplx{0.0, 0.0} : spc[G0.plane0 + 1];
+            const cplx c0 = td.unit ? cplx{1.0, 0.0} : spc[G0.plane0], c1p = td.unit ? cplx{0.0, 0.0} : spc[G0.plane0 + 1];
             auto fetch = [&](cplx (&x)[8], unsigned ix) {    // the 8 operands of one entry: 8 ds_read_b128, rotated column order
                 const cplx *wr = win + ix * 8;
 #pragma unroll
                 for (int s = 0; s < 8; ++s) x[s] = wr[(s + rot) & 7];
             };
             auto apply = [&](const cplx (&x)[8], double2 a) {
-                cplx m = {fma(c0.x, a.x, c1.x * a.y), fma(c0.y, a.x, c1.y * a.y)};
+                cplx m = {fma(c0.x, a.x, c1p.x * a.y), fma(c0.y, a.x, c1p.y * a.y)};
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
                     if (!UNI && !td.unit) {
@@ -716,10 +812,6 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
                     cfma(acc[s], m, x[s]);
                 }
             };
-            // register-resident part, software-pipelined by hand: the operands of entry u+1 are requested before the FMAs of
-            // entry u, two operand sets alternate; absent entries are (slot 0, 0.0).  The scheduling fences pin that order --
-            // left alone hipcc hoists 32 reads, runs out of registers and then issues the rest two at a time behind
-            // s_waitcnt lgkmcnt(0).
             const unsigned short *__restrict__ si = T0.sidx;
             const double2 *__restrict__ v2 = (const double2 *)T0.svals;
             // rows longer than LPR * KR entries: the rest is streamed from L2, one entry ahead; the first of them is requested here,
@@ -727,6 +819,10 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
             unsigned ixs = 0;
             double2 avs = {0.0, 0.0};
             if (n0 > KR) { const int e = s00 + lane + 64 * KR; ixs = si[e]; avs = v2[e]; }
+            // register-resident part, software-pipelined by hand: the operands of entry u+1 are requested before the FMAs of
+            // entry u, two operand sets alternate; absent entries are (slot 0, 0.0).  The scheduling fences pin that order --
+            // left alone hipcc hoists 32 reads, runs out of registers and then issues the rest two at a time behind
+            // s_waitcnt lgkmcnt(0).
             cplx xa[8], xb[8];
             fetch(xa, ixr[0]);
 #pragma unroll
@@ -739,12 +835,12 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
                                   "+v"(acc[3].x), "+v"(acc[3].y), "+v"(acc[4].x), "+v"(acc[4].y), "+v"(acc[5].x), "+v"(acc[5].y),
                                   "+v"(acc[6].x), "+v"(acc[6].y), "+v"(acc[7].x), "+v"(acc[7].y) : : "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                if (more && 2 * u < NW) {                    // the next window, two pieces per entry: all under way by the middle
-                    issue_piece(Xn, buf ^ 1, gr, Wd, 2 * u); // of the phase, landed (mostly) by its end
-                    if (2 * u + 1 < NW) issue_piece(Xn, buf ^ 1, gr, Wd, 2 * u + 1);
+                if (more && 2 * u < NW) {                    // the window, two pieces per entry: all under way by the middle of the phase
+                    issue_piece(Xn, bt, gr, Wd, 2 * u);
+                    if (2 * u + 1 < NW) issue_piece(Xn, bt, gr, Wd, 2 * u + 1);
                 }
             }
-            if (more) issue_rest(Xn, buf ^ 1, same ? w0 : w0_n, Wd);
+            if (more) issue_rest(Xn, bt, nt_ ? w0_n : w0, Wd);
 #pragma unroll 1
             for (int k = KR; k < n0; ++k) {
                 const unsigned ixc = ixs;
@@ -755,8 +851,9 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
                 apply(x, avc);
             }
         } else if (more) {
-            issue_window(same ? chn : ch_n, buf ^ 1, gr, same ? w0 : w0_n, Wd);
+            issue_window(ct, bt, gr, nt_ ? w0_n : w0, Wd);
         }
+        if (more) { if (NBUF > 2) wn2 = true; else wn1 = true; }
         TILE_STAMP(3);
         // the partial sums of a row meet; afterwards each lane keeps NOUT results: those of the columns (rot_out + j) mod 8
         cplx res[NOUT];
@@ -774,21 +871,12 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
                               acc[j].y + lane_quad<0x93>(acc[j + 2].y) + lane_quad<0x4E>(acc[j + 4].y) + lane_quad<0x39>(acc[j + 6].y)};
         }
         TILE_STAMP(4);
-        // Epilogue.  Loads first, then the wait for this wavefront's pieces of the NEXT window (vector-memory operations complete
-        // in order, so the wait sits before the stores: those drain under the next chunk), then the stores.
-        const int lrow = wv * RPW + lane / LPR;              // this lane's row inside the tile
-        const bool live = lrow < nrows;
-        const int64_t row = r0 + (live ? lrow : 0);
-        const bool need_b = mode == MODE_RES || mode == MODE_ADD || mode == MODE_RES_DS || mode == MODE_JAC;
-        const bool need_d = !(mode == MODE_AX || mode == MODE_RES || mode == MODE_ADD);
-        cplx bv[NOUT], xv[NOUT];
+        // Epilogue.  (Two buffers: loads first, then the wait for this wavefront's pieces of the next window, which sits before the
+        // stores: those drain under the next chunk.)
+        if (NBUF == 2) epilogue_loads();
+        if (NBUF > 2 && mode == MODE_JAC && dslot != 0xFFFFu) {      // the row's own X: it is in the window
 #pragma unroll
-        for (int j = 0; j < NOUT; ++j) {                    // right-hand sides of the fused modes: requested together
-            const int c = (rot_out + j) & 7;
-            const int b = col0 + c < nb ? col0 + c : nb - 1;
-            const size_t e = (size_t)row * nb + b;
-            bv[j] = need_b ? B[e] : cplx{0.0, 0.0};
-            xv[j] = mode == MODE_JAC ? X[e] : cplx{0.0, 0.0};
+            for (int j = 0; j < NOUT; ++j) xv[j] = win[dslot * 8 + ((rot_out + j) & 7)];
         }
         if (side >= 0) {                                     // the other groups' part of this row (spmv_side_kernel)
 #pragma unroll
@@ -799,24 +887,20 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
                 res[j].x += sv.x; res[j].y += sv.y;
             }
         }
-        cplx dgu = {1.0, 0.0};
-        const double dsg = op.conj_diag ? -1.0 : 1.0;
-        if (UNI && need_d) {                                 // one diagonal per row and chunk
-            dgu = cplx{0.0, 0.0};
-            for (int q = 0; q < npl; ++q) { cplx dq = op.diag[(size_t)row * npl + q]; dq.y *= dsg; cfma(dgu, spc[q], dq); }
-        }
         cplx out[NOUT], b2[NOUT];
 #pragma unroll
         for (int j = 0; j < NOUT; ++j) {
             const int c = (rot_out + j) & 7;
             const cplx av = res[j];
             b2[j] = cplx{0.0, 0.0};
+            // (three buffers: av is A x - b, or A x + b, already: bz stands in for the right-hand side)
+            const cplx bz = NBUF > 2 ? cplx{0.0, 0.0} : bv[j];
             if (mode == MODE_AX) {
                 out[j] = av;
             } else if (mode == MODE_RES) {
-                out[j] = cplx{bv[j].x - av.x, bv[j].y - av.y};
+                out[j] = cplx{bz.x - av.x, bz.y - av.y};
             } else if (mode == MODE_ADD) {
-                out[j] = cplx{bv[j].x + av.x, bv[j].y + av.y};
+                out[j] = cplx{bz.x + av.x, bz.y + av.y};
             } else {
                 cplx dg = dgu;
                 if (!UNI) {
@@ -831,15 +915,17 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
                 } else if (mode == MODE_AX_DS) {
                     out[j] = cdiv(av, dg);
                 } else if (mode == MODE_RES_DS) {
-                    out[j] = cdiv(cplx{bv[j].x - av.x, bv[j].y - av.y}, dg);
+                    out[j] = cdiv(cplx{bz.x - av.x, bz.y - av.y}, dg);
                 } else {
-                    const cplx r = cdiv(cplx{bv[j].x - av.x, bv[j].y - av.y}, dg);
+                    const cplx r = cdiv(cplx{bz.x - av.x, bz.y - av.y}, dg);
                     out[j] = cplx{xv[j].x + jac_w * r.x, xv[j].y + jac_w * r.y};
                 }
             }
         }
         TILE_STAMP(5);
-        TILE_DMA_WAIT();
+        // this wavefront's pieces of the NEXT chunk's window must have landed (the barrier at the top of the next chunk tells the
+        // others); with three buffers the pieces just issued -- the youngest operations -- stay in flight
+        if (NBUF > 2 && more) dma_wait_but(pieces_of(Wd)); else TILE_DMA_WAIT();
         if (nx == 1) {                                       // the draw has come back: publish it (read at the tile switch)
             if (tid == 0 && has_next) *vt_slot = draw(gpx < share_size(xcd) ? gpx + (int)pend : -1);
             nx = 2;
@@ -850,9 +936,12 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
             pre_asked = false;
             sc_ready = true;
         }
-        if (sc_ready && !pre_ready && same && next_active(chn + 1, ch_end) >= ch_end) {   // end of the second-to-last chunk: this
-            load_list(gr, w0_n, W_n);                        // tile's own list has served (the last window is on its way); the
-            pre_ready = true;                                // next tile's list is requested (no wait: used in the last chunk)
+        // this tile has requested its last own window once fewer than NBUF - 1 of its chunks follow the next one: from then on gr
+        // holds the next tile's list (requested here, no wait: used under the next chunk at the earliest)
+        if (sc_ready && !pre_ready && has_next && same) {
+            int left = 0;                                    // own chunks after c1
+            for (int c = next_active(c1o + 1, ch_end); c < ch_end && left < NBUF; c = next_active(c + 1, ch_end)) ++left;
+            if (left < NBUF - 1) { load_list(gr, w0_n, W_n); pre_ready = true; }
         }
         if (live) {
 #pragma unroll
@@ -872,16 +961,16 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
 #ifdef WAE_TILE_STAMPS
         ++nstamp;
 #endif
-        buf ^= 1;
+        buf = (buf + 1) % NBUF;
+        wn0 = wn1; wn1 = wn2; wn2 = false;
         if (same) {
-            ch = chn;
+            ch = c1o;
         } else {                                             // ---- tile switch
             if (!has_next) break;
-            if (!pre_ready) {                                // (single-chunk tiles: the list could not be prefetched)
+            if (!pre_ready) {                                // (tiles of very few chunks: the list could not be prefetched)
                 if (!sc_ready) load_scalars(tile_n, s00_n, n0_n, w0_n, W_n, r0_n, nrows_n);
                 load_list(gr, w0_n, W_n);
             }
-            const bool had_window = more;                    // the first window of the next tile was gathered under this chunk
             tile = tile_n; ch = ch_n; ch_end = ch_end_n;
             s00 = s00_n; n0 = n0_n; w0 = w0_n; W = W_n; r0 = r0_n; nrows = nrows_n;
             load_matrix();                                   // (lands under the barrier and the first reads of the next chunk)
@@ -893,11 +982,6 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
                 has_next = vt >= 0 && decode(vt, tile_n, ch_n, ch_end_n);
             }
             nx = 0;
-            if (!had_window) {                               // gather it now, exposed
-                __syncthreads();                             // (the other buffer's last readers are done)
-                issue_window(ch, buf, gr, w0, W);
-                TILE_DMA_WAIT();
-            }
         }
     }
     leave();
@@ -918,17 +1002,20 @@ extern "C" int wae_debug_tile_stamps(unsigned long long *out) {
 static void launch_spmv_tile(const OpDev &op, const TileDev &td, const cplx *pc, int cps, const cplx *X, cplx *Y, const cplx *B, double jac_w,
                              int nb, int mode, hipStream_t st, const unsigned char *cmask) {
     static bool attr_set = false;
-    const size_t wslots = (size_t)(((td.wmax > 512 ? td.wmax : 512) + 7) & ~7);
+    const int nbuf = td.nbuf == 3 && td.lpr == 2 ? 3 : 2;
+    const size_t wslots = (size_t)((td.wmax + 7) & ~7);
     const int nch8 = ((nb + 7) / 8) * 8;
-    size_t shm = 2 * wslots * 8 * sizeof(cplx) + (size_t)nch8 * op.nplanes_total * sizeof(cplx) + 16;   // coefficients of all chunks staged once ...
+    size_t shm = nbuf * wslots * 8 * sizeof(cplx) + (size_t)nch8 * op.nplanes_total * sizeof(cplx) + 16;   // coefficients of all chunks staged once ...
     const int spc_all = shm <= 160 * 1024;                   // (+ 16: the word through which a workgroup learns its next tile)
-    if (!spc_all) shm = 2 * wslots * 8 * sizeof(cplx) + (size_t)8 * op.nplanes_total * sizeof(cplx) + 16;   // ... or chunk by chunk
+    if (!spc_all) shm = nbuf * wslots * 8 * sizeof(cplx) + (size_t)8 * op.nplanes_total * sizeof(cplx) + 16;   // ... or chunk by chunk
     if (shm > 160 * 1024) throw WaeError(WAE_ERR_INVALID, "tile windows do not fit LDS (WAE_TILE_WCAP too large)");
     if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<true, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<false, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<true, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<false, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<true, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<false, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     // Persistent workgroups, one per CU (157 KB of LDS each: the hardware cannot place two on a CU), walking the tiles of
@@ -955,9 +1042,10 @@ static void launch_spmv_tile(const OpDev &op, const TileDev &td, const cplx *pc,
                            op.conj_diag, pc, cps, X, nb, cmask);
         HIP_CHECK(hipGetLastError());
     }
-#define WAE_TILE_LAUNCH(U, L) hipLaunchKernelGGL((spmv_tile_kernel<U, L>), grid, dim3(512), shm, st, op, td, pc, cps, X, Y, B, jac_w, nb, mode, cmask, spc_all, csplit)
-    if (td.lpr == 4) { if (cps % 8 == 0) WAE_TILE_LAUNCH(true, 4); else WAE_TILE_LAUNCH(false, 4); }
-    else { if (cps % 8 == 0) WAE_TILE_LAUNCH(true, 2); else WAE_TILE_LAUNCH(false, 2); }
+#define WAE_TILE_LAUNCH(U, L, N) hipLaunchKernelGGL((spmv_tile_kernel<U, L, N>), grid, dim3(512), shm, st, op, td, pc, cps, X, Y, B, jac_w, nb, mode, cmask, spc_all, csplit)
+    if (td.lpr == 4) { if (cps % 8 == 0) WAE_TILE_LAUNCH(true, 4, 2); else WAE_TILE_LAUNCH(false, 4, 2); }
+    else if (nbuf == 3) { if (cps % 8 == 0) WAE_TILE_LAUNCH(true, 2, 3); else WAE_TILE_LAUNCH(false, 2, 3); }
+    else { if (cps % 8 == 0) WAE_TILE_LAUNCH(true, 2, 2); else WAE_TILE_LAUNCH(false, 2, 2); }
 #undef WAE_TILE_LAUNCH
     HIP_CHECK(hipGetLastError());
 }

@@ -290,7 +290,7 @@ static std::vector<int> build_levelop(LevelOp &L, const std::vector<CsrZ> &plane
 // tile-local storage of an operator whose rows have been cut into tiles (tiles.h): windows and the bulk group (two real planes on
 // one pattern).  U: pattern that defines the windows (every column any plane of the operator touches).
 static bool build_tiles_core(TileStore &T, const std::vector<const CsrZ *> &bulk, const Pattern &U, const std::vector<int> &row_ptr, int lpr,
-                             hipStream_t st, const char *what) {
+                             hipStream_t st, const char *what, int nbuf = 2) {
     T = TileStore();
     if (row_ptr.size() < 2) return false;
     const TileWindows W = build_windows(U, row_ptr);
@@ -307,16 +307,18 @@ static bool build_tiles_core(TileStore &T, const std::vector<const CsrZ *> &bulk
         T.sptr.upload(H.sptr.data(), H.sptr.size(), st);
         T.sidx.upload(H.sidx.data(), H.sidx.size(), st);
         T.svals.upload(H.svals.data(), H.svals.size(), st);
+        T.dslot.upload(H.dslot.data(), H.dslot.size(), st);
         HIP_CHECK(hipStreamSynchronize(st));                 // H dies at the end of this scope
         T.dev.g0.sptr = T.sptr.p;
         T.dev.g0.sidx = T.sidx.p;
         T.dev.g0.svals = T.svals.p;
+        T.dev.g0.dslot = T.dslot.p;
         if (getenv("WAE_SETUP_DEBUG")) {
             int over = 0, full = 0;                          // slices longer than the register-resident entries per lane
             for (size_t i = 0; i + 1 < H.sptr.size(); ++i) over += (H.sptr[i + 1] - H.sptr[i]) / 64 > (lpr == 2 ? 8 : 12);
             for (int t = 0; t < nt; ++t) full += row_ptr[t + 1] - row_ptr[t] == 512 / lpr;
-            fprintf(stderr, "[tiles] %s: %d tiles (%d lanes per row), %.1f rows and %.1f window rows per tile on average, %d full tiles, largest window %d\n", what,
-                    nt, lpr, (double)row_ptr[nt] / nt, (double)W.win_ptr[nt] / nt, full, wmax);
+            fprintf(stderr, "[tiles] %s: %d tiles (%d lanes per row, %d window buffers), %.1f rows and %.1f window rows per tile on average, %d full tiles, largest window %d\n",
+                    what, nt, lpr, (nbuf == 3 && lpr == 2 && wmax <= 400) ? 3 : 2, (double)row_ptr[nt] / nt, (double)W.win_ptr[nt] / nt, full, wmax);
             fprintf(stderr, "[tiles] %s: %lld nonzeros in %lld slots (%.3f filled), %d of %zu slices stream entries\n", what,
                     (long long)bulk[0]->ptr.back(), (long long)H.sptr.back(), (double)bulk[0]->ptr.back() / (double)std::max(1, H.sptr.back()),
                     over, H.sptr.size() - 1);
@@ -328,6 +330,7 @@ static bool build_tiles_core(TileStore &T, const std::vector<const CsrZ *> &bulk
     T.dev.ntiles = nt;
     T.dev.wmax = wmax;
     T.dev.lpr = lpr;
+    T.dev.nbuf = (nbuf == 3 && lpr == 2 && wmax <= 400) ? 3 : 2;
     T.dev.row_ptr = T.row_ptr.p;
     T.dev.win_ptr = T.win_ptr.p;
     T.dev.win_cols = T.win_cols.p;
@@ -336,7 +339,7 @@ static bool build_tiles_core(TileStore &T, const std::vector<const CsrZ *> &bulk
 }
 // ... of a level operator; planes in the level's numbering
 static void build_level_tiles(LevelOp &L, const std::vector<CsrZ> &planes, const std::vector<int> &slot_plane, const std::vector<int> &row_ptr,
-                              hipStream_t st, int lpr = 2) {
+                              hipStream_t st, int lpr = 2, int nbuf = 2) {
     TileStore &T = L.tiles;
     T = TileStore();
     if (L.groups.empty() || !L.groups[0].is_real || L.groups[0].nplanes != 2) return;   // the tile kernel's bulk group: two real planes
@@ -345,7 +348,7 @@ static void build_level_tiles(LevelOp &L, const std::vector<CsrZ> &planes, const
         const GroupHost &G = L.groups[0];
         std::vector<const CsrZ *> mats;
         for (int q = 0; q < G.nplanes; ++q) mats.push_back(&planes[slot_plane[G.plane0 + q]]);
-        if (!build_tiles_core(T, mats, union_pattern(planes), row_ptr, lpr, st, "operator")) return;
+        if (!build_tiles_core(T, mats, union_pattern(planes), row_ptr, lpr, st, "operator", nbuf)) return;
     }
     T.all_symmetric = true;
     for (size_t g = 0; g < ng; ++g) T.all_symmetric = T.all_symmetric && L.groups[g].symmetric;
@@ -1472,7 +1475,11 @@ int wae_family_create(wae_family **out, int64_t d, int32_t T, int32_t index_byte
         // renumber the rows into compact tiles (tiles.h); WAE_REORDER=0 keeps the caller's numbering (A/B measurements)
         static const bool reorder_on = !(getenv("WAE_REORDER") && atoi(getenv("WAE_REORDER")) == 0);
         if (reorder_on) {
-            static const int wcap = getenv("WAE_TILE_WCAP") ? atoi(getenv("WAE_TILE_WCAP")) : 608;      // 2 workgroups x 78 KB of LDS per CU
+            // fine level: two window buffers of 608 rows x 128 B.  WAE_TILE_NBUF=3: three of 400 (two windows in flight while a
+            // third is read) -- measured slower, 966 vs 733 us at 1M unknowns and 64 columns: a chunk costs a wavefront the same
+            // ~10 k cycles whether its tile has 174 rows or 256 (lane = row), the gather was not what it waited for.
+            static const int nbuf0 = getenv("WAE_TILE_NBUF") ? atoi(getenv("WAE_TILE_NBUF")) : 2;
+            static const int wcap = getenv("WAE_TILE_WCAP") ? atoi(getenv("WAE_TILE_WCAP")) : (nbuf0 == 3 ? 400 : 608);
             static const int thick = getenv("WAE_TILE_THICK") ? atoi(getenv("WAE_TILE_THICK")) : 6;
             const double tq0 = now_s();
             TilePlan plan = plan_tiles(union_pattern(h->planes0), 256, wcap, thick);
@@ -1493,7 +1500,8 @@ int wae_family_create(wae_family **out, int64_t d, int32_t T, int32_t index_byte
         h->ops.resize(1);
         h->slot_plane.resize(1);
         h->slot_plane[0] = build_levelop(h->ops[0], h->planes0, h->stream);
-        if (!h->tile_row_ptr.empty()) build_level_tiles(h->ops[0], h->planes0, h->slot_plane[0], h->tile_row_ptr, h->stream);
+        if (!h->tile_row_ptr.empty())
+            build_level_tiles(h->ops[0], h->planes0, h->slot_plane[0], h->tile_row_ptr, h->stream, 2, getenv("WAE_TILE_NBUF") ? atoi(getenv("WAE_TILE_NBUF")) : 2);
         cplx one = {1.0, 0.0};
         h->one_dev.upload(&one, 1, h->stream);
         HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -1738,7 +1746,7 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
         const int tile1 = getenv("WAE_TILE_LEVEL1") ? atoi(getenv("WAE_TILE_LEVEL1")) : 1;      // (read per call: the tests switch it)
         if (tile1 && lv.size() >= 2 && !h->tile_row_ptr.empty()) {
             const double tq0 = now_s();
-            const int wcap = getenv("WAE_TILE_WCAP") ? atoi(getenv("WAE_TILE_WCAP")) : 608;
+            const int wcap = getenv("WAE_TILE_WCAP1") ? atoi(getenv("WAE_TILE_WCAP1")) : 608;        // (two window buffers)
             const int thick = getenv("WAE_TILE_THICK") ? atoi(getenv("WAE_TILE_THICK")) : 6;
             TilePlan plan = plan_tiles(union_pattern(lv[0].coarse_planes), 128, wcap, thick);
             if (!plan.perm.empty()) {
@@ -1829,7 +1837,7 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
             X.r_val.upload(lv[l].R.val.data(), lv[l].R.val.size(), st);
             HIP_CHECK(hipStreamSynchronize(st));
             if (l == 0 && !tile1_row_ptr.empty()) {
-                const int wcap = getenv("WAE_TILE_WCAP") ? atoi(getenv("WAE_TILE_WCAP")) : 608;
+                const int wcap = getenv("WAE_TILE_WCAP1") ? atoi(getenv("WAE_TILE_WCAP1")) : 608;
                 const int tile_r = getenv("WAE_TILE_RESTRICT") ? atoi(getenv("WAE_TILE_RESTRICT")) : 1;
                 if (tile_r) build_restriction_tiles(X, lv[0].R, wcap, st);
             }

@@ -296,6 +296,7 @@ TileGroupHost build_tile_group(const std::vector<const CsrZ *> &mats, bool is_re
     const size_t total = (size_t)T.sptr.back();
     T.sidx.assign(total, 0);
     T.svals.assign(total * wpe, 0.0);
+    T.dslot.assign((size_t)row_ptr.back(), (unsigned short)0xFFFF);
     static const bool parity_sort = !(getenv("WAE_TILE_PARITY") && atoi(getenv("WAE_TILE_PARITY")) == 0);
     std::vector<std::pair<int, int>> ent, ev, od;
     for (size_t t = 0; t < nt; ++t) {
@@ -311,7 +312,10 @@ TileGroupHost build_tile_group(const std::vector<const CsrZ *> &mats, bool is_re
             // lpr = 4: the partner of lane (row i, q) is lane (row i', q) of a row whose number differs in bit 1 (kernel: rot);
             // rows with that bit clear list their even-slot entries first, the others their odd-slot entries.
             ent.clear();
-            for (int p = A.ptr[r]; p < A.ptr[r + 1]; ++p) ent.emplace_back((int)(std::lower_bound(wc, wc + wn, A.col[p]) - wc), p);
+            for (int p = A.ptr[r]; p < A.ptr[r + 1]; ++p) {
+                ent.emplace_back((int)(std::lower_bound(wc, wc + wn, A.col[p]) - wc), p);
+                if (A.col[p] == r && A.n == A.m) T.dslot[(size_t)r] = (unsigned short)ent.back().first;
+            }
             if (parity_sort && lpr == 2) {
                 ev.clear(); od.clear();
                 for (const auto &e : ent) (e.first & 1 ? od : ev).push_back(e);

@@ -33,6 +33,7 @@ struct TileGroupHost {
     std::vector<int> sptr;                 // TILE_SLICES*ntiles + 1 entry offsets (multiples of 64)
     std::vector<unsigned short> sidx;      // local column index per entry
     std::vector<double> svals;             // [entry][nplanes] doubles (real group) or [entry][nplanes][2]
+    std::vector<unsigned short> dslot;     // per row: window slot of the row's own column, 0xFFFF if the row has no such entry
 };
 struct TileWindows {
     std::vector<int> win_ptr, win_cols;    // per tile: sorted distinct (new) columns of all groups

@@ -75,11 +75,13 @@ struct TileGroupDev {
     const int *sptr;                // 8*ntiles+1: entry offset of the slice of (tile, wavefront): 64/lpr rows, lpr lanes per row
     const unsigned short *sidx;     // window-local column of every entry ([k][lane] inside a slice)
     const void *svals;              // [entry][nplanes] double or double2, same value layout as GroupDev::vals
+    const unsigned short *dslot;    // [rows]: window slot of the row's own column (its diagonal entry), 0xFFFF if it has none; may be null
 };
 struct TileDev {
     int ntiles;
     int wmax;                       // largest window
     int lpr;                        // lanes per row: 2 (tiles of up to 256 rows) or 4 (up to 128 rows)
+    int nbuf;                       // window buffers in LDS: 2 (windows up to 608 rows) or 3 (up to 400: two windows in flight; lpr = 2 only)
     int unit;                       // the operator is plane 0 itself (coefficients 1, 0: the restriction), no coefficient table is read
     const int *row_ptr;             // ntiles+1
     const int *win_ptr;             // ntiles+1
@@ -160,7 +162,7 @@ struct TileStore {                  // device arrays behind a TileDev
     DevBuf<int> row_ptr, win_ptr, win_cols;
     DevBuf<unsigned> counters;
     DevBuf<int> sptr;
-    DevBuf<unsigned short> sidx;
+    DevBuf<unsigned short> sidx, dslot;
     DevBuf<double> svals;
     DevBuf<int> side_of_row, side_ptr, side_col, side_slot;
     DevBuf<cplx> side_val, side_acc;
