@@ -242,8 +242,9 @@ def main():
             if tj.get("preset") == args.preset and tj.get("r") == rb:
                 traffic = tj["traffic_bytes"]
         tiled = os.environ.get("WAE_SPMV_TILE", "1") != "0" and os.environ.get("WAE_REORDER", "1") != "0"
-        roof = {"bound": "hbm", "kernel": ("spmv_tile_kernel<true>" if tiled else "spmv_lds_kernel<4>")
-                                          + " (fused multi-term complex CSR SpMV of the fine level, r columns per launch)",
+        roof = {"bound": "hbm", "kernel": ("spmv_tile_kernel<true, 2, 2> (+ spmv_side_kernel: the rows of the boundary / flame terms, ~5 % of the time)"
+                                           if tiled else "spmv_lds_kernel<4>")
+                                          + ": one fused multi-term complex CSR operator product of the fine level, r columns",
                 "achieved": abytes / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": abytes / ms / 1e6 / HBM_PEAK_GBS, "traffic": traffic,
                 "r": rb, "us_per_launch": ms * 1e3, "algorithmic_bytes": int(abytes),

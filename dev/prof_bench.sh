@@ -14,4 +14,4 @@ print("total kernel s %.3f" % (tot / 1e9))
 for r in rows[:18]:
     print("%-44s %6s calls %9.1f ms avg %8.1f us %5.1f%%" % (r["Name"].split("(")[0].replace("void ", "")[:44], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
 PY
-tail -1 $OUT/log.txt | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('value', d['value'], 'ms_per_step', d['ms_per_step'], 'iters', d['solver']['iters_total'])"
+grep "^{" $OUT/log.txt | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('value', d['value'], 'ms_per_step', d['ms_per_step'], 'iters', d['solver']['iters_total'])"

@@ -418,28 +418,27 @@ __global__ __launch_bounds__(256) void spmv_side_kernel(TileDev td, int npl, int
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Tile kernel for batch widths >= 8 on a reordered fine-level operator (tiles.h).
+// Tile kernel for batch widths >= 8 on an operator whose rows have been renumbered into tiles (tiles.h): the fine level (LPR = 2
+// lanes per row), the first coarse level and the fine-to-coarse restriction (LPR = 4).  DESIGN.md 4b tells how it got here.
 //
-// One PERSISTENT workgroup of 8 wavefronts = one tile (<= 256 consecutive rows forming a compact brick of the mesh graph); it
-// walks the tile's chunks of 8 batch columns.
-//  * The matrix slice of its rows is loaded ONCE into registers and serves every chunk.  Wavefront w owns rows 32 w .. 32 w + 31;
-//    the two lanes of a row split its entries (lane 2 i + h: entries h, h + 2, ...; 8 register-resident entries per lane cover
-//    16 per row, longer rows stream the rest).
-//  * The tile's window -- the ~2 x 256 distinct X rows its rows touch, 128 B each per chunk -- is gathered into LDS by LDS-DMA
-//    (global_load_lds_dwordx4: the per-lane source address makes it a row gather, no VGPR round trip).  Two window buffers
-//    alternate: the gather of chunk c+1 is issued piece by piece between the entries of chunk c.
+// PERSISTENT workgroups of 8 wavefronts, one per CU; each draws tiles (<= 512 / LPR consecutive rows forming a compact brick of
+// the mesh graph) and walks a tile's chunks of 8 batch columns.
+//  * The matrix slice of a tile's rows is loaded ONCE into registers and serves every chunk: wavefront w owns rows
+//    (64 / LPR) w .. (64 / LPR)(w + 1) - 1; the LPR lanes of a row split its entries (lane LPR i + h: entries h, h + LPR, ...;
+//    8 / 12 register-resident entries per lane cover 16 / 48 per row, longer rows stream the rest one entry ahead).
+//  * The tile's window -- the distinct X rows its rows touch (~2 x 256 on the fine level), 128 B each per chunk -- is gathered
+//    into LDS by LDS-DMA (global_load_lds_dwordx4: the per-lane source address makes it a row gather, no VGPR round trip).
+//    NBUF window buffers form a ring: the gather for the chunk NBUF - 1 ahead is issued piece by piece between the entries of
+//    the current chunk.
 //  * Compute: per entry one coefficient product and 8 x (ds_read_b128 + complex FMA), software-pipelined by hand (operands of
-//    entry u+1 requested before the FMAs of entry u).  Both lanes of a row read the columns in the rotated order (s + i) mod 8,
-//    so that the 16 lanes a ds_read_b128 serves per LDS cycle (8 lane pairs) spread over all bank groups; the two lanes of a
-//    pair share a group only if their window slots have equal parity, which the entry order avoids (tiles.cpp).
-//  * The two partial sums of a row meet through a DPP lane swap -- no LDS staging, no second barrier -- and each lane writes
-//    four of the row's eight results (the two lanes of a row complete one 128-B segment): ONE barrier per chunk, and the
-//    stores of chunk c drain under the compute of chunk c+1.
+//    entry u+1 requested before the FMAs of entry u).  The lanes read the columns in a rotated order so that the 16 lanes a
+//    ds_read_b128 serves per LDS cycle spread over all bank groups; partner lanes share a group only if their window slots
+//    have equal parity, which the entry order avoids (tiles.cpp).
+//  * The partial sums of a row meet through DPP quad permutations -- no LDS staging, no second barrier -- and each lane writes
+//    8 / LPR of the row's eight results (the lanes of a row complete one 128-B segment): ONE barrier per chunk, and the stores
+//    of chunk c drain under the compute of chunk c+1.
+//  * The rows of the other pattern groups come from spmv_side_kernel (above).
 // UNI: the 8 columns of a chunk belong to one system (columns per system a multiple of 8): one coefficient set per chunk.
-// History (C3, r = 64): one workgroup per (tile, chunk) 1805 us; persistent + matrix in registers, 4 wavefronts 1699 us;
-// 8 wavefronts with the entries split between wavefronts w and w+4 and the partial sums staged through LDS 984 us (three
-// barriers per chunk; hipcc put s_waitcnt vmcnt(0) between the builtin LDS-DMA and the next ds_read of the OTHER buffer, and
-// issued half of the ds_reads two at a time); asm LDS-DMA + pipelined entries 872 us; this version: see DESIGN.md 4b.
 // ---------------------------------------------------------------------------------------------------
 #ifdef WAE_TILE_STAMPS
 __device__ unsigned long long wae_tile_stamps[8 * 64 + 8]; // diagnostic build only: s_memtime at the phase boundaries of one workgroup
