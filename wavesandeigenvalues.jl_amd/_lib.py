@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libwaehip.so")
+LIB_PATH = os.environ.get("WAE_LIB_PATH") or os.path.join(_HERE, "csrc", "libwaehip.so")     # (WAE_LIB_PATH: an A/B build of the library)
 
 WAE_OK, WAE_WARN_MAXITER, WAE_WARN_STAGNATION = 0, 1, 2
 WAE_ERR_INVALID, WAE_ERR_BREAKDOWN, WAE_ERR_EIGS, WAE_ERR_NAN, WAE_ERR_HIP = -1, -2, -3, -4, -5

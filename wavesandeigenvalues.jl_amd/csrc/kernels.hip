@@ -6,6 +6,7 @@
 // Operators are sums of "planes" (term matrices) grouped by shared sparsity pattern: a group stores
 // rowptr/col once and its planes' values interleaved per nonzero ([nnz][nplanes], real planes as 8-B doubles),
 // so the fused multi-term SpMV reads each index once and all term values of that nonzero in one load.
+#include <mutex>
 #include "wae_internal.h"
 
 #include <cstdlib>
@@ -18,6 +19,17 @@ __device__ __forceinline__ cplx cconj(cplx a) { return cplx{a.x, -a.y}; }
 __device__ __forceinline__ void cfma(cplx &acc, cplx a, cplx b) {
     acc.x = fma(a.x, b.x, acc.x); acc.x = fma(-a.y, b.y, acc.x);
     acc.y = fma(a.x, b.y, acc.y); acc.y = fma(a.y, b.x, acc.y);
+}
+// streaming (non-temporal) read of a vector entry: the Krylov basis is read once per kernel and is far larger than any cache
+// (1.1 % of a 1M-DoF pass, paired runs; the same hint on w and on the store of the update: nothing measurable)
+typedef double dbl2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cplx stream_load(const cplx *p) {
+#ifndef WAE_NO_NT_GS
+    const dbl2v v = __builtin_nontemporal_load((const dbl2v *)p);
+    return cplx{v.x, v.y};
+#else
+    return *p;
+#endif
 }
 __device__ __forceinline__ cplx cdiv(cplx a, cplx b) {
     double s = 1.0 / (b.x * b.x + b.y * b.y);
@@ -1000,7 +1012,12 @@ extern "C" int wae_debug_tile_stamps(unsigned long long *out) {
 #endif
 static void launch_spmv_tile(const OpDev &op, const TileDev &td, const cplx *pc, int cps, const cplx *X, cplx *Y, const cplx *B, double jac_w,
                              int nb, int mode, hipStream_t st, const unsigned char *cmask) {
-    static bool attr_set = false;
+    // (the opt-in to more than 64 KB of dynamic LDS is a property of the function ON A DEVICE: one process may drive several --
+    // wae_beyn_moments_mgpu runs a host thread per device -- so it is kept per device, under a lock)
+    static std::mutex attr_mutex;
+    static bool attr_done[64] = {false};
+    int dev_now = 0;
+    HIP_CHECK(hipGetDevice(&dev_now));
     const int nbuf = td.nbuf == 3 && td.lpr == 2 ? 3 : 2;
     const size_t wslots = (size_t)((td.wmax + 7) & ~7);
     const int nch8 = ((nb + 7) / 8) * 8;
@@ -1008,6 +1025,8 @@ static void launch_spmv_tile(const OpDev &op, const TileDev &td, const cplx *pc,
     const int spc_all = shm <= 160 * 1024;                   // (+ 16: the word through which a workgroup learns its next tile)
     if (!spc_all) shm = nbuf * wslots * 8 * sizeof(cplx) + (size_t)8 * op.nplanes_total * sizeof(cplx) + 16;   // ... or chunk by chunk
     if (shm > 160 * 1024) throw WaeError(WAE_ERR_INVALID, "tile windows do not fit LDS (WAE_TILE_WCAP too large)");
+    std::unique_lock<std::mutex> attr_lock(attr_mutex);
+    bool &attr_set = attr_done[dev_now & 63];
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<true, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<false, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1017,14 +1036,14 @@ static void launch_spmv_tile(const OpDev &op, const TileDev &td, const cplx *pc,
         HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<false, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    attr_lock.unlock();
     // Persistent workgroups, one per CU (157 KB of LDS each: the hardware cannot place two on a CU), walking the tiles of
     // their XCD.  With fewer tiles than CUs the chunks of a tile are shared out between csplit workgroups.  (Sharing them out
     // as soon as a CU had fewer than 8 tiles was measured and is slower -- 200k DoF, 780 tiles: 229 -> 259 us: the matrix
     // slice is re-loaded and the window pipeline restarts per part.)
-    static int ncu = 0;
+    static int ncu = 0;                                      // (same for every device of a node)
     if (!ncu) {
-        int dev = 0;
-        HIP_CHECK(hipGetDevice(&dev));
+        const int dev = dev_now;
         HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
         if (getenv("WAE_TILE_GRID")) ncu = atoi(getenv("WAE_TILE_GRID"));
         ncu = ncu < 8 ? 8 : ncu & ~7;
@@ -1454,7 +1473,7 @@ __global__ __launch_bounds__(256) void dots_kernel(const cplx *__restrict__ V, s
 #pragma unroll
             for (int i = 0; i < MAXV; ++i) {
                 if (i < nv) {
-                    const cplx v = V[(size_t)i * stride + e];
+                    const cplx v = stream_load(V + (size_t)i * stride + e);
                     acc[i].x += v.x * w.x + v.y * w.y;
                     acc[i].y += v.x * w.y - v.y * w.x;
                 }
@@ -1668,7 +1687,7 @@ __global__ __launch_bounds__(256) void axpy_neg_kernel(const cplx *__restrict__ 
         for (; i + AXU <= nv; i += AXU) {
             cplx v[AXU];
 #pragma unroll
-            for (int u = 0; u < AXU; ++u) v[u] = V[(size_t)(i + u) * stride + e];
+            for (int u = 0; u < AXU; ++u) v[u] = stream_load(V + (size_t)(i + u) * stride + e);
 #pragma unroll
             for (int u = 0; u < AXU; ++u) {
                 const cplx c = hs[(i + u) * nb + b];
@@ -1678,7 +1697,7 @@ __global__ __launch_bounds__(256) void axpy_neg_kernel(const cplx *__restrict__ 
         }
         for (; i < nv; ++i) {
             const cplx c = hs[i * nb + b];
-            const cplx v = V[(size_t)i * stride + e];
+            const cplx v = stream_load(V + (size_t)i * stride + e);
             acc.x += c.x * v.x - c.y * v.y;
             acc.y += c.x * v.y + c.y * v.x;
         }
