@@ -601,7 +601,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
             if (u < n0) { const int e = s00 + lane + 64 * u; ixr[u] = si[e]; avr[u] = v2[e]; }   // (uniform; absent entries stay (0, 0.0))
         const int lr = wv * RPW + lane / LPR;
         side = (td.nside && lr < nrows) ? td.side_of_row[r0 + lr] : -1;
-        dslot = (NBUF > 2 && T0.dslot && lr < nrows) ? T0.dslot[r0 + lr] : 0xFFFFu;
+        dslot = (T0.dslot && lr < nrows) ? T0.dslot[r0 + lr] : 0xFFFFu;
     };
     // The LDS-DMA is issued from an asm statement, NOT through __builtin_amdgcn_global_load_lds: hipcc counts the builtin as a
     // pending write to LDS and puts s_waitcnt vmcnt(0) before the next ds_read of ANY address -- the wavefront that had just
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
                 const int b = col0 + c < nb ? col0 + c : nb - 1;
                 const size_t e = (size_t)row * nb + b;
                 bv[j] = need_b ? B[e] : cplx{0.0, 0.0};
-                xv[j] = (mode == MODE_JAC && (NBUF == 2 || dslot == 0xFFFFu)) ? X[e] : cplx{0.0, 0.0};
+                xv[j] = (mode == MODE_JAC && dslot == 0xFFFFu) ? X[e] : cplx{0.0, 0.0};       // (normally taken from the window, below)
             }
             if (UNI && need_d) {                             // one diagonal per row and chunk
                 dgu = cplx{0.0, 0.0};
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
         // Epilogue.  (Two buffers: loads first, then the wait for this wavefront's pieces of the next window, which sits before the
         // stores: those drain under the next chunk.)
         if (NBUF == 2) epilogue_loads();
-        if (NBUF > 2 && mode == MODE_JAC && dslot != 0xFFFFu) {      // the row's own X: it is in the window
+        if (mode == MODE_JAC && dslot != 0xFFFFu) {          // the row's own X: it is in the window (1 GB per sweep not read again)
 #pragma unroll
             for (int j = 0; j < NOUT; ++j) xv[j] = win[dslot * 8 + ((rot_out + j) & 7)];
         }
