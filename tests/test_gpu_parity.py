@@ -938,15 +938,17 @@ def test_long_rows_are_split_off_and_summed_by_a_workgroup(monkeypatch):
 def test_coarse_level_and_restriction_tiles_agree_with_the_untiled_hierarchy(monkeypatch):
     """wae_solver_setup renumbers level 1 into tiles (4 lanes per row) and cuts the fine-to-coarse restriction into tiles as well; the
     numbering of a coarse level is invisible at the boundary.  A/B on the 20k-DoF annulus (level 1: ~2 400 unknowns, ~40 tiles;
-    widths 8, 16 and 24 columns take the tile kernels, a partial last chunk included): the solutions agree with each other and
-    with a sparse LU, and the iteration counts stay within two of each other."""
+    widths 8, 16 and 21 columns take the tile kernels, a partial last chunk included): the solutions agree with each other and
+    with a sparse LU, and the iteration counts stay within two of each other.  A third configuration runs the fine level on the
+    three-buffer form of the tile kernel (WAE_TILE_NBUF=3: windows of 400 rows, two gathers in flight; slower, kept as an option)."""
     import scipy.sparse.linalg as spla
     from wae_amd.helmholtz.family import annulus_family
     rng = np.random.default_rng(5)
     z = 2 * np.pi * (430 + 15j)
     sols, iters = {}, {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("WAE_TILE_LEVEL1", flag)
+    for flag in ("1", "0", "3buf"):
+        monkeypatch.setenv("WAE_TILE_LEVEL1", "0" if flag == "0" else "1")
+        monkeypatch.setenv("WAE_TILE_NBUF", "3" if flag == "3buf" else "2")
         L, pb = annulus_family("20k", tau=2e-4)
         T, p = pb["terms"], pb["params"]
         d = pb["d"]
@@ -962,5 +964,6 @@ def test_coarse_level_and_restriction_tiles_agree_with_the_untiled_hierarchy(mon
             iters[(flag, r)] = L.device().last_info["iters_max"]
         L._drop_device()
     for r in Bs:
-        assert relerr(sols[("1", r)], sols[("0", r)]) < 1e-9
-        assert abs(iters[("1", r)] - iters[("0", r)]) <= 2
+        for other in ("0", "3buf"):
+            assert relerr(sols[("1", r)], sols[(other, r)]) < 1e-9
+            assert abs(iters[("1", r)] - iters[(other, r)]) <= 2

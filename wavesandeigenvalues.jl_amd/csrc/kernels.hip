@@ -959,11 +959,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
             for (int j = 0; j < NOUT; ++j) {
                 const int b = col0 + ((rot_out + j) & 7);
                 if (b >= nb) continue;
-#ifdef TILE_ABL_BLOCKED
-                const size_t e = ((size_t)ch * op.n + row) * 8 + (b & 7);
-#else
                 const size_t e = (size_t)row * nb + b;
-#endif
                 Y[e] = out[j];
                 if (mode == MODE_AX_J0) const_cast<cplx *>(B)[e] = b2[j];
             }

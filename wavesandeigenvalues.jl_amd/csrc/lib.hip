@@ -1478,8 +1478,8 @@ int wae_family_create(wae_family **out, int64_t d, int32_t T, int32_t index_byte
             // fine level: two window buffers of 608 rows x 128 B.  WAE_TILE_NBUF=3: three of 400 (two windows in flight while a
             // third is read) -- measured slower, 966 vs 733 us at 1M unknowns and 64 columns: a chunk costs a wavefront the same
             // ~10 k cycles whether its tile has 174 rows or 256 (lane = row), the gather was not what it waited for.
-            static const int nbuf0 = getenv("WAE_TILE_NBUF") ? atoi(getenv("WAE_TILE_NBUF")) : 2;
-            static const int wcap = getenv("WAE_TILE_WCAP") ? atoi(getenv("WAE_TILE_WCAP")) : (nbuf0 == 3 ? 400 : 608);
+            const int nbuf0 = getenv("WAE_TILE_NBUF") ? atoi(getenv("WAE_TILE_NBUF")) : 2;          // (read per call: the tests switch it)
+            const int wcap = getenv("WAE_TILE_WCAP") ? atoi(getenv("WAE_TILE_WCAP")) : (nbuf0 == 3 ? 400 : 608);
             static const int thick = getenv("WAE_TILE_THICK") ? atoi(getenv("WAE_TILE_THICK")) : 6;
             const double tq0 = now_s();
             TilePlan plan = plan_tiles(union_pattern(h->planes0), 256, wcap, thick);
