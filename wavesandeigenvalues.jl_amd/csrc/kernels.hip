@@ -505,34 +505,39 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
     const int rot = LPR == 2 ? (lane >> 1) & 7 : (((lane >> 2) & 1) + 2 * sub) & 7;
     const int rot_out = LPR == 2 ? (rot + 4 * sub) & 7 : rot;    // column of this lane's first result
     // Work list.  The workgroups are PERSISTENT: the grid has one per CU, dealt round-robin over the 8 XCDs by the hardware.
-    // XCD k owns the k-th contiguous eighth of the (virtual) tiles; its workgroups take the first of them statically and then
-    // draw the next position of the share from a counter (td.counters[k]), so that they walk the share side by side --
+    // XCD k owns the k-th contiguous eighth of the tiles (its "share"); its workgroups take the first positions of the share
+    // statically and then draw the next position from a counter (td.counters[k]), so that they walk the share side by side --
     // neighbouring tiles (shared halo rows) are in flight on one L2 at about the same time -- at their own pace: the time per
-    // chunk differs by up to 1.6 x between CUs and XCDs (measured, identical work).  A workgroup whose share is used up draws
-    // from the other shares.  A virtual tile = (tile, part): with fewer tiles than CUs (csplit > 1) a tile's chunks are shared
-    // out between csplit workgroups.  The last workgroup to leave zeroes the counters for the next launch (launches that use
-    // one operator are ordered by its stream).
-    const int nvt = td.ntiles * csplit;
-    const int vpx = (nvt + 7) >> 3;
+    // chunk differs between CUs (measured, identical work).  A workgroup whose share is used up draws from the other shares.
+    // The LAST tiles of a share -- as many as the XCD has workgroups -- are handed out in `csplit` parts of their chunks each, so
+    // that the launch ends within a fraction of a tile's time on every CU (200k unknowns: three tiles per CU on average, four
+    // on some); with fewer tiles than CUs that is all of them.  A work item = (share, position) -> (tile, part).  The last
+    // workgroup to leave zeroes the counters for the next launch (launches that use one operator are ordered by its stream).
+    const int tpx = (td.ntiles + 7) >> 3;
     const int xcd = (int)(blockIdx.x & 7u), gpx = (int)(gridDim.x >> 3);
     auto next_active = [&](int c, int end) { while (c < end && cmask && !cmask[c]) ++c; return c; };
-    auto decode = [&](int vt, int &tile_, int &ch_, int &end_) {      // -> has an active chunk
-        tile_ = vt / csplit;
-        const int part = vt - tile_ * csplit;
-        end_ = (part + 1) * nch_all / csplit;
-        ch_ = next_active(part * nch_all / csplit, end_);
+    auto share_tiles = [&](int x) { const int left = td.ntiles - x * tpx; return left < tpx ? (left > 0 ? left : 0) : tpx; };
+    auto share_split = [&](int x) { const int n = share_tiles(x); return csplit > 1 ? (n < gpx ? n : gpx) : 0; };   // tiles handed out in parts
+    auto share_size = [&](int x) { return share_tiles(x) + share_split(x) * (csplit - 1); };
+    auto decode = [&](int item, int &tile_, int &ch_, int &end_) {    // item = share << 24 | position;  -> has an active chunk
+        const int x = item >> 24, p = item & 0xFFFFFF;
+        const int nfull = share_tiles(x) - share_split(x);
+        int part = 0, parts = 1;
+        if (p < nfull) tile_ = x * tpx + p;
+        else { const int q = p - nfull; tile_ = x * tpx + nfull + q / csplit; part = q - (q / csplit) * csplit; parts = csplit; }
+        end_ = (part + 1) * nch_all / parts;
+        ch_ = next_active(part * nch_all / parts, end_);
         return ch_ < end_;
     };
-    auto share_size = [&](int x) { const int left = nvt - x * vpx; return left < vpx ? (left > 0 ? left : 0) : vpx; };
-    auto draw = [&](int pend) {                              // (one thread) next virtual tile with work, or -1; pend: position already
+    auto draw = [&](int pend) {                              // (one thread) next work item with work, or -1; pend: position already
         int t_, c_, e_;                                      // drawn from the own share, or -1
-        if (pend >= 0 && pend < share_size(xcd) && decode(xcd * vpx + pend, t_, c_, e_)) return xcd * vpx + pend;
+        if (pend >= 0 && pend < share_size(xcd) && decode(xcd << 24 | pend, t_, c_, e_)) return xcd << 24 | pend;
         for (int a = 0; a < 8; ++a) {
             const int x2 = (xcd + a) & 7, lim = share_size(x2);
             while (gpx < lim) {
                 const int p = gpx + (int)atomicAdd(td.counters + x2, 1u);
                 if (p >= lim) break;
-                if (decode(x2 * vpx + p, t_, c_, e_)) return x2 * vpx + p;
+                if (decode(x2 << 24 | p, t_, c_, e_)) return x2 << 24 | p;
             }
         }
         return -1;
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
     int tile, ch, ch_end;
     {
         const int p0 = (int)(blockIdx.x >> 3);
-        bool ok = p0 < share_size(xcd) && decode(xcd * vpx + p0, tile, ch, ch_end);
+        bool ok = p0 < share_size(xcd) && decode(xcd << 24 | p0, tile, ch, ch_end);
         if (!ok) {                                           // (no static tile, or none of its chunks active)
             if (tid == 0) *vt_slot = draw(-1);
             __syncthreads();
@@ -1045,11 +1050,17 @@ static void launch_spmv_tile(const OpDev &op, const TileDev &td, const cplx *pc,
         ncu = ncu < 8 ? 8 : ncu & ~7;
     }
     const int nchunks = (nb + 7) / 8;
-    int csplit = (int)((ncu + td.ntiles - 1) / td.ntiles);
+    // parts in which the last tiles of every XCD's share are handed out (kernel: "Work list"): with fewer tiles than CUs all of
+    // them, so that every CU has work; otherwise four parts bring the end of the launch within a quarter of a tile on every CU
+    // (parts of at least two chunks: a one-chunk part cannot prefetch its successor.  Measured, r = 64: 200k unknowns 210 -> 192 us,
+    // 1M unknowns 764 -> 755 us)
+    int csplit = td.ntiles < ncu ? (int)((ncu + td.ntiles - 1) / td.ntiles)
+                                 : std::min(getenv("WAE_TILE_TAIL") ? atoi(getenv("WAE_TILE_TAIL")) : 4, std::max(1, nchunks / 2));
     if (csplit > nchunks) csplit = nchunks;
     if (csplit < 1) csplit = 1;
-    const unsigned vpx = (unsigned)((td.ntiles * csplit + 7) / 8);
-    const dim3 grid(8u * std::min(vpx, (unsigned)(ncu / 8)));
+    const unsigned tpx = (unsigned)((td.ntiles + 7) / 8);
+    const unsigned units = std::min<unsigned>(tpx, (unsigned)(ncu / 8)) * (unsigned)csplit + (tpx > (unsigned)(ncu / 8) ? tpx - (unsigned)(ncu / 8) : 0u);
+    const dim3 grid(8u * std::min(units, (unsigned)(ncu / 8)));
     if (td.nside) {
         if (nb > 256) throw WaeError(WAE_ERR_INVALID, "launch_spmv: batch wider than 256 columns");
         hipLaunchKernelGGL(spmv_side_kernel, dim3((unsigned)((td.nside + 31) / 32), (unsigned)nchunks), dim3(256), 0, st, td, op.nplanes_total,
