@@ -666,11 +666,9 @@ static int gmres_wide(wae_family *h, const Batch &bt, const cplx *B, cplx *X, do
     S.relres = h->gs_relres.p; S.bnorm = h->gs_bnorm.p; S.hist = h->gs_hist.p; S.rescale = h->gs_rescale.p; S.cmask = h->cmask.p;
     HIP_CHECK(hipMemsetAsync(h->gs_int.p, 0, ((size_t)5 * nb + 4) * sizeof(int), st));
     if (!have_x0) launch_fill_zero(X, vec, st);
-    {
-        const cplx *zb = vcycle(h, bt, 0, B);
-        launch_norms(zb, n, nb, h->partial.p, h->hdev.p, st);
-    }
-    HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
+    cplx *const zb = vcycle(h, bt, 0, B);                    // M^-1 b: its norm scales the stopping test; from a zero guess it is also
+    launch_norms(zb, n, nb, h->partial.p, h->hdev.p, st);    // the first preconditioned residual (nothing touches the V-cycle's
+    HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, nb * sizeof(cplx), hipMemcpyDeviceToHost, st));   // buffers until then)
     HIP_CHECK(hipStreamSynchronize(st));
     std::vector<double> bnorm(nb), relres(nb, 0.0);
     std::vector<int> iters(nb, 0), hostint((size_t)5 * nb + 4);
@@ -688,7 +686,7 @@ static int gmres_wide(wae_family *h, const Batch &bt, const cplx *B, cplx *X, do
     while (true) {
         cplx *z0;
         if (first) {
-            z0 = vcycle(h, bt, 0, B);
+            z0 = zb;
         } else {
             launch_spmv(A, pc, bt.cps, X, h->W.p, B, 0.0, nb, MODE_RES, st);
             z0 = vcycle(h, bt, 0, h->W.p);
@@ -846,10 +844,8 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
     // have_x0: X already holds an initial guess (the Galerkin projection on earlier solutions, beyn_moments_rb); the
     // stopping test stays relative to ||M^-1 b||, so the answer is the same as from a zero guess, only cheaper
     if (!have_x0) launch_fill_zero(X, vec, st);
-    {
-        const cplx *zb = vcycle(h, bt, 0, B);
-        launch_norms(zb, n, nb, h->partial.p, h->hdev.p, st);
-    }
+    cplx *const zb0 = vcycle(h, bt, 0, B);                   // M^-1 b: scales the stopping test; from a zero guess (and without a guess
+    launch_norms(zb0, n, nb, h->partial.p, h->hdev.p, st);   // direction, whose set-up runs further V-cycles) also the first residual
     HIP_CHECK(hipMemcpyAsync(hp, h->hdev.p, nb * sizeof(cplx), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     std::vector<double> bnorm(nb), relres(nb, 0.0);
@@ -924,7 +920,7 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
     while (true) {
         cplx *z0;
         if (first) {
-            z0 = vcycle(h, bt, 0, B);
+            z0 = (guess_dir == nullptr) ? zb0 : vcycle(h, bt, 0, B);       // (with a guess direction the buffers have been used again)
         } else {
             launch_spmv(A, pc, bt.cps, X, h->W.p, B, 0.0, nb, MODE_RES, st);
             z0 = vcycle(h, bt, 0, h->W.p);
