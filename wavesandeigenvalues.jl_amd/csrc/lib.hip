@@ -77,7 +77,10 @@ struct RbState {                     // snapshot basis of wae_beyn_moments_rb (o
     std::vector<zc> Hk;              // Hk[ki][(s*cap + i)*l + c] = q_i^H A_k q_s   (column c's basis)
     std::vector<zc> g;               // g[i*l + c] = q_i^H v_c
     DevBuf<cplx> W, Vi, hb, alpha, alpha2, ycoef;   // W_k = A_k Q (resident), probe columns interleaved, small scratch
+    std::future<void> w_job;         // W (20 GB at 1M unknowns: ~0.4 s of hipMalloc) is mapped on a helper thread while the first
+    void wait_w() { if (w_job.valid()) w_job.get(); }       // snapshot systems are solved; whoever touches W waits for it here
     bool vi_valid = false;           // Vi holds the probe matrix the basis was started with (false after an import)
+    ~RbState() { if (w_job.valid()) w_job.wait(); }
 };
 
 struct wae_family {
@@ -1257,7 +1260,16 @@ static void rb_reset(wae_family *h, cplx *Q, int cap, int l, const double *table
         if (used) R.kact.push_back(k);
     }
     const size_t vecl = (size_t)h->d * l;
-    if (R.W.n < R.kact.size() * (size_t)cap * vecl) R.W.alloc(R.kact.size() * (size_t)cap * vecl);
+    R.wait_w();
+    if (R.W.n < R.kact.size() * (size_t)cap * vecl) {
+        const size_t need = R.kact.size() * (size_t)cap * vecl;
+        const int dev = h->device;
+        RbState *Rp = &R;
+        R.w_job = std::async(std::launch::async, [Rp, need, dev]() {
+            HIP_CHECK(hipSetDevice(dev));
+            Rp->W.alloc(need);
+        });
+    }
     R.Hk.assign(R.kact.size() * (size_t)cap * cap * l, zc(0));
     R.g.assign((size_t)cap * l, zc(0));
     if (R.Vi.n < vecl) R.Vi.alloc(vecl);
@@ -1320,6 +1332,7 @@ static void rb_append_block(wae_family *h, int cnt, const std::vector<std::vecto
         for (int c = 0; c < l; ++c) R.g[(size_t)(S + j) * l + c] = zc(hh[(size_t)j * l + c].x, hh[(size_t)j * l + c].y);
     // (4) projected terms: new columns (all rows) and new rows (old columns)
     for (size_t ki = 0; ki < R.kact.size(); ++ki) {
+        R.wait_w();
         cplx *Wk = R.W.p + ki * (size_t)cap * vecl;
         cplx *wn = Wk + (size_t)S * vecl;
         upload_pc(h, pck[ki]);
