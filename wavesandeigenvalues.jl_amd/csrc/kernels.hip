@@ -7,6 +7,7 @@
 // rowptr/col once and its planes' values interleaved per nonzero ([nnz][nplanes], real planes as 8-B doubles),
 // so the fused multi-term SpMV reads each index once and all term values of that nonzero in one load.
 #include <mutex>
+#include <type_traits>
 #include "wae_internal.h"
 
 #include <cstdlib>
@@ -779,14 +780,21 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
         // memory operations complete in order, and the compiler's wait for a load retires everything older with it).  The
         // right-hand side goes straight into the accumulators (positions this lane will keep, sign such that they end up holding
         // A x - b, or A x + b for MODE_ADD): no registers of its own.
-        cplx acc[8];
+        // SPLIT (the columns of a chunk belong to several systems -- a rank's share of the probe columns in a multi-GPU pass, the
+        // Newton-type solvers): the two planes are accumulated separately, acc = M-plane x X and acc2 = K-plane x X, real times
+        // complex, and the systems' coefficients are applied once per chunk in the epilogue.  (Forming c0 m + c1 k per entry and
+        // COLUMN cost 16 more LDS reads and 28 more FMAs per entry: 1 150 us against 760 at 1M unknowns, 64 columns.)
+        constexpr bool SPLIT = !UNI;
+        constexpr bool FOLD = NBUF > 2 && !SPLIT;            // the right-hand side starts out in the accumulators
+        cplx acc[8], acc2[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) acc[s] = cplx{0.0, 0.0};
+        for (int s = 0; s < 8; ++s) { acc[s] = cplx{0.0, 0.0}; acc2[s] = cplx{0.0, 0.0}; }
         if (NBUF > 2) {
             epilogue_loads();
             const double sb = mode == MODE_ADD ? 1.0 : -1.0;
 #pragma unroll
             for (int j = 0; j < NOUT; ++j) {
+                if (!FOLD) continue;
                 if (LPR == 2) {
                     acc[j] = cplx{sub == 0 ? sb * bv[j].x : 0.0, sub == 0 ? sb * bv[j].y : 0.0};
                     acc[j + 4] = cplx{sub == 1 ? sb * bv[j].x : 0.0, sub == 1 ? sb * bv[j].y : 0.0};
@@ -809,6 +817,79 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
         const int Wd = nt_ ? W_n : W;                        // rows of that window
         const int bt = (buf + NBUF - 1) % NBUF;              // its buffer
         TILE_STAMP(2);
+        // SPLIT on two lanes per row: two passes over the entries, four columns each (half the accumulators and operands at a time:
+        // with all eight columns the second set of accumulators did not fit the registers, 208 B of spill in the loop)
+        constexpr bool HALVES = SPLIT && LPR == 2;
+        cplx res[NOUT];
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) res[j] = cplx{0.0, 0.0};
+        if (HALVES && n0 > 0) {
+            const unsigned short *__restrict__ si = T0.sidx;
+            const double2 *__restrict__ v2 = (const double2 *)T0.svals;
+            auto half_pass = [&](auto HC) {
+                constexpr int H = decltype(HC)::value;
+                cplx p[4], q[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { p[s] = cplx{0.0, 0.0}; q[s] = cplx{0.0, 0.0}; }
+                auto fetch4 = [&](cplx (&x)[4], unsigned ix) {
+                    const cplx *wr = win + ix * 8;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) x[s] = wr[(4 * H + s + rot) & 7];
+                };
+                auto apply4 = [&](const cplx (&x)[4], double2 a) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        p[s].x = fma(a.x, x[s].x, p[s].x); p[s].y = fma(a.x, x[s].y, p[s].y);
+                        q[s].x = fma(a.y, x[s].x, q[s].x); q[s].y = fma(a.y, x[s].y, q[s].y);
+                    }
+                };
+                unsigned ixs = 0;
+                double2 avs = {0.0, 0.0};
+                if (n0 > KR) { const int e = s00 + lane + 64 * KR; ixs = si[e]; avs = v2[e]; }
+                cplx xa[4], xb[4];
+                fetch4(xa, ixr[0]);
+#pragma unroll
+                for (int u = 0; u < KR; ++u) {
+                    if (u + 1 < KR) { if (u & 1) fetch4(xa, ixr[u + 1]); else fetch4(xb, ixr[u + 1]); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (u & 1) apply4(xb, avr[u]); else apply4(xa, avr[u]);
+                    asm volatile("" : "+v"(p[0].x), "+v"(p[0].y), "+v"(p[1].x), "+v"(p[1].y), "+v"(p[2].x), "+v"(p[2].y), "+v"(p[3].x), "+v"(p[3].y),
+                                      "+v"(q[0].x), "+v"(q[0].y), "+v"(q[1].x), "+v"(q[1].y), "+v"(q[2].x), "+v"(q[2].y), "+v"(q[3].x), "+v"(q[3].y)
+                                 : : "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (H == 0 && more && 2 * u < NW) {
+                        issue_piece(Xn, bt, gr, Wd, 2 * u);
+                        if (2 * u + 1 < NW) issue_piece(Xn, bt, gr, Wd, 2 * u + 1);
+                    }
+                }
+                if (H == 0 && more) issue_rest(Xn, bt, nt_ ? w0_n : w0, Wd);
+#pragma unroll 1
+                for (int k = KR; k < n0; ++k) {
+                    const unsigned ixc = ixs;
+                    const double2 avc = avs;
+                    if (k + 1 < n0) { const int e = s00 + lane + 64 * (k + 1); ixs = si[e]; avs = v2[e]; }
+                    cplx x[4];
+                    fetch4(x, ixc);
+                    apply4(x, avc);
+                }
+                // the two lanes of a row meet; lane `sub` == H keeps these four columns: (rot_out + j) mod 8 for it
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const cplx P = {p[j].x + lane_quad<0xB1>(p[j].x), p[j].y + lane_quad<0xB1>(p[j].y)};
+                    const cplx Q = {q[j].x + lane_quad<0xB1>(q[j].x), q[j].y + lane_quad<0xB1>(q[j].y)};
+                    const int cs = (4 * H + j + rot) & 7;
+                    const cplx d0 = spc[cs * npl + G0.plane0], d1 = spc[cs * npl + G0.plane0 + 1];
+                    cplx t = {0.0, 0.0};
+                    cfma(t, d0, P);
+                    cfma(t, d1, Q);
+                    if (sub == H) res[j] = t;
+                }
+            };
+            half_pass(std::integral_constant<int, 0>{});
+            half_pass(std::integral_constant<int, 1>{});
+        } else if (HALVES) {
+            if (more) issue_window(ct, bt, gr, nt_ ? w0_n : w0, Wd);
+        } else
         if (n0 > 0) {                                        // the bulk group: mass + stiffness on one pattern, 16 B + 2 B per nonzero
             const cplx c0 = td.unit ? cplx{1.0, 0.0} : spc[G0.plane0], c1p = td.unit ? cplx{0.0, 0.0} : spc[G0.plane0 + 1];
             auto fetch = [&](cplx (&x)[8], unsigned ix) {    // the 8 operands of one entry: 8 ds_read_b128, rotated column order
@@ -817,15 +898,16 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
                 for (int s = 0; s < 8; ++s) x[s] = wr[(s + rot) & 7];
             };
             auto apply = [&](const cplx (&x)[8], double2 a) {
-                cplx m = {fma(c0.x, a.x, c1p.x * a.y), fma(c0.y, a.x, c1p.y * a.y)};
+                if (SPLIT) {
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    if (!UNI && !td.unit) {
-                        const int cs = (s + rot) & 7;
-                        const cplx d0 = spc[cs * npl + G0.plane0], d1 = spc[cs * npl + G0.plane0 + 1];
-                        m = cplx{fma(d0.x, a.x, d1.x * a.y), fma(d0.y, a.x, d1.y * a.y)};
+                    for (int s = 0; s < 8; ++s) {
+                        acc[s].x = fma(a.x, x[s].x, acc[s].x); acc[s].y = fma(a.x, x[s].y, acc[s].y);
+                        acc2[s].x = fma(a.y, x[s].x, acc2[s].x); acc2[s].y = fma(a.y, x[s].y, acc2[s].y);
                     }
-                    cfma(acc[s], m, x[s]);
+                } else {
+                    const cplx m = {fma(c0.x, a.x, c1p.x * a.y), fma(c0.y, a.x, c1p.y * a.y)};
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) cfma(acc[s], m, x[s]);
                 }
             };
             const unsigned short *__restrict__ si = T0.sidx;
@@ -850,6 +932,10 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
                 asm volatile("" : "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[1].x), "+v"(acc[1].y), "+v"(acc[2].x), "+v"(acc[2].y),
                                   "+v"(acc[3].x), "+v"(acc[3].y), "+v"(acc[4].x), "+v"(acc[4].y), "+v"(acc[5].x), "+v"(acc[5].y),
                                   "+v"(acc[6].x), "+v"(acc[6].y), "+v"(acc[7].x), "+v"(acc[7].y) : : "memory");
+                if (SPLIT)
+                    asm volatile("" : "+v"(acc2[0].x), "+v"(acc2[0].y), "+v"(acc2[1].x), "+v"(acc2[1].y), "+v"(acc2[2].x), "+v"(acc2[2].y),
+                                      "+v"(acc2[3].x), "+v"(acc2[3].y), "+v"(acc2[4].x), "+v"(acc2[4].y), "+v"(acc2[5].x), "+v"(acc2[5].y),
+                                      "+v"(acc2[6].x), "+v"(acc2[6].y), "+v"(acc2[7].x), "+v"(acc2[7].y) : : "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 if (more && 2 * u < NW) {                    // the window, two pieces per entry: all under way by the middle of the phase
                     issue_piece(Xn, bt, gr, Wd, 2 * u);
@@ -872,19 +958,34 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
         if (more) { if (NBUF > 2) wn2 = true; else wn1 = true; }
         TILE_STAMP(3);
         // the partial sums of a row meet; afterwards each lane keeps NOUT results: those of the columns (rot_out + j) mod 8
-        cplx res[NOUT];
-        if (LPR == 2) {
+        auto meet = [&](const cplx (&a)[8], cplx (&r)[NOUT]) {
+            if (LPR == 2) {
+#pragma unroll
+                for (int j = 0; j < NOUT; ++j) {
+                    const cplx lo = {a[j].x + lane_quad<0xB1>(a[j].x), a[j].y + lane_quad<0xB1>(a[j].y)};
+                    const cplx hi = {a[j + 4].x + lane_quad<0xB1>(a[j + 4].x), a[j + 4].y + lane_quad<0xB1>(a[j + 4].y)};
+                    r[j] = sub ? hi : lo;
+                }
+            } else {                                         // lane q takes positions j + 2 d from lane q - d, d = 0..3
+#pragma unroll
+                for (int j = 0; j < NOUT; ++j)
+                    r[j] = cplx{a[j].x + lane_quad<0x93>(a[j + 2].x) + lane_quad<0x4E>(a[j + 4].x) + lane_quad<0x39>(a[j + 6].x),
+                                a[j].y + lane_quad<0x93>(a[j + 2].y) + lane_quad<0x4E>(a[j + 4].y) + lane_quad<0x39>(a[j + 6].y)};
+            }
+        };
+        if (!HALVES) meet(acc, res);
+        if (SPLIT && !HALVES) {                              // res = c0 (M x) + c1 (K x), the coefficients of each column's system
+            cplx res2[NOUT];
+            meet(acc2, res2);
 #pragma unroll
             for (int j = 0; j < NOUT; ++j) {
-                const cplx lo = {acc[j].x + lane_quad<0xB1>(acc[j].x), acc[j].y + lane_quad<0xB1>(acc[j].y)};
-                const cplx hi = {acc[j + 4].x + lane_quad<0xB1>(acc[j + 4].x), acc[j + 4].y + lane_quad<0xB1>(acc[j + 4].y)};
-                res[j] = sub ? hi : lo;
+                const int cs = (rot_out + j) & 7;
+                const cplx d0 = td.unit ? cplx{1.0, 0.0} : spc[cs * npl + G0.plane0], d1 = td.unit ? cplx{0.0, 0.0} : spc[cs * npl + G0.plane0 + 1];
+                cplx t = {0.0, 0.0};
+                cfma(t, d0, res[j]);
+                cfma(t, d1, res2[j]);
+                res[j] = t;
             }
-        } else {                                             // lane q takes positions j + 2 d from lane q - d, d = 0..3
-#pragma unroll
-            for (int j = 0; j < NOUT; ++j)
-                res[j] = cplx{acc[j].x + lane_quad<0x93>(acc[j + 2].x) + lane_quad<0x4E>(acc[j + 4].x) + lane_quad<0x39>(acc[j + 6].x),
-                              acc[j].y + lane_quad<0x93>(acc[j + 2].y) + lane_quad<0x4E>(acc[j + 4].y) + lane_quad<0x39>(acc[j + 6].y)};
         }
         TILE_STAMP(4);
         // Epilogue.  (Two buffers: loads first, then the wait for this wavefront's pieces of the next window, which sits before the
@@ -910,7 +1011,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
             const cplx av = res[j];
             b2[j] = cplx{0.0, 0.0};
             // (three buffers: av is A x - b, or A x + b, already: bz stands in for the right-hand side)
-            const cplx bz = NBUF > 2 ? cplx{0.0, 0.0} : bv[j];
+            const cplx bz = FOLD ? cplx{0.0, 0.0} : bv[j];
             if (mode == MODE_AX) {
                 out[j] = av;
             } else if (mode == MODE_RES) {

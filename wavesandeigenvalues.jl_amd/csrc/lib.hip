@@ -2522,16 +2522,21 @@ int wae_bench_spmv(wae_family *h, const double *coeffs, int32_t r, int32_t reps,
         HIP_CHECK(hipMemcpyAsync(x.p, hx.data(), cnt * sizeof(cplx), hipMemcpyHostToDevice, st));
         std::vector<zc> pc;
         plane_coeffs(h, coeffs, WAE_OP_N, pc);
-        std::vector<cplx> tab(h->nplanes);
-        for (int q = 0; q < h->nplanes; ++q) { const zc c = pc[h->slot_plane[0][q]]; tab[q] = cplx{c.real(), c.imag()}; }
+        // WAE_BENCH_CPS = columns per system (diagnostic: 1, 2 or 4 is what a rank of a multi-GPU pass sees: its share of the
+        // probe columns of every system); default: one system, all columns
+        const int cps = getenv("WAE_BENCH_CPS") ? std::max(1, atoi(getenv("WAE_BENCH_CPS"))) : (1 << 30);
+        const int nsys = cps >= r ? 1 : (r + cps - 1) / cps;
+        std::vector<cplx> tab((size_t)h->nplanes * nsys);
+        for (int sidx = 0; sidx < nsys; ++sidx)
+            for (int q = 0; q < h->nplanes; ++q) { const zc c = pc[h->slot_plane[0][q]]; tab[(size_t)sidx * h->nplanes + q] = cplx{c.real(), c.imag()}; }
         pcd.upload(tab.data(), tab.size(), st);
         const OpDev A = h->ops[0].dev(WAE_OP_N);
-        for (int i = 0; i < 3; ++i) launch_spmv(A, pcd.p, 1 << 30, x.p, y.p, nullptr, 0.0, r, MODE_AX, st);
+        for (int i = 0; i < 3; ++i) launch_spmv(A, pcd.p, cps, x.p, y.p, nullptr, 0.0, r, MODE_AX, st);
         hipEvent_t e0, e1;
         HIP_CHECK(hipEventCreate(&e0));
         HIP_CHECK(hipEventCreate(&e1));
         HIP_CHECK(hipEventRecord(e0, st));
-        for (int i = 0; i < reps; ++i) launch_spmv(A, pcd.p, 1 << 30, x.p, y.p, nullptr, 0.0, r, MODE_AX, st);
+        for (int i = 0; i < reps; ++i) launch_spmv(A, pcd.p, cps, x.p, y.p, nullptr, 0.0, r, MODE_AX, st);
         HIP_CHECK(hipEventRecord(e1, st));
         HIP_CHECK(hipEventSynchronize(e1));
         float ms = 0.f;
