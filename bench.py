@@ -124,7 +124,8 @@ def main():
     import wae_amd  # noqa: F401
     from wae_amd.helmholtz.family import annulus_family
     from wae_amd.nlevp import compute_moment_matrices, gauss_points, initialize_V, moments2eigs, pos_test
-    from wae_amd.nlevp.distributed import allreduce_sum_, beyn_moments_distributed_rb, moments2eigs_device, shard_points
+    from wae_amd.nlevp.distributed import (_guard, allreduce_sum_, beyn_moments_distributed_rb, fail_together, moments2eigs_device,
+                                           shard_points)
     from wae_amd.nlevp.beyn import inpoly
 
     t0 = time.time()
@@ -166,7 +167,8 @@ def main():
             if rank == 0:
                 tim.update({"snapshot_solves": ph["snapshots"], "allgather": ph["allgather"], "projected_solves": ph["projected"]})
         else:
-            compute_moment_matrices(L, G, V, K=K, N=args.N, points=(zr, wr), out_dev=buf.data_ptr(), rb=0)
+            _, err = _guard(compute_moment_matrices, L, G, V, K=K, N=args.N, points=(zr, wr), out_dev=buf.data_ptr(), rb=0)
+            fail_together(err, "beyn moments")                # (a rank whose share failed must not leave the others in the all-reduce)
             t.append(time.time())
             info = dict(fam.last_info)
             allreduce_sum_(buf)                              # sum of the partial moment tensors (RCCL over xGMI)

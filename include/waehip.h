@@ -280,6 +280,23 @@ int wae_bench_spmv(wae_family *h, const double *coeffs, int32_t r, int32_t reps,
 /* device triad a = b + s*c over n doubles: measured streaming bandwidth in GB/s */
 int wae_bench_triad(int32_t device, int64_t n, int32_t reps, double *gbs_out);
 
+/* -- test hook (tests/ only) ----------------------------------------------------------------------------
+ * The solver applies the operator `L(z)*X` (LinOpFam.jl:482-529) in fused forms that no public entry exposes -- residual,
+ * damped-Jacobi sweep, product + first sweep, converged-chunk masks -- and on the coarse levels of its hierarchy.  This entry
+ * runs ONE such launch so that the parity tests can compare every form with the CPU oracle:
+ *   which = 0: the operator of multigrid level `level` (0 = the family itself; >= 1 needs wae_solver_setup);
+ *   which = 1: the restriction from `level` to `level + 1` (coefficients ignored).
+ *   mode: 0 Y = A X | 1 Y = B - A X | 2 Y = X + w/diag (B - A X) | 3 Y = B + A X | 4 Y = (A X)/diag | 5 Y = (B - A X)/diag
+ *         | 6 Y = A X and B2 = w/diag (A X)  (diag = the diagonal of sum_k c_k A_k, w = jac_w)
+ *   coeffs: ncoef x T (ncoef = 1: one system; ncoef = r: one coefficient row per column);
+ *   X, B, Y, B2: column-major n_in x r / n_out x r complex (B may be NULL for modes 0, 4; B2 only for mode 6).  Level 0 is in
+ *   the caller's row numbering; coarser levels in the hierarchy's own (their size: n_in/n_out = 0 on entry returns it in *n_out_q).
+ *   cmask: NULL or one byte per 8-column chunk; 0 = the chunk is skipped and keeps the values Y (and B2) hold on entry.
+ *   flags bit 0: bypass the tile-local storage (the plain CSR kernels), for A/B comparisons of the two storage forms. */
+int wae_debug_spmv(wae_family *h, int32_t which, int32_t level, int32_t mode, const double *coeffs, int32_t ncoef, const double *X,
+                   const double *B, double *Y, double *B2, int32_t r, int32_t op, double jac_w, const uint8_t *cmask, int32_t flags,
+                   int64_t *n_in_q, int64_t *n_out_q);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,7 +27,14 @@ def main():
     d = pb["d"]
     V = np.random.default_rng(5).standard_normal((d, l)) + 0j
     timings = {}
-    buf, info = beyn_moments_distributed_rb(L, G, V, 1, 16, S, timings=timings)
+    if os.environ.get("WAE_TEST_FAIL_RANK") == str(rank):       # this rank's inner solves cannot converge: one iteration allowed
+        L.solver_maxit = 1
+    try:
+        buf, info = beyn_moments_distributed_rb(L, G, V, 1, 16, S, timings=timings)
+    except Exception as e:          # noqa: BLE001
+        print(f"rank {rank}: {type(e).__name__}: {e}", flush=True)
+        L._drop_device()
+        sys.exit(7)
     torch.cuda.synchronize()
     A = buf.cpu().numpy().view(np.complex128).reshape((d, l, 2), order="F")
     # every rank holds the reduced tensor: check that on the ranks themselves, rank 0 reports

@@ -72,6 +72,49 @@ def test_sharded_beyn_matches_single_process():
         assert min(abs(o - w) for o in Om) < 1e-9
 
 
+def _failing_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import wae_amd  # noqa: F401
+    from wae_amd.nlevp.distributed import RankFailure, beyn_moments_distributed
+
+    def moment_fn(zs, ws):            # rank 1's share fails (a stalled inner solve raises in DeviceFamily._report)
+        if rank == 1:
+            raise ValueError("inner solve did not converge")
+        return torch.zeros(3 * 6 * 4 * 2, dtype=torch.float64)
+
+    try:
+        beyn_moments_distributed([2 + 2j, -2 + 2j, -2 - 2j, 2 - 2j], 16, (3, 6, 4), moment_fn)
+    except RankFailure:
+        q.put((rank, "RankFailure"))
+        raise SystemExit(3)
+    except ValueError:
+        q.put((rank, "ValueError"))
+        raise SystemExit(4)
+    q.put((rank, "no error"))
+
+
+def test_a_failing_rank_takes_every_rank_down_before_the_collective():
+    """a rank whose share raises must not leave the others blocked in the all-reduce until the process-group
+    timeout -- every rank agrees on a status word first and all of them raise."""
+    import time
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, q)) for r in range(world)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert time.time() - t0 < 120
+    assert got == {0: "RankFailure", 1: "ValueError"}
+    assert [p.exitcode for p in procs] == [3, 4]
+
+
 def test_shard_covers_all_points_once():
     sys.path.insert(0, ROOT)
     import wae_amd  # noqa: F401

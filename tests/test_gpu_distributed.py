@@ -59,6 +59,24 @@ def test_two_process_projected_guesses_match_single_process(tmp_path, l, branch)
     assert np.max(np.abs(r["A"] - A0)) <= 1e-8 * np.max(np.abs(A0))
 
 
+def test_two_process_run_fails_on_every_rank_when_one_rank_stalls(tmp_path):
+    """rank 1 is allowed one Krylov iteration per solve: its snapshot phase raises (DeviceFamily: contour integrals are fatal);
+    rank 0 must not wait in the all-gather -- both leave promptly with the worker's error code"""
+    import time
+    port = _free_port()
+    procs = []
+    t0 = time.time()
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", WAE_TEST_FAIL_RANK="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_rb_worker.py"), str(tmp_path / "x.npz"), "4", "24"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=300)[0] for p in procs]
+    assert [p.returncode for p in procs] == [7, 7], "\n".join(logs)
+    assert "RankFailure" in logs[0] and "WaeError" in logs[1], "\n".join(logs)
+    assert time.time() - t0 < 200
+
+
 @pytest.mark.parametrize("l,nsnap", [(4, 24), (4, 0), (5, 24)])
 def test_single_process_mgpu_entry_on_one_device(l, nsnap):
     """wae_beyn_moments_mgpu with ngpu = 1: the same code as on 8 GPUs with one rank -- per-device host thread, snapshot phase,
@@ -82,3 +100,32 @@ def test_single_process_mgpu_entry_on_one_device(l, nsnap):
     with pytest.raises(_lib.WaeError):
         beyn_moments_mgpu([L, L], GAMMA, V, K=1, N=16, nsnap=nsnap)
     L._drop_device()
+
+
+@pytest.mark.parametrize("l,nsnap,ngpu", [(4, 24, 2), (3, 24, 2), (4, 0, 2), (6, 24, 3), (5, 24, 3)])
+def test_single_process_mgpu_entry_with_several_virtual_ranks(monkeypatch, l, nsnap, ngpu):
+    """The G > 1 logic of wae_beyn_moments_mgpu on a one-GPU box: WAE_MGPU_EXCHANGE=copy replaces the two RCCL collectives by
+    device-to-device copies (and a fixed-order sum), which allows several handles on ONE device to act as ranks.  Everything else
+    is the code an 8-GPU node runs: a host thread and a stream per rank, column shares (l divisible by the rank count: the basis
+    slabs gathered and merged back into column order by merge_slabs_kernel with G > 1, the projected terms interleaved, wae_rb_import
+    on every rank) or point shares (raw snapshots gathered, every rank rebuilds the basis, slot0 = the used snapshot count),
+    round-robin projected phase, reduction to rank 0.  Against the plain single-GPU moments (<= 1e-8)."""
+    from wae_amd import _lib
+    from wae_amd.helmholtz.family import annulus_family
+    from wae_amd.nlevp.distributed import beyn_moments_mgpu
+    monkeypatch.setenv("WAE_MGPU_EXCHANGE", "copy")
+    A0 = _reference(l)
+    fams = []
+    for _ in range(ngpu):
+        L, pb = annulus_family("small", n=1.0, tau=2e-4)
+        L.solver_tol = 1e-11
+        L.solver_ref = 2 * np.pi * 500.0
+        fams.append(L)
+    V = np.random.default_rng(5).standard_normal((pb["d"], l)) + 0j
+    A, info = beyn_moments_mgpu(fams, GAMMA, V, K=1, N=16, nsnap=nsnap)
+    assert info["n_unconverged"] == 0
+    assert np.max(np.abs(A - A0)) <= 1e-8 * np.max(np.abs(A0))
+    with pytest.raises(_lib.WaeError):                      # the same handle twice is still refused
+        beyn_moments_mgpu([fams[0], fams[0]], GAMMA, V, K=1, N=16, nsnap=nsnap)
+    for L in fams:
+        L._drop_device()

@@ -1,0 +1,101 @@
+"""GPU parity of the dominant kernel -- the tile form of the fused multi-term operator product `L(z)*X` (LinOpFam.jl:482-529) --
+in the regime the benchmark runs it in, against scipy.
+
+`launch_spmv_tile` (csrc/kernels.hip) has two work-list regimes.  Below one tile per compute unit every tile is cut into parts
+(what every small parity case exercises); from 256 tiles on (C2: 780, C3: 3 888 on the fine level, 1 828 on level 1) the
+workgroups are persistent, draw tiles from per-XCD counters, steal, and share out the last tiles.  Here the second regime is
+checked (a) at BASELINE's full sizes C2 and C3 against scipy products of the caller's own term matrices -- one system per launch
+(`spmv_tile_kernel<true,2,2>`) and one system per column (`<false,2,2>`, the instantiation a multi-GPU rank and the Newton-type
+solvers run), op N and C, every fused form the solver uses, with a converged-chunk mask -- and (b) in a child process that
+forces the regime onto an 8 736-DoF problem (WAE_TILE_GRID=8) with both tail settings, where a sparse LU is affordable too.
+Tolerances: tests/_tilecheck.py (1e-13 per column in the max-norm and element-wise against the row's rounding bound)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from _tilecheck import TermProducts, assert_close, check_modes
+from wae_amd.helmholtz.family import annulus_family
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("preset,d_expect", [("C2", 199680), ("C3", 995328)])
+def test_tile_kernel_at_benchmark_size_against_scipy(preset, d_expect):
+    rng = np.random.default_rng(21)
+    L, pb = annulus_family(preset, tau=2e-4)
+    d, T = pb["d"], pb["terms"]
+    assert d == d_expect
+    L.solver_tol = 1e-10
+    L.solver_ref = 2 * np.pi * 500.0
+    L.solver_opts = {"batch": 64, "restart": 40, "sweeps": 1}
+    fam = L.device()
+    zs = 2 * np.pi * (np.linspace(155, 995, 64) + 1j * np.linspace(-145, 145, 64))
+    ct1 = np.array([L.coefficients(zs[40])])
+    ct64 = np.array([L.coefficients(z) for z in zs])
+    X = rng.standard_normal((d, 64)) + 1j * rng.standard_normal((d, 64))
+    tpN = TermProducts(T, X, "N")
+    mask = np.array([1, 0, 1, 1, 0, 0, 1, 1], dtype=bool)
+    # r = 64: one system per launch, one system per column; every fused form; masked chunks keep their contents
+    check_modes(fam, tpN, ct1, X, rng, f"{preset} r=64 one system")
+    check_modes(fam, tpN, ct64, X, rng, f"{preset} r=64 one system per column")
+    check_modes(fam, tpN, ct1, X, rng, f"{preset} r=64 one system, masked", cmask=mask, modes=(0, 1, 2, 6))
+    check_modes(fam, tpN, ct64, X, rng, f"{preset} r=64 one system per column, masked", cmask=mask, modes=(0, 2))
+    for ct in (ct1, ct64):                                          # the public entries (wae_spmv_sum / wae_spmv_sum_cols)
+        want, bound, _ = tpN.apply(ct)
+        assert_close(fam.spmv(ct if len(ct) > 1 else ct[0], X), want, bound, f"{preset} wae_spmv_sum r=64")
+    tpC = TermProducts(T, X, "C")
+    for ct in (ct1, ct64):
+        want, bound, _ = tpC.apply(ct)
+        assert_close(fam.spmv(ct if len(ct) > 1 else ct[0], X, op=2), want, bound, f"{preset} wae_spmv_sum r=64 op C")
+    del tpC
+    # r = 8 (the width of the first snapshot chunks): columns 8..15 of the same X
+    X8 = np.ascontiguousarray(X[:, 8:16])
+    tp8 = TermProducts(T, X8, "N")
+    check_modes(fam, tp8, ct1, X8, rng, f"{preset} r=8 one system", modes=(0, 1, 2, 6))
+    check_modes(fam, tp8, ct64[:8], X8, rng, f"{preset} r=8 one system per column", modes=(0, 2))
+    tp8c = TermProducts(T, X8, "C")
+    want, bound, _ = tp8c.apply(ct1)
+    assert_close(fam.spmv(ct1[0], X8, op=2), want, bound, f"{preset} wae_spmv_sum r=8 op C")
+    # more than 256 columns through the public entry (column groups inside the library)
+    if preset == "C2":
+        X300 = rng.standard_normal((d, 300)) + 1j * rng.standard_normal((d, 300))
+        tp300 = TermProducts(T, X300, "N")
+        want, bound, _ = tp300.apply(ct1)
+        assert_close(fam.spmv(ct1[0], X300), want, bound, "C2 wae_spmv_sum r=300")
+        del tp300, X300
+    # level 1 and the restriction (4 lanes per row, 1 828 / 4 804 tiles at C3) against the CSR kernels of the same hierarchy
+    fam = L.ensure_solver()
+    sizes = {(w, lv): (ni, no) for w, lv, ni, no in fam.level_sizes()}
+    for which, lv in ((0, 1), (1, 0)):
+        ni, no = sizes[(which, lv)]
+        Xl = rng.standard_normal((ni, 64)) + 1j * rng.standard_normal((ni, 64))
+        Bl = rng.standard_normal((no, 64)) + 1j * rng.standard_normal((no, 64))
+        for mode in ((0, 1, 2, 6) if which == 0 else (0,)):
+            a = fam.debug_spmv(ct1, Xl, mode=mode, B=None if mode in (0, 6) else Bl, level=lv, which=which)
+            b = fam.debug_spmv(ct1, Xl, mode=mode, B=None if mode in (0, 6) else Bl, level=lv, which=which, no_tiles=True)
+            for u, v in zip(a if mode == 6 else (a,), b if mode == 6 else (b,)):
+                assert np.max(np.abs(u - v)) <= 1e-12 * np.max(np.abs(v)), (which, lv, mode)
+    # a lock-step solve of 64 shifted systems; the residual is formed with scipy, not with the kernel under test
+    B = rng.standard_normal((d, 64)) + 1j * rng.standard_normal((d, 64))
+    Xs = fam.solve(ct64, B, tol=1e-10, maxit=300)
+    assert fam.last_info["n_unconverged"] == 0 and fam.last_info["relres_max"] <= 1e-10
+    AXs, _, dg = TermProducts(T, Xs, "N").apply(ct64)
+    R = B - AXs
+    for j in range(64):                                             # error-like (diagonal-scaled) measure, as the solver's own
+        assert np.linalg.norm(R[:, j] / dg[:, j]) <= 1e-8 * np.linalg.norm(B[:, j] / dg[:, j]), j
+    L._drop_device()
+
+
+@pytest.mark.parametrize("tail", ["1", "4"])
+def test_persistent_work_list_forced_onto_a_small_problem(tail):
+    """tests/tile_worker.py under WAE_TILE_GRID=8: 35 fine tiles on "8 CUs" -- static + dynamic draw, stealing, tail parts"""
+    env = dict(os.environ, WAE_TILE_GRID="8", WAE_TILE_TAIL=tail)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tile_worker.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    res = json.loads(out.stdout.strip().split("\n")[-1])
+    assert res["checks"] > 100 and res["grid"] == "8" and res["tail"] == tail

@@ -1138,18 +1138,19 @@ static void launch_spmv_tile(const OpDev &op, const TileDev &td, const cplx *pc,
         HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<false, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    static int ncu_dev[64] = {0};                            // CUs per device (devices of a node may differ; under the lock)
+    int &ncu_slot = ncu_dev[dev_now & 63];
+    if (!ncu_slot) {
+        HIP_CHECK(hipDeviceGetAttribute(&ncu_slot, hipDeviceAttributeMultiprocessorCount, dev_now));
+        if (getenv("WAE_TILE_GRID")) ncu_slot = atoi(getenv("WAE_TILE_GRID"));
+        ncu_slot = ncu_slot < 8 ? 8 : ncu_slot & ~7;
+    }
+    const int ncu = ncu_slot;
     attr_lock.unlock();
     // Persistent workgroups, one per CU (157 KB of LDS each: the hardware cannot place two on a CU), walking the tiles of
     // their XCD.  With fewer tiles than CUs the chunks of a tile are shared out between csplit workgroups.  (Sharing them out
     // as soon as a CU had fewer than 8 tiles was measured and is slower -- 200k DoF, 780 tiles: 229 -> 259 us: the matrix
     // slice is re-loaded and the window pipeline restarts per part.)
-    static int ncu = 0;                                      // (same for every device of a node)
-    if (!ncu) {
-        const int dev = dev_now;
-        HIP_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        if (getenv("WAE_TILE_GRID")) ncu = atoi(getenv("WAE_TILE_GRID"));
-        ncu = ncu < 8 ? 8 : ncu & ~7;
-    }
     const int nchunks = (nb + 7) / 8;
     // parts in which the last tiles of every XCD's share are handed out (kernel: "Work list"): with fewer tiles than CUs all of
     // them, so that every CU has work; otherwise four parts bring the end of the launch within a quarter of a tile on every CU
@@ -1875,6 +1876,217 @@ void launch_axpy_neg_norm(const cplx *V, size_t stride, int nv, const cplx *h, c
     HIP_CHECK(hipGetLastError());
     launch_reduce_partials(partial, (int)grid, nb, norms, 1, st, nullptr, inv_out);
 }
+// ---------------------------------------------------------------------------------------------------
+// Two Arnoldi steps per pass over the basis (lib.hip gmres_wide, "pair" steps).  With w1 = Op v_j and w2 = Op w1 -- the operator
+// applied to the vector BEFORE it is orthogonalised -- both new basis vectors come out of ONE reading of V_0..j for the inner
+// products and ONE for the update, where two single steps read it four times: the Gram-Schmidt traffic of a long recurrence, the
+// largest stream of a from-zero solve, halves.
+//   dots2:  c1 = V^H w1, c2 = V^H w2 (each scaled by 1/||v_i||^2: coefficients against the unnormalised basis) and the Gram
+//           entries w1^H w1, w1^H w2, w2^H w2;
+//   axpy2:  v_{j+1} = w1 - V c1,   v_{j+2} = w2 - alpha w1 - V (c2 - alpha c1)   in place, with their squared norms.
+// ---------------------------------------------------------------------------------------------------
+template <int MAXV, bool POW2>
+__global__ __launch_bounds__(256) void dots2_kernel(const cplx *__restrict__ V, size_t stride, int nv, const cplx *__restrict__ W1,
+                                                    const cplx *__restrict__ W2, int64_t n, int nb, cplx *__restrict__ partial,
+                                                    const unsigned char *__restrict__ cmask, int gram) {
+    __shared__ cplx sm[256];
+    const int tid = threadIdx.x;
+    const int R = 256 / nb;
+    const int b = tid % nb, rl = tid / nb;
+    const bool live = rl < R && (!cmask || cmask[b >> 3]);
+    cplx a1[MAXV], a2[MAXV];
+    cplx g[3];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) { a1[i] = cplx{0.0, 0.0}; a2[i] = cplx{0.0, 0.0}; }
+    g[0] = g[1] = g[2] = cplx{0.0, 0.0};
+    if (live) {
+        for (int64_t row = (int64_t)blockIdx.x * R + rl; row < n; row += (int64_t)gridDim.x * R) {
+            const size_t e = (size_t)row * nb + b;
+            const cplx w1 = W1[e], w2 = W2[e];
+            if (gram) {
+                g[0].x += w1.x * w1.x + w1.y * w1.y;
+                g[1].x += w1.x * w2.x + w1.y * w2.y; g[1].y += w1.x * w2.y - w1.y * w2.x;
+                g[2].x += w2.x * w2.x + w2.y * w2.y;
+            }
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                if (i < nv) {
+                    const cplx v = stream_load(V + (size_t)i * stride + e);
+                    a1[i].x += v.x * w1.x + v.y * w1.y; a1[i].y += v.x * w1.y - v.y * w1.x;
+                    a2[i].x += v.x * w2.x + v.y * w2.y; a2[i].y += v.x * w2.y - v.y * w2.x;
+                }
+            }
+        }
+    }
+    // block reduction (as dots_kernel); output order [k][i][b], k = 0, 1, then the three Gram entries
+    const int nout = 2 * nv + (gram ? 3 : 0);
+    auto reduce_store = [&](cplx v, int slot) {
+        if (POW2) {
+            for (int m = 32; m >= nb; m >>= 1) { v.x += __shfl_xor(v.x, m); v.y += __shfl_xor(v.y, m); }
+            const int lane = tid & 63, wv = tid >> 6;
+            if (lane < nb) sm[wv * nb + lane] = v;
+            __syncthreads();
+            if (tid < nb) {
+                cplx s = sm[tid];
+                for (int k = 1; k < 4; ++k) { s.x += sm[k * nb + tid].x; s.y += sm[k * nb + tid].y; }
+                partial[((size_t)blockIdx.x * nout + slot) * nb + tid] = s;
+            }
+            __syncthreads();
+        } else {
+            sm[tid] = v;
+            __syncthreads();
+            if (tid < nb) {
+                cplx s = sm[tid];
+                for (int k = 1; k < R; ++k) { s.x += sm[k * nb + tid].x; s.y += sm[k * nb + tid].y; }
+                partial[((size_t)blockIdx.x * nout + slot) * nb + tid] = s;
+            }
+            __syncthreads();
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (i < nv) { reduce_store(a1[i], i); reduce_store(a2[i], nv + i); }
+    if (gram)
+        for (int q = 0; q < 3; ++q) reduce_store(g[q], 2 * nv + q);
+}
+// second stage: out1[i][b], out2[i][b] (scaled by scale[i][b].x) and gram[q][b] from partial[blk][2 nv + 3][nb]
+__global__ __launch_bounds__(256) void reduce_partials2_kernel(const cplx *__restrict__ partial, int nblk, int nv, int nb, int gram, cplx *__restrict__ out1,
+                                                               cplx *__restrict__ out2, const cplx *__restrict__ scale, cplx *__restrict__ gram_out) {
+    __shared__ cplx sm[256];
+    constexpr int EPB = 2, NS = 256 / EPB;
+    const int count = (2 * nv + (gram ? 3 : 0)) * nb;
+    const int lane_e = threadIdx.x % EPB, slice = threadIdx.x / EPB;
+    const int e = blockIdx.x * EPB + lane_e;
+    cplx acc = {0.0, 0.0};
+    if (e < count)
+        for (int k = slice; k < nblk; k += NS) { const cplx p = partial[(size_t)k * count + e]; acc.x += p.x; acc.y += p.y; }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int s = NS / 2; s >= 1; s >>= 1) {
+        if (slice < s) { sm[threadIdx.x].x += sm[threadIdx.x + s * EPB].x; sm[threadIdx.x].y += sm[threadIdx.x + s * EPB].y; }
+        __syncthreads();
+    }
+    if (slice == 0 && e < count) {
+        acc = sm[threadIdx.x];
+        const int slot = e / nb, b = e - slot * nb;
+        if (slot < 2 * nv) {
+            const int i = slot < nv ? slot : slot - nv;
+            const double sc = scale[(size_t)i * nb + b].x;
+            (slot < nv ? out1 : out2)[(size_t)i * nb + b] = cplx{acc.x * sc, acc.y * sc};
+        } else {
+            gram_out[(size_t)(slot - 2 * nv) * nb + b] = acc;
+        }
+    }
+}
+void launch_dots2_scaled(const cplx *V, size_t stride, int nv, const cplx *W1, const cplx *W2, int64_t n, int nb, cplx *partial, cplx *out1,
+                         cplx *out2, cplx *gram_out, const cplx *scale, hipStream_t st, const unsigned char *cmask) {
+    if (nb < 1 || nb > 256) throw WaeError(WAE_ERR_INVALID, "dots2: nb must be in 1..256");
+    const bool pow2 = nb <= 64 && (nb & (nb - 1)) == 0;
+    const int64_t steps = (n + (256 / nb) - 1) / (256 / nb);
+    const int nblk = (int)std::max<int64_t>(32, std::min<int64_t>(768, (steps + 3) / 4));
+    int done = 0;
+    do {
+        const int chunk = std::min(16, nv - done);
+        const int gram = done == 0 ? 1 : 0;
+        const cplx *Vc = V + (size_t)done * stride;
+        if (pow2) hipLaunchKernelGGL((dots2_kernel<16, true>), dim3(nblk), dim3(256), 0, st, Vc, stride, chunk, W1, W2, n, nb, partial, cmask, gram);
+        else hipLaunchKernelGGL((dots2_kernel<16, false>), dim3(nblk), dim3(256), 0, st, Vc, stride, chunk, W1, W2, n, nb, partial, cmask, gram);
+        HIP_CHECK(hipGetLastError());
+        const int count = (2 * chunk + (gram ? 3 : 0)) * nb;
+        hipLaunchKernelGGL(reduce_partials2_kernel, dim3((count + 1) / 2), dim3(256), 0, st, partial, nblk, chunk, nb, gram, out1 + (size_t)done * nb,
+                           out2 + (size_t)done * nb, scale + (size_t)done * nb, gram_out);
+        HIP_CHECK(hipGetLastError());
+        done += chunk;
+    } while (done < nv);
+}
+
+// v1 = w1 - V c1,  v2 = w2 - alpha w1 - V c2m  (c2m = c2 - alpha c1), in place of w1 / w2; partial[blk][k][b] = this workgroup's part
+// of ||v_k||^2.  Coefficients staged in LDS ([2][nv][nb]); 512 threads so that one workgroup per CU keeps ~64 KB of loads in flight.
+template <int NT>
+__global__ __launch_bounds__(NT) void axpy2_kernel(const cplx *__restrict__ V, size_t stride, int nv, const cplx *__restrict__ c1, const cplx *__restrict__ c2m,
+                                                   const cplx *__restrict__ alpha, cplx *W1, cplx *W2, int64_t n, int nb,
+                                                   const unsigned char *__restrict__ cmask, cplx *__restrict__ partial) {
+    extern __shared__ cplx hs[];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < nv * nb; k += NT) { hs[k] = c1[k]; hs[nv * nb + k] = c2m[k]; }
+    __syncthreads();
+    const int R = NT / nb;
+    const int b = tid % nb, rl = tid / nb;
+    const bool live = rl < R && !(cmask && !cmask[b >> 3]);
+    double n1 = 0.0, n2 = 0.0;
+    if (live) {
+        const cplx al = alpha[b];
+        const cplx *h1 = hs + b, *h2 = hs + (size_t)nv * nb + b;
+        for (int64_t row = (int64_t)blockIdx.x * R + rl; row < n; row += (int64_t)gridDim.x * R) {
+            const size_t e = (size_t)row * nb + b;
+            const cplx w1 = W1[e], w2 = W2[e];
+            cplx o1 = w1;
+            cplx o2 = {w2.x - (al.x * w1.x - al.y * w1.y), w2.y - (al.x * w1.y + al.y * w1.x)};
+            int i = 0;
+            for (; i + AXU <= nv; i += AXU) {
+                cplx v[AXU];
+#pragma unroll
+                for (int u = 0; u < AXU; ++u) v[u] = stream_load(V + (size_t)(i + u) * stride + e);
+#pragma unroll
+                for (int u = 0; u < AXU; ++u) {
+                    const cplx p = h1[(size_t)(i + u) * nb], q = h2[(size_t)(i + u) * nb];
+                    o1.x -= p.x * v[u].x - p.y * v[u].y; o1.y -= p.x * v[u].y + p.y * v[u].x;
+                    o2.x -= q.x * v[u].x - q.y * v[u].y; o2.y -= q.x * v[u].y + q.y * v[u].x;
+                }
+            }
+            for (; i < nv; ++i) {
+                const cplx p = h1[(size_t)i * nb], q = h2[(size_t)i * nb];
+                const cplx v = stream_load(V + (size_t)i * stride + e);
+                o1.x -= p.x * v.x - p.y * v.y; o1.y -= p.x * v.y + p.y * v.x;
+                o2.x -= q.x * v.x - q.y * v.y; o2.y -= q.x * v.y + q.y * v.x;
+            }
+            W1[e] = o1;
+            W2[e] = o2;
+            n1 += o1.x * o1.x + o1.y * o1.y;
+            n2 += o2.x * o2.x + o2.y * o2.y;
+        }
+    }
+    __syncthreads();                            // hs is re-used for the reduction
+    double *sm = (double *)hs;
+    sm[tid] = n1; sm[NT + tid] = n2;
+    __syncthreads();
+    if (tid < nb) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < R; ++k) { s1 += sm[k * nb + tid]; s2 += sm[NT + k * nb + tid]; }
+        partial[((size_t)blockIdx.x * 2 + 0) * nb + tid] = cplx{s1, 0.0};
+        partial[((size_t)blockIdx.x * 2 + 1) * nb + tid] = cplx{s2, 0.0};
+    }
+}
+// norms[k][b] = ||v_k[:,b]|| and inv[k][b] = 1/||v_k||^2, k = 0, 1 (norms, inv: 2 x nb each)
+void launch_axpy2_norm(const cplx *V, size_t stride, int nv, const cplx *c1, const cplx *c2m, const cplx *alpha, cplx *W1, cplx *W2, int64_t n, int nb,
+                       cplx *partial, cplx *norms, cplx *inv_out, hipStream_t st, const unsigned char *cmask) {
+    if (!n || nb < 1) return;
+    if (nb > 256 || nv < 1 || (size_t)2 * nv * nb * sizeof(cplx) > 150 * 1024) throw WaeError(WAE_ERR_INVALID, "axpy2: coefficients do not fit LDS");
+    static std::mutex mu;
+    static bool attr_done[64] = {false};
+    int dev_now = 0;
+    HIP_CHECK(hipGetDevice(&dev_now));
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!attr_done[dev_now & 63]) {
+            HIP_CHECK(hipFuncSetAttribute((const void *)axpy2_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            HIP_CHECK(hipFuncSetAttribute((const void *)axpy2_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_done[dev_now & 63] = true;
+        }
+    }
+    const size_t shm = std::max((size_t)2 * nv * nb * sizeof(cplx), (size_t)2 * 512 * sizeof(double));
+    const bool big = shm > 40 * 1024;              // few workgroups fit a CU: make them large
+    const int NT = big ? 512 : 256;
+    const int R = NT / nb;
+    const int64_t steps = (n + R - 1) / R;
+    const unsigned grid = (unsigned)std::min<int64_t>(steps, big ? 512 : 1024);
+    if (big) hipLaunchKernelGGL(axpy2_kernel<512>, dim3(grid), dim3(512), shm, st, V, stride, nv, c1, c2m, alpha, W1, W2, n, nb, cmask, partial);
+    else hipLaunchKernelGGL(axpy2_kernel<256>, dim3(grid), dim3(256), shm, st, V, stride, nv, c1, c2m, alpha, W1, W2, n, nb, cmask, partial);
+    HIP_CHECK(hipGetLastError());
+    launch_reduce_partials(partial, (int)grid, 2 * nb, norms, 1, st, nullptr, inv_out);
+}
+
 void launch_lincomb(const cplx *V, size_t stride, int nv, const cplx *y, cplx *Y, int64_t n, int nb, hipStream_t st) {
     axpy_impl(V, stride, nv, y, Y, n, nb, 1.0, nullptr, st, nullptr);
 }

@@ -1558,8 +1558,10 @@ int wae_spmv_sum_cols(wae_family *h, const double *coeffs, int32_t ncoef, const 
         hipStream_t st = h->stream;
         const size_t cnt = (size_t)h->d * r;
         ensure(h->io_a, cnt); ensure(h->io_b, cnt);
+        constexpr int GW = 256;                                   // widest launch (the side-row / long-row scratch is sized for it)
+        const int gw = std::min<int>(r, GW);
         DevBuf<cplx> xi, yi;
-        xi.alloc(cnt); yi.alloc(cnt);
+        xi.alloc((size_t)h->d * gw); yi.alloc((size_t)h->d * gw);
         std::vector<cplx> tab((size_t)ncoef * h->nplanes);
         std::vector<zc> pc;
         for (int s = 0; s < ncoef; ++s) {
@@ -1569,9 +1571,13 @@ int wae_spmv_sum_cols(wae_family *h, const double *coeffs, int32_t ncoef, const 
         DevBuf<cplx> pcd;
         pcd.upload(tab.data(), tab.size(), st);
         HIP_CHECK(hipMemcpyAsync(h->io_a.p, X, cnt * sizeof(cplx), hipMemcpyHostToDevice, st));
-        launch_colmajor_to_inter(h->io_a.p, h->d, r, xi.p, r, st, h->perm());
-        launch_spmv(h->ops[0].dev(op), pcd.p, ncoef == 1 ? (1 << 30) : 1, xi.p, yi.p, nullptr, 0.0, r, MODE_AX, st);
-        launch_inter_to_colmajor(yi.p, r, h->d, r, h->io_b.p, st, h->perm());
+        for (int c0 = 0; c0 < r; c0 += GW) {                      // column groups of at most GW
+            const int w = std::min(GW, r - c0);
+            launch_colmajor_to_inter(h->io_a.p + (size_t)c0 * h->d, h->d, w, xi.p, w, st, h->perm());
+            launch_spmv(h->ops[0].dev(op), ncoef == 1 ? pcd.p : pcd.p + (size_t)c0 * h->nplanes, ncoef == 1 ? (1 << 30) : 1, xi.p, yi.p, nullptr, 0.0,
+                        w, MODE_AX, st);
+            launch_inter_to_colmajor(yi.p, w, h->d, w, h->io_b.p + (size_t)c0 * h->d, st, h->perm());
+        }
         HIP_CHECK(hipMemcpyAsync(Y, h->io_b.p, cnt * sizeof(cplx), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         xi.release(); yi.release(); pcd.release();
@@ -1580,6 +1586,15 @@ int wae_spmv_sum_cols(wae_family *h, const double *coeffs, int32_t ncoef, const 
 }
 
 int wae_eig_residuals(wae_family *h, int32_t n, const double *coeff_table, const double *P, uint64_t P_dev, double *res_out) {
+    if (h && n > 256 && coeff_table && (P || P_dev) && res_out) {  // pairs are independent: groups of at most 256 (the widest launch)
+        for (int32_t j0 = 0; j0 < n; j0 += 256) {
+            const int32_t w = std::min<int32_t>(256, n - j0);
+            const int rc = wae_eig_residuals(h, w, coeff_table + (size_t)j0 * 2 * h->T, P ? P + (size_t)j0 * 2 * h->d : nullptr,
+                                             P_dev ? P_dev + (uint64_t)j0 * h->d * sizeof(cplx) : 0, res_out + j0);
+            if (rc != WAE_OK) return rc;
+        }
+        return WAE_OK;
+    }
     return guarded([&]() {
         WAE_REQUIRE(h && n > 0 && coeff_table && (P || P_dev) && res_out, "bad argument");
         HIP_CHECK(hipSetDevice(h->device));
@@ -2545,6 +2560,75 @@ int wae_bench_spmv(wae_family *h, const double *coeffs, int32_t r, int32_t reps,
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
         x.release(); y.release(); pcd.release();
+        return WAE_OK;
+    });
+}
+
+int wae_debug_spmv(wae_family *h, int32_t which, int32_t level, int32_t mode, const double *coeffs, int32_t ncoef, const double *X,
+                   const double *B, double *Y, double *B2, int32_t r, int32_t op, double jac_w, const uint8_t *cmask, int32_t flags,
+                   int64_t *n_in_q, int64_t *n_out_q) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && (which == 0 || which == 1) && level >= 0 && op >= 0 && op <= 2, "bad argument");
+        WAE_REQUIRE(level == 0 || h->solver_ready, "levels >= 1 need wae_solver_setup");
+        // (the last level of a hierarchy is dense: it has no sparse operator to launch)
+        WAE_REQUIRE(which == 0 ? (level == 0 || level < (int)h->ops.size() - 1) : level < (int)h->xfer.size(), "no such level");
+        const int64_t n_in = which == 0 ? h->ops[level].n : h->xfer[level].nf;
+        const int64_t n_out = which == 0 ? h->ops[level].n : h->xfer[level].nc;
+        if (n_in_q) *n_in_q = n_in;
+        if (n_out_q) *n_out_q = n_out;
+        if (!X && !Y) return WAE_OK;                               // size query
+        WAE_REQUIRE(X && Y && r > 0 && r <= 256, "bad argument (1 <= r <= 256)");
+        WAE_REQUIRE(which == 1 || (coeffs && (ncoef == 1 || ncoef == r)), "ncoef must be 1 or r");
+        WAE_REQUIRE(mode >= MODE_AX && mode <= MODE_AX_J0 && (which == 0 || mode == MODE_AX), "bad mode");
+        WAE_REQUIRE(B || mode == MODE_AX || mode == MODE_AX_DS || mode == MODE_AX_J0, "this mode reads B");
+        WAE_REQUIRE(mode != MODE_AX_J0 || B2, "mode 6 writes B2");
+        HIP_CHECK(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        const int *perm = level == 0 && which == 0 ? h->perm() : nullptr;
+        const int *perm_in = which == 1 && level == 0 ? h->perm() : perm;
+        DevBuf<cplx> xc, yc, xi, yi, bi, pcd;
+        DevBuf<unsigned char> cm;
+        const size_t cin = (size_t)n_in * r, cout = (size_t)n_out * r;
+        xc.alloc(std::max(cin, cout)); yc.alloc(cout); xi.alloc(cin); yi.alloc(cout); bi.alloc(cout);
+        HIP_CHECK(hipMemcpyAsync(xc.p, X, cin * sizeof(cplx), hipMemcpyHostToDevice, st));
+        launch_colmajor_to_inter(xc.p, n_in, r, xi.p, r, st, perm_in);
+        auto stage = [&](const double *src, cplx *dst) {           // host column-major n_out x r -> interleaved on the device
+            HIP_CHECK(hipMemcpyAsync(yc.p, src, cout * sizeof(cplx), hipMemcpyHostToDevice, st));
+            launch_colmajor_to_inter(yc.p, n_out, r, dst, r, st, perm);
+        };
+        stage(Y, yi.p);                                             // a masked chunk keeps what Y held on entry
+        if (mode == MODE_AX_J0) stage(B2, bi.p);
+        else if (B) stage(B, bi.p);
+        if (cmask) {
+            cm.alloc((size_t)(r + 7) / 8);
+            HIP_CHECK(hipMemcpyAsync(cm.p, cmask, (size_t)(r + 7) / 8, hipMemcpyHostToDevice, st));
+        }
+        OpDev A;
+        int cps = 1 << 30;
+        if (which == 0) {
+            std::vector<cplx> tab((size_t)ncoef * h->nplanes);
+            std::vector<zc> pc;
+            for (int s = 0; s < ncoef; ++s) {
+                plane_coeffs(h, coeffs + (size_t)s * 2 * h->T, op, pc);
+                for (int q = 0; q < h->nplanes; ++q) { const zc c = pc[h->slot_plane[level][q]]; tab[(size_t)s * h->nplanes + q] = cplx{c.real(), c.imag()}; }
+            }
+            pcd.upload(tab.data(), tab.size(), st);
+            A = h->ops[level].dev(op);
+            cps = ncoef == 1 ? (1 << 30) : 1;
+        } else {
+            A = h->xfer[level].devR();
+        }
+        if (flags & 1) A.tiles = nullptr;
+        launch_spmv(A, which == 0 ? pcd.p : h->one_dev.p, cps, xi.p, yi.p, (mode == MODE_AX || mode == MODE_AX_DS) ? nullptr : bi.p, jac_w, r, mode, st,
+                    cmask ? cm.p : nullptr);
+        launch_inter_to_colmajor(yi.p, r, n_out, r, yc.p, st, perm);
+        HIP_CHECK(hipMemcpyAsync(Y, yc.p, cout * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        if (mode == MODE_AX_J0) {
+            HIP_CHECK(hipStreamSynchronize(st));
+            launch_inter_to_colmajor(bi.p, r, n_out, r, yc.p, st, perm);
+            HIP_CHECK(hipMemcpyAsync(B2, yc.p, cout * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        }
+        HIP_CHECK(hipStreamSynchronize(st));
         return WAE_OK;
     });
 }

@@ -66,20 +66,93 @@ struct CommSet {
     std::vector<int> devs;
     std::vector<ncclComm_t> comms;
 };
-std::vector<CommSet> &comm_cache() { static std::vector<CommSet> c; return c; }
-const std::vector<ncclComm_t> &comms_for(const std::vector<int> &devs) {
-    for (const CommSet &c : comm_cache())
+std::vector<ncclComm_t> comms_for(const std::vector<int> &devs) {       // (by value: the cache may grow under another caller)
+    static std::mutex mu;
+    static std::vector<CommSet> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const CommSet &c : cache)
         if (c.devs == devs) return c.comms;
     const Rccl &R = rccl();
     if (!R.lib || !R.CommInitAll || !R.AllGather || !R.Reduce || !R.GroupStart || !R.GroupEnd)
-        throw WaeError(WAE_ERR_HIP, "RCCL (librccl.so) could not be loaded: wae_beyn_moments_mgpu needs it for more than one GPU");
+        throw WaeError(WAE_ERR_HIP, "RCCL (librccl.so) could not be loaded: wae_beyn_moments_mgpu needs it for more than one GPU "
+                                    "(WAE_MGPU_EXCHANGE=copy exchanges through device-to-device copies instead)");
     CommSet c;
     c.devs = devs;
     c.comms.resize(devs.size());
     nccl_check(R.CommInitAll(c.comms.data(), (int)devs.size(), devs.data()), "ncclCommInitAll");
-    comm_cache().push_back(c);
-    return comm_cache().back().comms;
+    cache.push_back(c);
+    return c.comms;
 }
+
+struct DeviceRestore {               // the entry switches devices: the caller gets its current device back, also on an error
+    int dev = 0;
+    DeviceRestore() { (void)hipGetDevice(&dev); }
+    ~DeviceRestore() { (void)hipSetDevice(dev); }
+};
+
+__global__ __launch_bounds__(256) void add_into_kernel(cplx *__restrict__ acc, const cplx *__restrict__ x, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) { acc[e].x += x[e].x; acc[e].y += x[e].y; }
+}
+
+// The two exchange steps of the multi-GPU pass.  Default: RCCL collectives on the devices' streams (xGMI).  WAE_MGPU_EXCHANGE=copy:
+// plain device-to-device copies (hipMemcpyPeerAsync) and a sum on device 0 -- no RCCL needed, and the "devices" may then be
+// several handles on ONE device ("virtual ranks"): the whole G > 1 logic -- shares, slab merge, basis import, reduction -- runs
+// on a one-GPU box (tests/test_gpu_distributed.py).
+struct Exchange {
+    bool copy = false;
+    std::vector<int> devs;
+    std::vector<hipStream_t> streams;
+    std::vector<ncclComm_t> comms;
+    int G() const { return (int)devs.size(); }
+    void sync_all() const {
+        for (int g = 0; g < G(); ++g) { HIP_CHECK(hipSetDevice(devs[g])); HIP_CHECK(hipStreamSynchronize(streams[g])); }
+    }
+    // dst[q] (G * count elements, rank-major) <- src[g] (count elements) of every g, on every q
+    void all_gather(const std::vector<cplx *> &src, const std::vector<cplx *> &dst, size_t count) const {
+        if (!copy) {
+            const Rccl &R = rccl();
+            struct Group { const Rccl &R; bool open = false; ~Group() { if (open) (void)R.GroupEnd(); } } grp{R};
+            nccl_check(R.GroupStart(), "ncclGroupStart");
+            grp.open = true;
+            for (int g = 0; g < G(); ++g) nccl_check(R.AllGather(src[g], dst[g], count * 2, NCCL_DOUBLE, comms[g], streams[g]), "ncclAllGather");
+            grp.open = false;
+            nccl_check(R.GroupEnd(), "ncclGroupEnd");
+            return;
+        }
+        sync_all();                                              // every source is complete
+        for (int q = 0; q < G(); ++q) {
+            HIP_CHECK(hipSetDevice(devs[q]));
+            for (int g = 0; g < G(); ++g)
+                HIP_CHECK(hipMemcpyPeerAsync(dst[q] + (size_t)g * count, devs[q], src[g], devs[g], count * sizeof(cplx), streams[q]));
+        }
+        sync_all();
+    }
+    // bufs[0] <- sum over g of bufs[g]  (fixed order g = 1, 2, ...: deterministic)
+    void reduce_to_first(const std::vector<cplx *> &bufs, size_t count) const {
+        if (!copy) {
+            const Rccl &R = rccl();
+            struct Group { const Rccl &R; bool open = false; ~Group() { if (open) (void)R.GroupEnd(); } } grp{R};
+            nccl_check(R.GroupStart(), "ncclGroupStart");
+            grp.open = true;
+            for (int g = 0; g < G(); ++g) nccl_check(R.Reduce(bufs[g], bufs[g], count * 2, NCCL_DOUBLE, NCCL_SUM, 0, comms[g], streams[g]), "ncclReduce");
+            grp.open = false;
+            nccl_check(R.GroupEnd(), "ncclGroupEnd");
+            sync_all();
+            return;
+        }
+        sync_all();
+        if (G() == 1) return;
+        HIP_CHECK(hipSetDevice(devs[0]));
+        DevBuf<cplx> tmp;
+        tmp.alloc(count);
+        for (int g = 1; g < G(); ++g) {
+            HIP_CHECK(hipMemcpyPeerAsync(tmp.p, devs[0], bufs[g], devs[g], count * sizeof(cplx), streams[0]));
+            hipLaunchKernelGGL(add_into_kernel, dim3(4096), dim3(256), 0, streams[0], bufs[0], tmp.p, count);
+            HIP_CHECK(hipGetLastError());
+        }
+        HIP_CHECK(hipStreamSynchronize(streams[0]));
+    }
+};
 
 // slabs[g][s][row][c_local]  ->  store[s][row][g*ls + c_local]   (the probe columns back in order after the all-gather)
 __global__ __launch_bounds__(256) void merge_slabs_kernel(const cplx *__restrict__ slabs, cplx *__restrict__ store, int G, int S, int64_t d, int ls) {
@@ -136,6 +209,12 @@ extern "C" int wae_beyn_moments_mgpu(wae_family *const *handles, int32_t ngpu, i
     try {
         WAE_REQUIRE(handles && ngpu >= 1 && ngpu <= 64 && npts >= 0 && (npts == 0 || (z && w && coeff_table)) && V && l > 0 && K > 0 && A_out,
                     "bad argument");
+        DeviceRestore restore_device;
+        Exchange ex;
+        {
+            const char *e = getenv("WAE_MGPU_EXCHANGE");
+            ex.copy = e && std::string(e) == "copy";
+        }
         int64_t d = 0;
         int32_t T = 0;
         std::vector<int> devs(ngpu);
@@ -149,10 +228,14 @@ extern "C" int wae_beyn_moments_mgpu(wae_family *const *handles, int32_t ngpu, i
             WAE_REQUIRE(dg == d && Tg == T, "the handles are not replicas of one family");
             devs[g] = wae_internal_device(handles[g]);
             streams[g] = wae_internal_stream(handles[g]);
-            for (int q = 0; q < g; ++q) WAE_REQUIRE(devs[q] != devs[g], "two handles on one device");
+            for (int q = 0; q < g; ++q) {
+                WAE_REQUIRE(handles[q] != handles[g], "one handle passed twice");
+                WAE_REQUIRE(ex.copy || devs[q] != devs[g], "two handles on one device (only with WAE_MGPU_EXCHANGE=copy)");
+            }
         }
-        const std::vector<ncclComm_t> &comms = comms_for(devs);
-        const Rccl &R = rccl();
+        ex.devs = devs;
+        ex.streams = streams;
+        if (!ex.copy) ex.comms = comms_for(devs);
         const int npow = 2 * K;
         const size_t acnt = (size_t)d * l * npow;
         wae_solve_info tot;
@@ -218,10 +301,11 @@ extern "C" int wae_beyn_moments_mgpu(wae_family *const *handles, int32_t ngpu, i
                 return wae_beyn_moments_rb(handles[g], S, zs.data(), ws.data(), cs.data(), V + (size_t)2 * d * g * ls, ls, K, tol, maxit, 0, S, 0,
                                            (uint64_t)(uintptr_t)local[g].p, nullptr, (uint64_t)(uintptr_t)Ad[g].p, 1, l, g * ls, li);
             }));
-            nccl_check(R.GroupStart(), "ncclGroupStart");
-            for (int g = 0; g < ngpu; ++g)
-                nccl_check(R.AllGather(local[g].p, slabs[g].p, slab * 2, NCCL_DOUBLE, comms[g], streams[g]), "ncclAllGather");
-            nccl_check(R.GroupEnd(), "ncclGroupEnd");
+            {
+                std::vector<cplx *> src(ngpu), dst(ngpu);
+                for (int g = 0; g < ngpu; ++g) { src[g] = local[g].p; dst[g] = slabs[g].p; }
+                ex.all_gather(src, dst, slab);
+            }
             // projected terms and right-hand-side projections of every device's columns
             int32_t Sx = 0, lx = 0, nk = 0;
             if (wae_rb_export(handles[0], &Sx, &lx, &nk, nullptr, nullptr, nullptr) != WAE_OK) throw WaeError(WAE_ERR_INVALID, wae_last_error());
@@ -268,11 +352,12 @@ extern "C" int wae_beyn_moments_mgpu(wae_family *const *handles, int32_t ngpu, i
                 return wae_beyn_moments_rb(handles[g], per, zz.data(), ww.data(), cc.data(), V, l, K, tol, maxit, 0, per, 0,
                                            (uint64_t)(uintptr_t)local[g].p, nullptr, (uint64_t)(uintptr_t)Ad[g].p, 1, 0, 0, li);
             }));
-            nccl_check(R.GroupStart(), "ncclGroupStart");
-            for (int g = 0; g < ngpu; ++g)
-                nccl_check(R.AllGather(local[g].p, store[g].p, slab * 2, NCCL_DOUBLE, comms[g], streams[g]), "ncclAllGather");
-            nccl_check(R.GroupEnd(), "ncclGroupEnd");
-            for (int g = 0; g < ngpu; ++g) { HIP_CHECK(hipSetDevice(devs[g])); HIP_CHECK(hipStreamSynchronize(streams[g])); }
+            {
+                std::vector<cplx *> src(ngpu), dst(ngpu);
+                for (int g = 0; g < ngpu; ++g) { src[g] = local[g].p; dst[g] = store[g].p; }
+                ex.all_gather(src, dst, slab);
+            }
+            ex.sync_all();
             code = std::max(code, on_all([&](int g, wae_solve_info *li) {
                 std::vector<int> mine;
                 for (size_t i = g; i < rest.size(); i += ngpu) mine.push_back(rest[i]);
@@ -282,11 +367,11 @@ extern "C" int wae_beyn_moments_mgpu(wae_family *const *handles, int32_t ngpu, i
             }));
         }
         // sum of the partial moment tensors on device 0 (in place), then to the host
-        nccl_check(R.GroupStart(), "ncclGroupStart");
-        for (int g = 0; g < ngpu; ++g)
-            nccl_check(R.Reduce(Ad[g].p, Ad[g].p, acnt * 2, NCCL_DOUBLE, NCCL_SUM, 0, comms[g], streams[g]), "ncclReduce");
-        nccl_check(R.GroupEnd(), "ncclGroupEnd");
-        for (int g = 0; g < ngpu; ++g) { HIP_CHECK(hipSetDevice(devs[g])); HIP_CHECK(hipStreamSynchronize(streams[g])); }
+        {
+            std::vector<cplx *> bufs(ngpu);
+            for (int g = 0; g < ngpu; ++g) bufs[g] = Ad[g].p;
+            ex.reduce_to_first(bufs, acnt);
+        }
         HIP_CHECK(hipSetDevice(devs[0]));
         HIP_CHECK(hipMemcpy(A_out, Ad[0].p, acnt * sizeof(cplx), hipMemcpyDeviceToHost));
         for (int g = 0; g < ngpu; ++g) {                        // buffers are freed on their own device

@@ -35,6 +35,39 @@ def allreduce_sum_(t):
     return t
 
 
+class RankFailure(RuntimeError):
+    """raised on the ranks that were fine when another rank's share of the work failed"""
+
+
+def _guard(fn, *a, **kw):
+    """run a per-rank piece of work; returns (result, exception or None) instead of raising, so that the rank still reaches
+    `fail_together` -- a rank that raised and left would let the others block in the next collective until the process-group
+    timeout"""
+    try:
+        return fn(*a, **kw), None
+    except Exception as e:          # noqa: BLE001  (whatever it was, the other ranks must hear of it)
+        return None, e
+
+
+def fail_together(err, what):
+    """Every rank calls this between its share of the work and the next collective: one MAX all-reduce of a status word; if
+    any rank failed (e.g. an inner solve stalled at a quadrature point near a pole: DeviceFamily raises for contour
+    integrals), ALL ranks raise now -- the failing rank its own exception, the others a RankFailure."""
+    d = _dist()
+    bad = 1 if err is not None else 0
+    if d is not None and d.get_world_size() > 1:
+        import torch
+        t = torch.tensor([bad], dtype=torch.int32)
+        if d.get_backend() == "nccl":
+            t = t.cuda()
+        d.all_reduce(t, op=d.ReduceOp.MAX)
+        bad = int(t.item())
+    if err is not None:
+        raise err
+    if bad:
+        raise RankFailure(f"{what}: another rank failed; no rank continues into the collective")
+
+
 def device_moment_fn(L, G, V, K, N):
     """default producer of a rank's partial moments: the HIP path writing straight into a torch CUDA buffer."""
     import torch
@@ -54,7 +87,8 @@ def beyn_moments_distributed(G, N, shape, moment_fn):
     rank, world = rank_world()
     zs, ws = gauss_points(G, N)
     zr, wr = shard_points(zs, ws, rank, world)
-    buf = moment_fn(zr, wr)
+    buf, err = _guard(moment_fn, zr, wr)
+    fail_together(err, "beyn_moments_distributed")
     allreduce_sum_(buf)
     return buf.cpu().numpy().view(np.complex128).reshape(shape, order="F")
 
@@ -110,7 +144,8 @@ def beyn_moments_distributed_rb(L, G, V, K, N, S, timings=None, extra=None):
         c0 = rank * ls
         cap = S + (0 if (extra is None or world > 1) else int(extra))
         local = torch.empty(cap * d * ls * 2, dtype=torch.float64, device=dev)
-        fam.beyn_moments_rb(zs[idx], ws[idx], ct[idx], V[:, c0:c0 + ls], 0, cap, Q_dev=local.data_ptr(), l_total=l, col0=c0, **kw)
+        _, err = _guard(fam.beyn_moments_rb, zs[idx], ws[idx], ct[idx], V[:, c0:c0 + ls], 0, cap, Q_dev=local.data_ptr(), l_total=l, col0=c0, **kw)
+        fail_together(err, "snapshot phase")
         i0 = dict(fam.last_info)
         snap_cols = S * ls
         t1 = time.perf_counter()
@@ -132,9 +167,9 @@ def beyn_moments_distributed_rb(L, G, V, K, N, S, timings=None, extra=None):
         t2 = time.perf_counter()
         mine2 = rest[rank::world]
         if world > 1:
-            fam.beyn_moments_rb(zs[mine2], ws[mine2], ct[mine2], V, 2, S, Q_dev=store.data_ptr(), accumulate=True, **kw)
+            _, err = _guard(fam.beyn_moments_rb, zs[mine2], ws[mine2], ct[mine2], V, 2, S, Q_dev=store.data_ptr(), accumulate=True, **kw)
         else:        # same handle, same probe matrix: it is still in HBM
-            fam.beyn_moments_rb(zs[mine2], ws[mine2], ct[mine2], None, 2, cap, Q_dev=store.data_ptr(), accumulate=True, l_total=l, **kw)
+            _, err = _guard(fam.beyn_moments_rb, zs[mine2], ws[mine2], ct[mine2], None, 2, cap, Q_dev=store.data_ptr(), accumulate=True, l_total=l, **kw)
     else:
         S = min(int(S), len(zs))
         S = max(world, (S // world) * world)                      # equal snapshot shares (all_gather wants equal sizes)
@@ -144,7 +179,8 @@ def beyn_moments_distributed_rb(L, G, V, K, N, S, timings=None, extra=None):
         mine = idx[rank::world]
         per = len(mine)
         local = torch.empty(per * d * l * 2, dtype=torch.float64, device=dev)
-        fam.beyn_moments_rb(zs[mine], ws[mine], ct[mine], V, 0, per, Q_dev=local.data_ptr(), **kw)
+        _, err = _guard(fam.beyn_moments_rb, zs[mine], ws[mine], ct[mine], V, 0, per, Q_dev=local.data_ptr(), **kw)
+        fail_together(err, "snapshot phase")
         i0 = dict(fam.last_info)
         snap_cols = per * l
         t1 = time.perf_counter()
@@ -153,7 +189,8 @@ def beyn_moments_distributed_rb(L, G, V, K, N, S, timings=None, extra=None):
         torch.cuda.synchronize(dev)
         t2 = time.perf_counter()
         mine2 = rest[rank::world]
-        fam.beyn_moments_rb(zs[mine2], ws[mine2], ct[mine2], V, 1, S, slot0=S, Q_dev=store.data_ptr(), accumulate=True, **kw)
+        _, err = _guard(fam.beyn_moments_rb, zs[mine2], ws[mine2], ct[mine2], V, 1, S, slot0=S, Q_dev=store.data_ptr(), accumulate=True, **kw)
+    fail_together(err, "projected phase")
     i1 = dict(fam.last_info)
     t3 = time.perf_counter()
     allreduce_sum_(buf)

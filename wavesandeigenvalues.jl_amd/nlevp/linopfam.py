@@ -309,6 +309,39 @@ class DeviceFamily:
         self._report(code, info, f"perturb (order {N})", quiet=quiet)
         return lam, V
 
+    def debug_spmv(self, coeffs, X, mode=0, B=None, Y0=None, op=OP_N, jac_w=0.8, cmask=None, level=0, which=0, no_tiles=False):
+        """wae_debug_spmv (test hook): one launch of the fused operator product in any of the solver's forms.  Returns Y, or
+        (Y, B2) for mode 6.  ``level``/``which`` select a coarse-level operator or a restriction of the multigrid hierarchy."""
+        lib = _lib.lib()
+        nin, nout = C.c_int64(0), C.c_int64(0)
+        check(lib.wae_debug_spmv(self.handle, which, level, 0, None, 0, None, None, None, None, 0, op, 0.0, None, 0, C.byref(nin), C.byref(nout)))
+        c = np.ascontiguousarray(coeffs, dtype=np.complex128).reshape(-1, self.T)
+        Xf = np.asfortranarray(np.asarray(X, dtype=np.complex128).reshape(nin.value, -1))
+        r = Xf.shape[1]
+        Y = np.zeros((nout.value, r), dtype=np.complex128, order="F") if Y0 is None else np.asfortranarray(np.array(Y0, dtype=np.complex128))
+        Bf = None if B is None else np.asfortranarray(np.asarray(B, dtype=np.complex128).reshape(nout.value, r))
+        B2 = np.zeros((nout.value, r), dtype=np.complex128, order="F") if mode == 6 else None
+        if mode == 6 and Y0 is not None:
+            B2[...] = Y0
+        cm = None if cmask is None else (C.c_uint8 * ((r + 7) // 8))(*[1 if x else 0 for x in cmask])
+        check(lib.wae_debug_spmv(self.handle, which, level, mode, zptr(c), c.shape[0], zptr(Xf), None if Bf is None else zptr(Bf), zptr(Y),
+                                 None if B2 is None else zptr(B2), r, op, float(jac_w), cm, 1 if no_tiles else 0, C.byref(nin), C.byref(nout)))
+        return (Y, B2) if mode == 6 else Y
+
+    def level_sizes(self):
+        """(n_in, n_out) of every sparse level operator / restriction of the hierarchy (test hook)"""
+        out = []
+        lib = _lib.lib()
+        for which in (0, 1):
+            lv = 0
+            while True:
+                nin, nout = C.c_int64(0), C.c_int64(0)
+                if lib.wae_debug_spmv(self.handle, which, lv, 0, None, 0, None, None, None, None, 0, 0, 0.0, None, 0, C.byref(nin), C.byref(nout)) != 0:
+                    break
+                out.append((which, lv, nin.value, nout.value))
+                lv += 1
+        return out
+
     def bench_spmv(self, coeffs, r=1, reps=20):
         c = np.ascontiguousarray(coeffs, dtype=np.complex128)
         ms = C.c_double(0)
