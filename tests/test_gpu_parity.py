@@ -744,13 +744,16 @@ print(json.dumps({"its": i["iters_total"], "unconv": i["n_unconverged"], "sum": 
     # the default keeps it on the device (gmres_wide) and looks at the status words every 4 iterations, "sync1" every iteration
     for name, extra in (("default", {}), ("guard", {"WAE_LAZY_LIMIT": "3"}), ("explicit", {"WAE_LAZY": "0"}),
                         ("host", {"WAE_GMRES_DEVICE": "0"}), ("host_guard", {"WAE_GMRES_DEVICE": "0", "WAE_LAZY_LIMIT": "3"}),
-                        ("sync1", {"WAE_GMRES_SYNC": "1"})):
+                        ("sync1", {"WAE_GMRES_SYNC": "1"}),
+                        # pair steps (two Arnoldi steps per pass over the basis, round 3): off / from the first iteration / from the
+                        # default iteration on -- the same Krylov space and the same per-column stopping test
+                        ("single", {"WAE_GMRES_PAIR": "-1"}), ("pair0", {"WAE_GMRES_PAIR": "0"}), ("pair1_sync1", {"WAE_GMRES_PAIR": "1", "WAE_GMRES_SYNC": "1"})):
         env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         import json
         out[name] = json.loads(r.stdout.strip().splitlines()[-1])
-    for name in ("guard", "explicit", "host", "host_guard", "sync1"):
+    for name in ("guard", "explicit", "host", "host_guard", "sync1", "single", "pair0", "pair1_sync1"):
         assert out[name]["unconv"] == 0 and out["default"]["unconv"] == 0
         assert abs(out[name]["its"] - out["default"]["its"]) <= 0.02 * out["default"]["its"]
         assert np.allclose(out[name]["sum"], out["default"]["sum"], rtol=1e-8)

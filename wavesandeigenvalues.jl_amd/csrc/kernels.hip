@@ -2397,7 +2397,8 @@ __global__ __launch_bounds__(256) void gmres_init_kernel(GmresDev S, const cplx 
 // after Arnoldi step j: hd[i][b], i <= j: s_i^2-scaled dots of the new vector against the unnormalised basis; hd[j+1][b].x: norm of
 // the orthogonalised vector (lib.hip: "lazy" basis).  Produces the Hessenberg column of the normalised recurrence, rotates it,
 // updates g, the residual estimate and the flags; marks vectors whose running scale left [1/lim, lim] for renormalisation.
-__global__ __launch_bounds__(256) void gmres_step_kernel(GmresDev S, const cplx *__restrict__ hd, int j, double tol, double lim, int use_mask) {
+__global__ __launch_bounds__(256) void gmres_step_kernel(GmresDev S, const cplx *__restrict__ hd, int j, double tol, double lim, int use_mask,
+                                                         const cplx *__restrict__ rn) {
     __shared__ int act[256];
     const int b = threadIdx.x;
     const int nb = S.nb, m = S.m;
@@ -2405,10 +2406,15 @@ __global__ __launch_bounds__(256) void gmres_step_kernel(GmresDev S, const cplx 
     if (b < nb) {
         const int nvj = j + 1;
         const double sj = S.sv[(size_t)j * nb + b];
-        const double r = hd[(size_t)nvj * nb + b].x;
+        const double r = rn ? rn[b].x : hd[(size_t)nvj * nb + b].x;        // norm of the new (unnormalised) vector
+        if (S.Hraw) {                                         // the unnormalised recurrence itself (read by the pair steps):
+            cplx *Hr = S.Hraw + (size_t)j * (m + 1) * nb;     // Op v_j = sum_{i<=j} Hraw[j][i] v_i + sub[j] v_{j+1}
+            for (int i = 0; i <= j; ++i) Hr[(size_t)i * nb + b] = hd[(size_t)i * nb + b];
+        }
         double svn = r > 0.0 ? 1.0 / r : 0.0;
         const bool resc = svn > lim || (svn > 0.0 && svn < 1.0 / lim);
         S.rescale[b] = resc ? cplx{r, 0.0} : cplx{0.0, 0.0};
+        if (S.sub) S.sub[(size_t)j * nb + b] = resc ? r : 1.0;
         if (resc) {                                          // the vector is normalised in place by gmres_rescale_kernel
             S.vsq[(size_t)nvj * nb + b] = cplx{svn > 0.0 ? 1.0 : 0.0, 0.0};
             svn = svn > 0.0 ? 1.0 : 0.0;
@@ -2519,8 +2525,59 @@ void launch_gmres_init(const GmresDev &S, const cplx *beta, const unsigned char 
     hipLaunchKernelGGL(gmres_init_kernel, dim3(1), dim3(256), 0, st, S, beta, done, use_mask);
     HIP_CHECK(hipGetLastError());
 }
-void launch_gmres_step(const GmresDev &S, const cplx *hd, int j, double tol, double lim, int use_mask, cplx *Vnew, int64_t n, hipStream_t st) {
-    hipLaunchKernelGGL(gmres_step_kernel, dim3(1), dim3(256), 0, st, S, hd, j, tol, lim, use_mask);
+// One thread per column, ahead of the update pass of a pair step (after dots2): alpha = u1^H u2 / u1^H u1 from the Gram entries and
+// the coefficients (u_k = w_k - V c_k), c2m = c2 - alpha c1, and the coefficients hd2 of Op v_{j+1} against the unnormalised basis
+// v_0..v_{j+1}:  Op v_{j+1} = Op (w1 - V c1) = w2 - sum_k c1_k Op v_k,  w2 = V c2 + alpha v_{j+1} + v_{j+2}  and
+// Op v_k = sum_{i<=k} Hraw[k][i] v_i + sub[k] v_{k+1} (column j of it being c1 itself, with sub[j] = 1).
+__global__ __launch_bounds__(256) void gmres_pair_coef_kernel(GmresDev S, int j, const cplx *__restrict__ c1, const cplx *__restrict__ c2,
+                                                              const cplx *__restrict__ gram, cplx *__restrict__ alpha, cplx *__restrict__ c2m,
+                                                              cplx *__restrict__ hd2) {
+    const int b = threadIdx.x;
+    const int nb = S.nb, m = S.m;
+    if (b >= nb) return;
+    double uu = gram[b].x;
+    cplx u12 = gram[(size_t)nb + b];
+    for (int i = 0; i <= j; ++i) {
+        const double q = S.vsq[(size_t)i * nb + b].x;
+        const double w = q > 0.0 ? 1.0 / q : 0.0;             // ||v_i||^2
+        const cplx a = c1[(size_t)i * nb + b], c = c2[(size_t)i * nb + b];
+        uu -= (a.x * a.x + a.y * a.y) * w;
+        u12.x -= (a.x * c.x + a.y * c.y) * w;                 // conj(a) c
+        u12.y -= (a.x * c.y - a.y * c.x) * w;
+    }
+    cplx al = {0.0, 0.0};
+    if (uu > 0.0 && uu > 1e-28 * gram[b].x) al = cplx{u12.x / uu, u12.y / uu};
+    alpha[b] = al;
+    cplx *Hj = S.Hraw + (size_t)j * (m + 1) * nb;
+    for (int i = 0; i <= j; ++i) {
+        const cplx a = c1[(size_t)i * nb + b], c = c2[(size_t)i * nb + b];
+        Hj[(size_t)i * nb + b] = a;
+        c2m[(size_t)i * nb + b] = cplx{c.x - (al.x * a.x - al.y * a.y), c.y - (al.x * a.y + al.y * a.x)};
+    }
+    S.sub[(size_t)j * nb + b] = 1.0;
+    for (int i = 0; i <= j + 1; ++i) {
+        cplx t = i <= j ? c2[(size_t)i * nb + b] : al;
+        for (int k = i; k <= j; ++k) {
+            const cplx hk = S.Hraw[((size_t)k * (m + 1) + i) * nb + b], ck = c1[(size_t)k * nb + b];
+            t.x -= hk.x * ck.x - hk.y * ck.y;
+            t.y -= hk.x * ck.y + hk.y * ck.x;
+        }
+        if (i >= 1) {
+            const double sb = S.sub[(size_t)(i - 1) * nb + b];
+            const cplx ck = c1[(size_t)(i - 1) * nb + b];
+            t.x -= sb * ck.x;
+            t.y -= sb * ck.y;
+        }
+        hd2[(size_t)i * nb + b] = t;
+    }
+}
+void launch_gmres_pair_coef(const GmresDev &S, int j, const cplx *c1, const cplx *c2, const cplx *gram, cplx *alpha, cplx *c2m, cplx *hd2, hipStream_t st) {
+    hipLaunchKernelGGL(gmres_pair_coef_kernel, dim3(1), dim3(256), 0, st, S, j, c1, c2, gram, alpha, c2m, hd2);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_gmres_step(const GmresDev &S, const cplx *hd, int j, double tol, double lim, int use_mask, cplx *Vnew, int64_t n, hipStream_t st,
+                       const cplx *rn) {
+    hipLaunchKernelGGL(gmres_step_kernel, dim3(1), dim3(256), 0, st, S, hd, j, tol, lim, use_mask, rn);
     hipLaunchKernelGGL(gmres_rescale_kernel, dim3(512), dim3(256), 0, st, Vnew, S.rescale, S.status, (size_t)n * S.nb, S.nb);
     hipLaunchKernelGGL(gmres_clear_rescale_kernel, dim3(1), dim3(1), 0, st, S.status);
     HIP_CHECK(hipGetLastError());

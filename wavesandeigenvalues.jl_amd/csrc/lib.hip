@@ -118,7 +118,8 @@ struct wae_family {
     DevBuf<int> plane_col_dev;
     DevBuf<unsigned char> cmask;     // one byte per 8-column chunk of the current batch (0 = converged)
     // device-resident recurrence of the wide-batch GMRES (gmres_wide)
-    DevBuf<cplx> gs_R, gs_sn, gs_g, gs_rescale;
+    DevBuf<cplx> gs_R, gs_sn, gs_g, gs_rescale, gs_Hraw, gs_pair;
+    DevBuf<double> gs_sub;
     DevBuf<double> gs_cs, gs_sv, gs_relres, gs_bnorm, gs_hist;
     DevBuf<int> gs_int;              // conv | steps | iters | histlen | stalled | status(4)
     DevBuf<unsigned char> gs_done;
@@ -543,7 +544,9 @@ static void dense_setup(wae_family *h, const Batch &bt) {
 
 // x = Minv b on level l;  returns pointer to the result (either lx[l] or lt[l])
 // have_x0: the first sweep of level l (x = w/diag b) is already in lx[l] (written by the SpMV that produced b, MODE_AX_J0)
-static cplx *vcycle(wae_family *h, const Batch &bt, int l, const cplx *b, const unsigned char *cm = nullptr, bool have_x0 = false) {
+// final_out (level 0 only): the last post-smoothing sweep writes its result there (a Krylov basis slot) instead of into lx/lt
+static cplx *vcycle(wae_family *h, const Batch &bt, int l, const cplx *b, const unsigned char *cm = nullptr, bool have_x0 = false,
+                    cplx *final_out = nullptr) {
     const int L = (int)h->ops.size() - 1;
     hipStream_t st = h->stream;
     if (l == L) {
@@ -567,9 +570,11 @@ static cplx *vcycle(wae_family *h, const Batch &bt, int l, const cplx *b, const 
     static const int post_coarse = getenv("WAE_VC_POST_COARSE") ? atoi(getenv("WAE_VC_POST_COARSE")) : 1;
     const int npost = (l >= 1 && !post_coarse) ? 0 : h->nsweeps;
     for (int s = 0; s < npost; ++s) {
-        launch_spmv(A, pc, bt.cps, x, t, b, h->jac_w, bt.nb, MODE_JAC, st, cm);
-        std::swap(x, t);
+        cplx *dst = (final_out && s == npost - 1) ? final_out : t;
+        launch_spmv(A, pc, bt.cps, x, dst, b, h->jac_w, bt.nb, MODE_JAC, st, cm);
+        if (dst == t) std::swap(x, t); else x = dst;
     }
+    if (final_out && x != final_out) { launch_copy(x, final_out, (size_t)h->ops[l].n * bt.nb, st); x = final_out; }
     return x;
 }
 
@@ -667,6 +672,17 @@ static int gmres_wide(wae_family *h, const Batch &bt, const cplx *B, cplx *X, do
     S.R = h->gs_R.p; S.cs = h->gs_cs.p; S.sn = h->gs_sn.p; S.g = h->gs_g.p; S.sv = h->gs_sv.p; S.vsq = h->vsq.p;
     S.conv = h->gs_int.p; S.steps = S.conv + nb; S.iters = S.steps + nb; S.histlen = S.iters + nb; S.stalled = S.histlen + nb; S.status = S.stalled + nb;
     S.relres = h->gs_relres.p; S.bnorm = h->gs_bnorm.p; S.hist = h->gs_hist.p; S.rescale = h->gs_rescale.p; S.cmask = h->cmask.p;
+    // Pair steps (kernels.hip "Two Arnoldi steps per pass over the basis"): from iteration pair_min of a cycle on, while most columns
+    // are still active, the operator is applied twice before the Gram-Schmidt pass.  Same Krylov space, same per-column stopping test
+    // after each of the two steps; what it costs is one operator application when the batch ends on the first step of a pair.
+    static const int pair_min = getenv("WAE_GMRES_PAIR") ? atoi(getenv("WAE_GMRES_PAIR")) : 4;       // (< 0: off)
+    const bool pair_on = pair_min >= 0 && lim >= 1e50 && nb >= 8 && h->ops.size() > 1;
+    ens(h->gs_Hraw, (size_t)m * (m + 1) * nb); ens(h->gs_pair, ((size_t)4 * (m + 3) + 8) * nb);
+    if (h->gs_sub.n < (size_t)m * nb) h->gs_sub.alloc((size_t)m * nb);
+    S.Hraw = h->gs_Hraw.p; S.sub = h->gs_sub.p;
+    cplx *const pr_c1 = h->gs_pair.p, *const pr_c2 = pr_c1 + (size_t)(m + 3) * nb, *const pr_c2m = pr_c2 + (size_t)(m + 3) * nb,
+               *const pr_hd2 = pr_c2m + (size_t)(m + 3) * nb, *const pr_gram = pr_hd2 + (size_t)(m + 3) * nb, *const pr_alpha = pr_gram + (size_t)3 * nb,
+               *const pr_norm = pr_alpha + nb;
     HIP_CHECK(hipMemsetAsync(h->gs_int.p, 0, ((size_t)5 * nb + 4) * sizeof(int), st));
     if (!have_x0) launch_fill_zero(X, vec, st);
     cplx *const zb = vcycle(h, bt, 0, B);                    // M^-1 b: its norm scales the stopping test; from a zero guess it is also
@@ -730,21 +746,42 @@ static int gmres_wide(wae_family *h, const Batch &bt, const cplx *B, cplx *X, do
         int j = 0;
         int status[4] = {0, 0, 0, 0};
         for (int b = 0; b < nb; ++b) status[0] += done[b] ? 0 : 1;              // columns still to converge at the start of this cycle
+        int since_sync = 0;
         for (; j < m && total_it < maxit;) {
             const cplx *vj = h->V.p + (size_t)j * vec;
             const int nvj = j + 1;
             const bool fuse0 = h->ops.size() > 1;
-            launch_spmv(A, pc, bt.cps, vj, h->W.p, fuse0 ? h->lx[0].p : nullptr, fuse0 ? h->jac_w : 0.0, nb, fuse0 ? MODE_AX_J0 : MODE_AX, st, mk);
-            cplx *w = vcycle(h, bt, 0, h->W.p, mk, fuse0);
-            launch_dots_scaled(h->V.p, vec, nvj, w, n, nb, h->partial.p, h->hdev.p, h->vsq.p, st, mk);
-            launch_axpy_neg_norm(h->V.p, vec, nvj, h->hdev.p, h->V.p + (size_t)nvj * vec, n, nb, h->partial.p, h->hdev.p + (size_t)nvj * nb, st, mk,
-                                 w, h->vsq.p + (size_t)nvj * nb);
-            launch_gmres_step(S, h->hdev.p, j, tol, lim, use_mask ? 1 : 0, h->V.p + (size_t)nvj * vec, n, st);
-            ++j;
-            ++total_it;
+            if (pair_on && j >= pair_min && j + 2 <= m && total_it + 2 <= maxit && status[0] > nb / 4) {
+                cplx *w1 = h->V.p + (size_t)nvj * vec, *w2 = w1 + vec;         // computed in their basis slots, orthogonalised in place
+                launch_spmv(A, pc, bt.cps, vj, h->W.p, h->lx[0].p, h->jac_w, nb, MODE_AX_J0, st, mk);
+                vcycle(h, bt, 0, h->W.p, mk, true, w1);
+                launch_spmv(A, pc, bt.cps, w1, h->W.p, h->lx[0].p, h->jac_w, nb, MODE_AX_J0, st, mk);
+                vcycle(h, bt, 0, h->W.p, mk, true, w2);
+                launch_dots2_scaled(h->V.p, vec, nvj, w1, w2, n, nb, h->partial.p, pr_c1, pr_c2, pr_gram, h->vsq.p, st, mk);
+                launch_gmres_pair_coef(S, j, pr_c1, pr_c2, pr_gram, pr_alpha, pr_c2m, pr_hd2, st);
+                launch_axpy2_norm(h->V.p, vec, nvj, pr_c1, pr_c2m, pr_alpha, w1, w2, n, nb, h->partial.p, pr_norm, h->vsq.p + (size_t)nvj * nb, st, mk);
+                // (the middle vector is not renormalised in place -- the relation of the vector after it was formed with it as it is;
+                // its norm is within one operator application of a vector the range guard has seen)
+                launch_gmres_step(S, pr_c1, j, tol, 1e300, use_mask ? 1 : 0, w1, n, st, pr_norm);
+                launch_gmres_step(S, pr_hd2, j + 1, tol, lim, use_mask ? 1 : 0, w2, n, st, pr_norm + nb);
+                j += 2;
+                total_it += 2;
+                since_sync += 2;
+            } else {
+                launch_spmv(A, pc, bt.cps, vj, h->W.p, fuse0 ? h->lx[0].p : nullptr, fuse0 ? h->jac_w : 0.0, nb, fuse0 ? MODE_AX_J0 : MODE_AX, st, mk);
+                cplx *w = vcycle(h, bt, 0, h->W.p, mk, fuse0);
+                launch_dots_scaled(h->V.p, vec, nvj, w, n, nb, h->partial.p, h->hdev.p, h->vsq.p, st, mk);
+                launch_axpy_neg_norm(h->V.p, vec, nvj, h->hdev.p, h->V.p + (size_t)nvj * vec, n, nb, h->partial.p, h->hdev.p + (size_t)nvj * nb, st, mk,
+                                     w, h->vsq.p + (size_t)nvj * nb);
+                launch_gmres_step(S, h->hdev.p, j, tol, lim, use_mask ? 1 : 0, h->V.p + (size_t)nvj * vec, n, st);
+                ++j;
+                ++total_it;
+                ++since_sync;
+            }
             // look at the status words every ksync iterations -- every iteration once few columns are left (the end of the
             // cycle is near: an overshoot iteration is ~25 launches of fully masked kernels)
-            if (j % ksync == 0 || j == m || total_it >= maxit || status[0] <= nb / 4) {
+            if (since_sync >= ksync || j == m || total_it >= maxit || status[0] <= nb / 4) {
+                since_sync = 0;
                 HIP_CHECK(hipMemcpyAsync(status, S.status, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
                 HIP_CHECK(hipStreamSynchronize(st));
                 if (status[1]) nan_seen = true;

@@ -283,9 +283,18 @@ struct GmresDev {
     cplx *rescale;          // [nb] factor of a pending renormalisation (0 = none)
     int *status;            // [0] active columns, [1] NaN seen, [2] renormalisation pending
     unsigned char *cmask;   // per 8-column chunk: any active column
+    cplx *Hraw;             // [m][m+1][nb]: the unnormalised recurrence, Op v_k = sum_{i<=k} Hraw[k][i] v_i + sub[k] v_{k+1} (pair steps); may be null
+    double *sub;            // [m][nb]
 };
 void launch_gmres_init(const GmresDev &S, const cplx *beta, const unsigned char *done, int use_mask, hipStream_t s);
-void launch_gmres_step(const GmresDev &S, const cplx *hd, int j, double tol, double lim, int use_mask, cplx *Vnew, int64_t n, hipStream_t s);
+void launch_gmres_step(const GmresDev &S, const cplx *hd, int j, double tol, double lim, int use_mask, cplx *Vnew, int64_t n, hipStream_t s,
+                       const cplx *rn = nullptr);     // rn (optional): the norm of the new vector, instead of hd[j+1]
+// pair steps (two Arnoldi steps per pass over the basis; kernels.hip)
+void launch_dots2_scaled(const cplx *V, size_t stride, int nv, const cplx *W1, const cplx *W2, int64_t n, int nb, cplx *partial, cplx *out1,
+                         cplx *out2, cplx *gram_out, const cplx *scale, hipStream_t s, const unsigned char *cmask = nullptr);
+void launch_axpy2_norm(const cplx *V, size_t stride, int nv, const cplx *c1, const cplx *c2m, const cplx *alpha, cplx *W1, cplx *W2, int64_t n, int nb,
+                       cplx *partial, cplx *norms, cplx *inv_out, hipStream_t s, const unsigned char *cmask = nullptr);
+void launch_gmres_pair_coef(const GmresDev &S, int j, const cplx *c1, const cplx *c2, const cplx *gram, cplx *alpha, cplx *c2m, cplx *hd2, hipStream_t s);
 void launch_gmres_solve_y(const GmresDev &S, int ju, cplx *out, hipStream_t s);
 // triad for bandwidth measurement
 void launch_triad(double *a, const double *b, const double *c, double s_, int64_t n, hipStream_t s);
