@@ -7,6 +7,7 @@
 #include "amg.h"
 #include <chrono>
 #include <cstdlib>
+#include <functional>
 #include <future>
 #include <thread>
 
@@ -63,15 +64,22 @@ template <class F> static void parallel_ranges(int64_t n, int nparts, F &&body) 
 // stitches per-part (col, val) pieces; ptr holds per-row counts in ptr[i+1] on entry
 template <class V> static void stitch(int64_t n, int nparts, std::vector<int> &ptr, std::vector<std::vector<int>> &pcol, std::vector<std::vector<V>> &pval,
                                       std::vector<int> &col, std::vector<V> &val) {
+    (void)nparts;
     for (int64_t i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
     col.resize((size_t)ptr[n]);
     val.resize((size_t)ptr[n]);
-    size_t off = 0;
-    for (size_t t = 0; t < pcol.size(); ++t) {
-        std::copy(pcol[t].begin(), pcol[t].end(), col.begin() + off);
-        std::copy(pval[t].begin(), pval[t].end(), val.begin() + off);
-        off += pcol[t].size();
-    }
+    // every part copies its own piece (the serial copy of 300 MB per product was a tenth of a second each at 1M unknowns)
+    std::vector<size_t> off(pcol.size() + 1, 0);
+    for (size_t t = 0; t < pcol.size(); ++t) off[t + 1] = off[t] + pcol[t].size();
+    std::vector<std::future<void>> jobs;
+    for (size_t t = 0; t < pcol.size(); ++t)
+        jobs.push_back(std::async(std::launch::async, [&, t]() {
+            std::copy(pcol[t].begin(), pcol[t].end(), col.begin() + off[t]);
+            std::copy(pval[t].begin(), pval[t].end(), val.begin() + off[t]);
+            std::vector<int>().swap(pcol[t]);
+            std::vector<V>().swap(pval[t]);
+        }));
+    for (auto &j : jobs) j.get();
 }
 
 // C = A * B   (row-wise Gustavson with a dense marker; columns sorted; structural zeros kept so that planes
@@ -262,18 +270,29 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
     // hierarchy and the iteration counts -- what they were before the renumbering.
     auto node = [&](int64_t k) -> int64_t { return visit ? (int64_t)(*visit)[k] : k; };
     std::vector<double> D(n);
-    for (int64_t i = 0; i < n; ++i) D[i] = std::fabs(diag_of(S, i));
+    parallel_ranges(n, setup_threads(), [&](int64_t lo, int64_t hi, int) { for (int64_t i = lo; i < hi; ++i) D[i] = std::fabs(diag_of(S, i)); });
     // strength graph (symmetric criterion), restricted to non-skipped nodes
     std::vector<int> gptr(n + 1, 0), gcol;
-    gcol.reserve(S.col.size());
-    for (int64_t i = 0; i < n; ++i) {
-        if (!skip[i])
-            for (int p = S.ptr[i]; p < S.ptr[i + 1]; ++p) {
-                const int j = S.col[p];
-                if (j == i || skip[j]) continue;
-                if (std::fabs(S.val[p]) >= theta * std::sqrt(D[i] * D[j])) gcol.push_back(j);
+    {
+        const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(setup_threads(), n / 4096 + 1));
+        std::vector<std::vector<int>> pcol(nparts);
+        parallel_ranges(n, nparts, [&](int64_t lo, int64_t hi, int part) {
+            std::vector<int> &oc = pcol[part];
+            for (int64_t i = lo; i < hi; ++i) {
+                int cnt = 0;
+                if (!skip[i])
+                    for (int p = S.ptr[i]; p < S.ptr[i + 1]; ++p) {
+                        const int j = S.col[p];
+                        if (j == i || skip[j]) continue;
+                        if (std::fabs(S.val[p]) >= theta * std::sqrt(D[i] * D[j])) { oc.push_back(j); ++cnt; }
+                    }
+                gptr[i + 1] = cnt;
             }
-        gptr[i + 1] = (int)gcol.size();
+        });
+        for (int64_t i = 0; i < n; ++i) gptr[i + 1] += gptr[i];
+        gcol.resize((size_t)gptr[n]);
+        size_t off = 0;
+        for (auto &v : pcol) { std::copy(v.begin(), v.end(), gcol.begin() + off); off += v.size(); }
     }
     std::vector<int> agg(n, -1);
     int na = 0;
@@ -313,36 +332,47 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
         Pt.ptr[i + 1] = (int)Pt.col.size();
     }
     if (!smooth) return Pt;
-    // filtered matrix F: strong couplings + diagonal, weak couplings lumped onto the diagonal
+    // filtered matrix F: strong couplings + diagonal, weak couplings lumped onto the diagonal (rows independent: host threads)
     CsrD F;
     F.n = n; F.m = n;
     F.ptr.assign(n + 1, 0);
     std::vector<double> Fd(n, 1.0);
-    for (int64_t i = 0; i < n; ++i) {
-        if (!skip[i]) {
-            double dg = 0.0;
-            int gp = gptr[i];
-            size_t dpos = (size_t)-1;
-            for (int p = S.ptr[i]; p < S.ptr[i + 1]; ++p) {
-                const int j = S.col[p];
-                if (j == i) { dg += S.val[p]; dpos = F.col.size(); F.col.push_back(j); F.val.push_back(0.0); continue; }
-                if (skip[j]) continue;           // coupling to a penalty node: eliminated (value there is ~0)
-                // strong neighbours are listed in column order in gcol
-                while (gp < gptr[i + 1] && gcol[gp] < j) ++gp;
-                if (gp < gptr[i + 1] && gcol[gp] == j) { F.col.push_back(j); F.val.push_back(S.val[p]); }
-                else dg += S.val[p];
+    {
+        const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(setup_threads(), n / 4096 + 1));
+        std::vector<std::vector<int>> pcol(nparts);
+        std::vector<std::vector<double>> pval(nparts);
+        parallel_ranges(n, nparts, [&](int64_t lo, int64_t hi, int part) {
+            std::vector<int> &oc = pcol[part];
+            std::vector<double> &ov = pval[part];
+            for (int64_t i = lo; i < hi; ++i) {
+                const size_t row0 = oc.size();
+                if (!skip[i]) {
+                    double dg = 0.0;
+                    int gp = gptr[i];
+                    size_t dpos = (size_t)-1;
+                    for (int p = S.ptr[i]; p < S.ptr[i + 1]; ++p) {
+                        const int j = S.col[p];
+                        if (j == i) { dg += S.val[p]; dpos = oc.size(); oc.push_back(j); ov.push_back(0.0); continue; }
+                        if (skip[j]) continue;           // coupling to a penalty node: eliminated (value there is ~0)
+                        // strong neighbours are listed in column order in gcol
+                        while (gp < gptr[i + 1] && gcol[gp] < j) ++gp;
+                        if (gp < gptr[i + 1] && gcol[gp] == j) { oc.push_back(j); ov.push_back(S.val[p]); }
+                        else dg += S.val[p];
+                    }
+                    if (dpos == (size_t)-1) {   // structurally missing diagonal: insert it in column order
+                        oc.push_back((int)i); ov.push_back(0.0);
+                        size_t q = oc.size() - 1;
+                        while (q > row0 && oc[q - 1] > oc[q]) { std::swap(oc[q - 1], oc[q]); std::swap(ov[q - 1], ov[q]); --q; }
+                        dpos = q;
+                    }
+                    if (dg == 0.0) dg = 1.0;
+                    ov[dpos] = dg;
+                    Fd[i] = dg;
+                }
+                F.ptr[i + 1] = (int)(oc.size() - row0);
             }
-            if (dpos == (size_t)-1) {   // structurally missing diagonal: insert it in column order
-                F.col.push_back((int)i); F.val.push_back(0.0);
-                size_t q = F.col.size() - 1;
-                while (q > (size_t)F.ptr[i] && F.col[q - 1] > F.col[q]) { std::swap(F.col[q - 1], F.col[q]); std::swap(F.val[q - 1], F.val[q]); --q; }
-                dpos = q;
-            }
-            if (dg == 0.0) dg = 1.0;
-            F.val[dpos] = dg;
-            Fd[i] = dg;
-        }
-        F.ptr[i + 1] = (int)F.col.size();
+        });
+        stitch(n, nparts, F.ptr, pcol, pval, F.col, F.val);
     }
     // spectral radius of D^-1 F by power iteration
     std::vector<double> x(n), y(n);
@@ -373,31 +403,44 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
     CsrD P;
     P.n = n; P.m = na;
     P.ptr.assign(n + 1, 0);
-    for (int64_t i = 0; i < n; ++i) {
-        if (!skip[i]) {
-            const int a = agg[i];
-            bool seen = false;
-            for (int p = FP.ptr[i]; p < FP.ptr[i + 1]; ++p) {
-                double v = -omega * FP.val[p] / Fd[i];
-                if (FP.col[p] == a) { v += 1.0; seen = true; }
-                P.col.push_back(FP.col[p]);
-                P.val.push_back(v);
+    {
+        const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(setup_threads(), n / 4096 + 1));
+        std::vector<std::vector<int>> pcol(nparts);
+        std::vector<std::vector<double>> pval(nparts);
+        parallel_ranges(n, nparts, [&](int64_t lo, int64_t hi, int part) {
+            std::vector<int> &oc = pcol[part];
+            std::vector<double> &ov = pval[part];
+            for (int64_t i = lo; i < hi; ++i) {
+                const size_t row0 = oc.size();
+                if (!skip[i]) {
+                    const int a = agg[i];
+                    bool seen = false;
+                    for (int p = FP.ptr[i]; p < FP.ptr[i + 1]; ++p) {
+                        double v = -omega * FP.val[p] / Fd[i];
+                        if (FP.col[p] == a) { v += 1.0; seen = true; }
+                        oc.push_back(FP.col[p]);
+                        ov.push_back(v);
+                    }
+                    if (!seen && a >= 0) {   // keep sorted order
+                        oc.push_back(a);
+                        ov.push_back(1.0);
+                        size_t q = oc.size() - 1;
+                        while (q > row0 && oc[q - 1] > oc[q]) { std::swap(oc[q - 1], oc[q]); std::swap(ov[q - 1], ov[q]); --q; }
+                    }
+                }
+                P.ptr[i + 1] = (int)(oc.size() - row0);
             }
-            if (!seen && a >= 0) {   // keep sorted order
-                P.col.push_back(a);
-                P.val.push_back(1.0);
-                int q = (int)P.col.size() - 1;
-                while (q > P.ptr[i] && P.col[q - 1] > P.col[q]) { std::swap(P.col[q - 1], P.col[q]); std::swap(P.val[q - 1], P.val[q]); --q; }
-            }
-        }
-        P.ptr[i + 1] = (int)P.col.size();
+        });
+        stitch(n, nparts, P.ptr, pcol, pval, P.col, P.val);
     }
     return P;
 }
 
 void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, const AmgOptions &opt, std::vector<AmgLevel> &levels,
-               std::vector<char> *penalty_rows, const std::vector<zc> *pc_shape, const std::vector<int> *visit0) {
+               std::vector<char> *penalty_rows, const std::vector<zc> *pc_shape, const std::vector<int> *visit0,
+               const std::function<void(const AmgLevel &)> &on_level) {
     levels.clear();
+    levels.reserve((size_t)opt.max_levels + 1);             // (on_level may keep a reference to a level while the next ones are built)
     const bool dbg = getenv("WAE_SETUP_DEBUG") != nullptr;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tq = now();
@@ -415,23 +458,34 @@ void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, c
     S.n = S.m = n0;
     S.ptr.assign(n0 + 1, 0);
     {
-        CsrZ At = csr_transpose(Aref);
-        for (int64_t i = 0; i < n0; ++i) {
-            int q = At.ptr[i];
-            const int qe = At.ptr[i + 1];
-            for (int p = Aref.ptr[i]; p < Aref.ptr[i + 1]; ++p) {
-                const int j = Aref.col[p];
-                while (q < qe && At.col[q] < j) ++q;
-                const bool mirrored = q < qe && At.col[q] == j;
-                const double aij = std::abs(Aref.val[p]);
-                const double aji = mirrored ? std::abs(At.val[q]) : 0.0;
-                if (j == i || (mirrored && aji >= 0.25 * aij && aij >= 0.25 * aji)) {
-                    S.col.push_back(j);
-                    S.val.push_back(Aref.val[p].real());
+        // (the mirror entry a_ji is looked up in row j -- columns are sorted -- instead of in a transposed copy: rows are
+        // independent, so the host threads divide them; same entries, same values as the transpose-based loop)
+        const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(setup_threads(), n0 / 4096 + 1));
+        std::vector<std::vector<int>> pcol(nparts);
+        std::vector<std::vector<double>> pval(nparts);
+        parallel_ranges(n0, nparts, [&](int64_t lo, int64_t hi, int part) {
+            std::vector<int> &oc = pcol[part];
+            std::vector<double> &ov = pval[part];
+            for (int64_t i = lo; i < hi; ++i) {
+                int cnt = 0;
+                for (int p = Aref.ptr[i]; p < Aref.ptr[i + 1]; ++p) {
+                    const int j = Aref.col[p];
+                    bool keep = j == i;
+                    if (!keep) {
+                        const int *b = Aref.col.data() + Aref.ptr[j], *e = Aref.col.data() + Aref.ptr[j + 1];
+                        const int *f = std::lower_bound(b, e, (int)i);
+                        if (f != e && *f == (int)i) {
+                            const double aij = std::abs(Aref.val[p]);
+                            const double aji = std::abs(Aref.val[(size_t)(f - Aref.col.data())]);
+                            keep = aji >= 0.25 * aij && aij >= 0.25 * aji;
+                        }
+                    }
+                    if (keep) { oc.push_back(j); ov.push_back(Aref.val[p].real()); ++cnt; }
                 }
+                S.ptr[i + 1] = cnt;
             }
-            S.ptr[i + 1] = (int)S.col.size();
-        }
+        });
+        stitch(n0, nparts, S.ptr, pcol, pval, S.col, S.val);
     }
     std::vector<double> dabs(n0);
     for (int64_t i = 0; i < n0; ++i) {
@@ -472,6 +526,7 @@ void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, c
         lap("galerkin products");
         L.coarse_planes = next;
         levels.push_back(std::move(L));
+        if (on_level) on_level(levels.back());
         n = S.n;
         skip.assign(n, 0);
         cur.swap(next);

@@ -1,5 +1,7 @@
 // Host-side multigrid set-up (smoothed aggregation) -- declarations.
 #pragma once
+#include <functional>
+
 #include "wae_internal.h"
 
 struct AmgOptions {
@@ -20,5 +22,8 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
 // from, when that should not be the full reference operator (Bloch families: without the seam couplings, so that no
 // aggregate spans the seam across which the solution jumps by exp(i b 2pi/N)).
 // visit0 (optional): order in which the fine-level aggregation visits the nodes (see build_prolongator).
+// on_level (optional): called with every level right after its planes have been formed (the caller may start work that needs
+// only that level -- the tile plan of level 1 -- on another thread while the deeper levels are built; the reference stays valid).
 void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, const AmgOptions &opt, std::vector<AmgLevel> &levels,
-               std::vector<char> *penalty_rows = nullptr, const std::vector<zc> *pc_shape = nullptr, const std::vector<int> *visit0 = nullptr);
+               std::vector<char> *penalty_rows = nullptr, const std::vector<zc> *pc_shape = nullptr, const std::vector<int> *visit0 = nullptr,
+               const std::function<void(const AmgLevel &)> &on_level = nullptr);

@@ -227,9 +227,14 @@ static std::vector<int> build_levelop(LevelOp &L, const std::vector<CsrZ> &plane
         // transpose orientation (exact symmetry test: bitwise)
         std::vector<CsrZ> tr;
         bool sym = (A0.n == A0.m);
-        for (int q : g.members) {
-            tr.push_back(csr_transpose(planes[q]));
-            if (sym && !(tr.back().ptr == planes[q].ptr && tr.back().col == planes[q].col && tr.back().val == planes[q].val)) sym = false;
+        {
+            std::vector<std::future<CsrZ>> tj;
+            for (int q : g.members) tj.push_back(std::async(std::launch::async, [&planes, q]() { return csr_transpose(planes[q]); }));
+            for (size_t k = 0; k < tj.size(); ++k) {
+                const int q = g.members[k];
+                tr.push_back(tj[k].get());
+                if (sym && !(tr.back().ptr == planes[q].ptr && tr.back().col == planes[q].col && tr.back().val == planes[q].val)) sym = false;
+            }
         }
         G.symmetric = sym;
         std::vector<CsrZ> kept;
@@ -1773,20 +1778,42 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
         const double t_amg0 = now_s();
         // The Krylov basis -- (restart + 1) vectors of d x NB complex numbers, 42 GB at 1M unknowns -- takes the driver about a
         // second to map: it is requested now, on a helper thread, and is there when the host part of the set-up is done.
+        // opts[8], opts[9] (hints): probe columns and snapshot capacity of the contour integrals to come -- their snapshot store
+        // (5 GB at 1M unknowns x 8 columns x 40 snapshots) and the resident term products (20 GB) are then mapped here as well,
+        // behind the host work, instead of in the first pass (0.4 s of its snapshot phase).
         std::future<void> basis_job;
         {
             const size_t vec = (size_t)h->d * h->NB, need = vec * (size_t)(h->restart + 1);
-            if (h->V.n != need)
-                basis_job = std::async(std::launch::async, [h, need]() {
+            const size_t hint_l = (size_t)opt(8, 0.0), hint_s = (size_t)opt(9, 0.0);
+            const size_t need_q = hint_l > 0 && hint_s > 0 && hint_l <= (size_t)h->NB ? (size_t)h->d * hint_l * hint_s : 0;
+            const size_t need_w = need_q * (size_t)h->nplanes;
+            h->rb.wait_w();
+            if (h->V.n != need || h->rbQ.n < need_q || h->rb.W.n < need_w)
+                basis_job = std::async(std::launch::async, [h, need, need_q, need_w]() {
                     HIP_CHECK(hipSetDevice(h->device));
-                    h->V.alloc(need);
+                    if (h->V.n != need) h->V.alloc(need);
+                    if (h->rbQ.n < need_q) h->rbQ.alloc(need_q);
+                    if (h->rb.W.n < need_w) h->rb.W.alloc(need_w);
                 });
         }
         struct Join { std::future<void> &f; ~Join() { if (f.valid()) f.wait(); } } basis_join{basis_job};     // (also on an exception)
         // fine-level aggregation in the caller's node order (iperm[o] = internal index of the caller's node o)
         std::vector<int> visit0;
         if (!h->perm_h.empty()) { visit0.resize(h->perm_h.size()); for (size_t i = 0; i < h->perm_h.size(); ++i) visit0[h->perm_h[i]] = (int)i; }
-        amg_setup(h->planes0, pc, ao, lv, &pen, excl ? &pc_shape : nullptr, visit0.empty() ? nullptr : &visit0);
+        // The tile plan of level 1 needs only that level's sparsity pattern: it is computed on a helper thread while the host
+        // builds the deeper levels (0.3 s at 1M unknowns, hidden behind the second prolongator and its triple products).
+        const int tile1 = getenv("WAE_TILE_LEVEL1") ? atoi(getenv("WAE_TILE_LEVEL1")) : 1;      // (read per call: the tests switch it)
+        std::future<TilePlan> plan_job;
+        struct JoinPlan { std::future<TilePlan> &f; ~JoinPlan() { if (f.valid()) f.wait(); } } plan_join{plan_job};
+        const bool want_plan = tile1 && !h->tile_row_ptr.empty();
+        amg_setup(h->planes0, pc, ao, lv, &pen, excl ? &pc_shape : nullptr, visit0.empty() ? nullptr : &visit0,
+                  [&](const AmgLevel &L) {
+                      if (!want_plan || plan_job.valid() || &L != &lv[0]) return;
+                      const int wcap = getenv("WAE_TILE_WCAP1") ? atoi(getenv("WAE_TILE_WCAP1")) : 608;        // (two window buffers)
+                      const int thick = getenv("WAE_TILE_THICK") ? atoi(getenv("WAE_TILE_THICK")) : 6;
+                      const std::vector<CsrZ> *pl = &L.coarse_planes;
+                      plan_job = std::async(std::launch::async, [pl, wcap, thick]() { return plan_tiles(union_pattern(*pl), 128, wcap, thick); });
+                  });
         const double t_amg1 = now_s();
         if (getenv("WAE_SETUP_DEBUG")) {
             fprintf(stderr, "[setup] amg_setup (host) %.3f s\n", t_amg1 - t_amg0);
@@ -1800,19 +1827,29 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
             }
         }
         hipStream_t st = h->stream;
+        double t_lap = now_s();
+        auto lap = [&](const char *what) {
+            if (!getenv("WAE_SETUP_DEBUG")) return;
+            HIP_CHECK(hipStreamSynchronize(st));
+            const double t = now_s();
+            fprintf(stderr, "[setup] %-34s %.3f s\n", what, t - t_lap);
+            t_lap = t;
+        };
         // Level 1 renumbered into tiles as well (the numbering of a coarse level is nobody's business but the hierarchy's): its
         // operator -- ~48 nonzeros per row, gathered from L2 at 1 KB per nonzero and launch -- then runs through the tile kernel.
         // P of level 0 changes its columns, R its rows; the transfer to level 2 the other way round.
         std::vector<int> tile1_row_ptr;
-        const int tile1 = getenv("WAE_TILE_LEVEL1") ? atoi(getenv("WAE_TILE_LEVEL1")) : 1;      // (read per call: the tests switch it)
-        if (tile1 && lv.size() >= 2 && !h->tile_row_ptr.empty()) {
+        if (plan_job.valid() && lv.size() < 2) plan_job.get();           // (a two-level hierarchy: level 1 is the dense one)
+        if (plan_job.valid() && lv.size() >= 2) {
             const double tq0 = now_s();
-            const int wcap = getenv("WAE_TILE_WCAP1") ? atoi(getenv("WAE_TILE_WCAP1")) : 608;        // (two window buffers)
-            const int thick = getenv("WAE_TILE_THICK") ? atoi(getenv("WAE_TILE_THICK")) : 6;
-            TilePlan plan = plan_tiles(union_pattern(lv[0].coarse_planes), 128, wcap, thick);
+            TilePlan plan = plan_job.get();
             if (!plan.perm.empty()) {
                 const std::vector<int> &pm = plan.perm, &ip = plan.iperm;
-                for (CsrZ &A : lv[0].coarse_planes) A = permute_symmetric(A, pm, ip);
+                {
+                    std::vector<std::future<void>> pj;
+                    for (CsrZ &A : lv[0].coarse_planes) pj.push_back(std::async(std::launch::async, [&A, &pm, &ip]() { A = permute_symmetric(A, pm, ip); }));
+                    for (auto &j : pj) j.get();
+                }
                 auto rename_cols = [&](CsrD &A) {            // column c -> ip[c], rows re-sorted
                     std::vector<std::pair<int, double>> row;
                     for (int64_t i = 0; i < A.n; ++i) {
@@ -1835,14 +1872,20 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
                     }
                     A = std::move(B);
                 };
-                rename_cols(lv[0].P); permute_rows(lv[0].R);
-                permute_rows(lv[1].P); rename_cols(lv[1].R);
+                {
+                    auto j1 = std::async(std::launch::async, [&]() { rename_cols(lv[0].P); });
+                    auto j2 = std::async(std::launch::async, [&]() { permute_rows(lv[0].R); });
+                    auto j3 = std::async(std::launch::async, [&]() { permute_rows(lv[1].P); });
+                    rename_cols(lv[1].R);
+                    j1.get(); j2.get(); j3.get();
+                }
                 tile1_row_ptr = plan.row_ptr;
             }
             if (getenv("WAE_SETUP_DEBUG"))
                 fprintf(stderr, "[setup] level 1 tile plan + permutation %.3f s (%zu tiles, largest window %d)\n", now_s() - tq0,
                         plan.row_ptr.empty() ? (size_t)0 : plan.row_ptr.size() - 1, plan.wmax);
         }
+        lap("level-1 plan + permutation");
         {   // the penalty rows' own sub-block, plane by plane (compact numbering)
             std::vector<int> rows, loc(pen.size(), -1);
             for (size_t i = 0; i < pen.size(); ++i)
@@ -1882,27 +1925,48 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
                 HIP_CHECK(hipStreamSynchronize(st));
             }
         }
+        lap("penalty operators");
         h->ops.resize(lv.size() + 1);
         h->slot_plane.resize(lv.size() + 1);
         h->xfer.resize(lv.size());
+        // the transfer operators of level 0 and the tile storage of the restriction: on a helper thread with a stream of its own,
+        // beside the level-1 operator (nothing shared but the device)
+        std::future<void> xfer0_job;
+        struct JoinX { std::future<void> &f; ~JoinX() { if (f.valid()) f.wait(); } } xfer0_join{xfer0_job};
+        auto upload_transfer = [](Transfer &X, const AmgLevel &L, hipStream_t s2) {
+            X.nf = L.P.n; X.nc = L.P.m;
+            X.p_ptr.upload(L.P.ptr.data(), L.P.ptr.size(), s2);
+            X.p_col.upload(L.P.col.data(), L.P.col.size(), s2);
+            X.p_val.upload(L.P.val.data(), L.P.val.size(), s2);
+            X.r_ptr.upload(L.R.ptr.data(), L.R.ptr.size(), s2);
+            X.r_col.upload(L.R.col.data(), L.R.col.size(), s2);
+            X.r_val.upload(L.R.val.data(), L.R.val.size(), s2);
+            HIP_CHECK(hipStreamSynchronize(s2));
+        };
+        if (!lv.empty()) {
+            const bool with_tiles = !tile1_row_ptr.empty();
+            xfer0_job = std::async(std::launch::async, [h, &lv, upload_transfer, with_tiles]() {
+                HIP_CHECK(hipSetDevice(h->device));
+                hipStream_t s2;
+                HIP_CHECK(hipStreamCreate(&s2));
+                struct Del { hipStream_t s; ~Del() { (void)hipStreamDestroy(s); } } del{s2};
+                upload_transfer(h->xfer[0], lv[0], s2);
+                if (with_tiles) {
+                    const int wcap = getenv("WAE_TILE_WCAP1") ? atoi(getenv("WAE_TILE_WCAP1")) : 608;
+                    const int tile_r = getenv("WAE_TILE_RESTRICT") ? atoi(getenv("WAE_TILE_RESTRICT")) : 1;
+                    if (tile_r) build_restriction_tiles(h->xfer[0], lv[0].R, wcap, s2);
+                }
+            });
+        }
         for (size_t l = 0; l < lv.size(); ++l) {
             h->slot_plane[l + 1] = build_levelop(h->ops[l + 1], lv[l].coarse_planes, st);
+            if (l == 0) lap("level-1 operator (groups, upload)");
             if (l == 0 && !tile1_row_ptr.empty()) build_level_tiles(h->ops[1], lv[0].coarse_planes, h->slot_plane[1], tile1_row_ptr, st, 4);
-            Transfer &X = h->xfer[l];
-            X.nf = lv[l].P.n; X.nc = lv[l].P.m;
-            X.p_ptr.upload(lv[l].P.ptr.data(), lv[l].P.ptr.size(), st);
-            X.p_col.upload(lv[l].P.col.data(), lv[l].P.col.size(), st);
-            X.p_val.upload(lv[l].P.val.data(), lv[l].P.val.size(), st);
-            X.r_ptr.upload(lv[l].R.ptr.data(), lv[l].R.ptr.size(), st);
-            X.r_col.upload(lv[l].R.col.data(), lv[l].R.col.size(), st);
-            X.r_val.upload(lv[l].R.val.data(), lv[l].R.val.size(), st);
-            HIP_CHECK(hipStreamSynchronize(st));
-            if (l == 0 && !tile1_row_ptr.empty()) {
-                const int wcap = getenv("WAE_TILE_WCAP1") ? atoi(getenv("WAE_TILE_WCAP1")) : 608;
-                const int tile_r = getenv("WAE_TILE_RESTRICT") ? atoi(getenv("WAE_TILE_RESTRICT")) : 1;
-                if (tile_r) build_restriction_tiles(X, lv[0].R, wcap, st);
-            }
+            if (l == 0) lap("level-1 tile storage");
+            if (l == 0) { xfer0_job.get(); lap("transfer + restriction tiles (helper thread): wait"); }
+            else upload_transfer(h->xfer[l], lv[l], st);
         }
+        lap("levels >= 2");
         // dense planes of the coarsest level (plane order, row-major)
         const std::vector<CsrZ> &last = lv.empty() ? h->planes0 : lv.back().coarse_planes;
         h->nc = last[0].n;
@@ -1921,6 +1985,7 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
             h->Ainv.alloc(nn * h->NB);
             h->dstatus.alloc(1);
         }
+        lap("dense coarsest level");
         // workspaces
         const int NB = h->NB, m = h->restart;
         const int nl = (int)h->ops.size();
@@ -1930,7 +1995,9 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
             h->lx[l].alloc(cnt); h->lb[l].alloc(cnt); h->lt[l].alloc(cnt);
         }
         const size_t vec = (size_t)h->d * NB;
+        lap("level workspaces");
         if (basis_job.valid()) basis_job.get();                      // (rethrows an allocation failure)
+        lap("wait for the Krylov basis");
         if (h->V.n != vec * (m + 1)) h->V.alloc(vec * (m + 1));
         h->W.alloc(vec); h->Xs.alloc(vec); h->Bs.alloc(vec); h->U.alloc(vec);
         // masked (converged) columns keep stale data: make sure "stale" is never an uninitialised NaN pattern
@@ -1951,6 +2018,7 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
         if (h->h_pinned) { (void)hipHostFree(h->h_pinned); h->h_pinned = nullptr; }
         HIP_CHECK(hipHostMalloc((void **)&h->h_pinned, (size_t)(m + 2) * NB * sizeof(cplx)));
         h->solver_ready = true;
+        lap("other workspaces + memsets");
         if (getenv("WAE_SETUP_DEBUG")) fprintf(stderr, "[setup] uploads + workspaces %.3f s\n", now_s() - t_amg1);
         return WAE_OK;
     });

