@@ -67,17 +67,24 @@ def cpu_baseline(l, N, n_in, d_bench, tau, n_flame, budget_s=30.0):
             spent += dt
             if len(rows) >= 2 and spent + 2.5 * dt > budget_s:
                 break
+    measured = None                  # one reference-shaped point at BASELINE configs[1] size, timed on the build container (dev/cpu_point_c2.py)
+    mfile = os.path.join(ROOT, "profiles", "r03_cpu_point_C2.json")
+    if os.path.exists(mfile):
+        measured = json.load(open(mfile))
     p = float(np.polyfit(np.log([r["d"] for r in rows]), np.log([r["seconds_per_point"] for r in rows]), 1)[0])
     t_bench = rows[-1]["seconds_per_point"] * (d_bench / rows[-1]["d"]) ** p
     npts = 4 * N
     return {"value": n_in / (npts * t_bench), "unit": "eigenpairs/sec", "cores": 1, "kind": "port", "extrapolated": True,
             "host_cores": os.cpu_count(), "exponent": p, "seconds_per_point_at_benchmark_size": t_bench, "samples": rows,
             "tau": tau, "n": n_flame,
+            "measured_point_C2": measured,
             "sample": f"1 quadrature point (assemble L(z) + SuperLU + {l} solves = the reference's per-point work, beyn.jl:62-71) on "
                       f"annulus meshes of {', '.join(str(r['d']) for r in rows)} DoF with the GPU leg's flame parameters, 1 of the host's "
                       f"{os.cpu_count()} cores; t_point ~ d^{p:.2f} extrapolated to d = {d_bench}: {t_bench:.0f} s per point, "
                       f"value = {n_in} eigenpairs / ({npts} points x t_point).  A lower bound on the CPU time: the fill exponent grows "
-                      f"with d (offline: 579 s per point at 199 680 DoF)."}
+                      f"with d" + (f" (measured, profiles/r03_cpu_point_C2.json: {measured['seconds_per_point']:.0f} s and {measured['peak_rss_GB']:.1f} GB for ONE "
+                                   f"point at {measured['d']} DoF, l = {measured['l']}, one core of the build container; the ladder's power law "
+                                   f"gives {rows[-1]['seconds_per_point'] * (measured['d'] / rows[-1]['d']) ** p:.0f} s there)." if measured else ".")}
 
 
 def main():
@@ -88,6 +95,9 @@ def main():
     ap.add_argument("--preset", default="C3")
     ap.add_argument("--l", type=int, default=8)
     ap.add_argument("--N", type=int, default=64)
+    ap.add_argument("--K", type=int, default=2,
+                    help="moments 0..2K-1 (beyn.jl:50-52).  K = 2 makes the Hankel matrix l*K = 16 columns wide from the same 2 048 solves: "
+                         "the 8 eigenvalues inside then show as a GAP in the singular values (rank_gap) instead of saturating an 8-column matrix")
     ap.add_argument("--tol", type=float, default=1e-10)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--restart", type=int, default=40)
@@ -154,7 +164,9 @@ def main():
     zr, wr = shard_points(zs, ws, rank, world)           # round-robin shard of the quadrature points
     # probe matrix (beyn.jl:43, random=true), seeded; column-major like the Julia array the reference would hand over
     V = np.asfortranarray(np.random.default_rng(7).standard_normal((d, args.l)) + 0j)
-    K = 1
+    K = args.K
+    # K > 1: moments in z' = (z - centre)/radius of the contour (same systems, better-conditioned Hankel matrix; see distributed.py)
+    zmap = (complex(np.mean(G)), float(np.max(np.abs(G - np.mean(G))))) if (K > 1 and args.rb > 0) else None
     buf = torch.zeros(d * args.l * 2 * K * 2, dtype=torch.float64, device=f"cuda:{local}")
 
     tim = {}
@@ -165,7 +177,7 @@ def main():
         if args.rb > 0:
             # snapshot points -> all-gather of the snapshot store -> projected initial guesses -> all-reduce of the moments
             ph = {}
-            buf, info = beyn_moments_distributed_rb(L, G, V, K, args.N, args.rb, timings=ph)
+            buf, info = beyn_moments_distributed_rb(L, G, V, K, args.N, args.rb, timings=ph, zmap=zmap)
             t.append(t[0] + ph["snapshots"] + ph["allgather"] + ph["projected"])
             t.append(time.time())
             if rank == 0:
@@ -182,6 +194,8 @@ def main():
         if rank == 0:
             t.append(time.time())
             Om, Pd, S = moments2eigs_device(buf, (d, args.l, 2 * K))       # SVD on the GPU, small eig on the host
+            if zmap is not None:
+                Om = zmap[0] + zmap[1] * Om                                  # back from the mapped variable of the moments
             mask = np.array([inpoly(w, G) for w in Om], dtype=bool)         # pos_test (beyn.jl:104-107)
             Om = Om[mask]
             Pt = Pd[:, torch.from_numpy(mask).to(Pd.device)].T.contiguous()   # (n, d) row-major = column-major d x n, in HBM
@@ -243,7 +257,9 @@ def main():
         tri = _C.c_double(0.0)                 # device triad a = b + s*c over 2^27 doubles: the streaming rate this GPU attains
         _wl.check(_wl.lib().wae_bench_triad(int(os.environ.get("LOCAL_RANK", 0)), 1 << 27, 20, _C.byref(tri)))
         traffic = None       # HBM bytes per launch from the PMC passes committed under profiles/ (not collectable in-run)
-        tfile = os.path.join(ROOT, "profiles", f"r02_spmv_traffic_{args.preset}.json")
+        tfile = os.path.join(ROOT, "profiles", f"r03_spmv_traffic_{args.preset}.json")
+        if not os.path.exists(tfile):
+            tfile = os.path.join(ROOT, "profiles", f"r02_spmv_traffic_{args.preset}.json")
         if os.path.exists(tfile):
             tj = json.load(open(tfile))
             if tj.get("preset") == args.preset and tj.get("r") == rb:
@@ -254,17 +270,31 @@ def main():
                                           + ": one fused multi-term complex CSR operator product of the fine level, r columns",
                 "achieved": abytes / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": abytes / ms / 1e6 / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": os.path.relpath(tfile, ROOT) if traffic is not None else None,
                 "r": rb, "us_per_launch": ms * 1e3, "algorithmic_bytes": int(abytes),
                 "triad_GBps": tri.value, "frac_of_triad": abytes / ms / 1e6 / tri.value if tri.value else None,
-                "r1": {"us": ms1 * 1e3, "GB/s": fam.spmv_bytes(r=1, mask=mask) / ms1 / 1e6},
-                "r8": {"us": ms8 * 1e3, "GB/s": fam.spmv_bytes(r=8, mask=mask) / ms8 / 1e6}}
+                # narrow products: EFFECTIVE rates (algorithmic bytes / time).  Repeated launches re-read the matrix from the L2 /
+                # Infinity Cache, so these are not HBM rates and carry no fraction of the HBM peak.
+                "r1": {"us": ms1 * 1e3, "effective_GB/s": fam.spmv_bytes(r=1, mask=mask) / ms1 / 1e6, "note": "algorithmic bytes / time; cache-resident matrix, not an HBM rate"},
+                "r8": {"us": ms8 * 1e3, "effective_GB/s": fam.spmv_bytes(r=8, mask=mask) / ms8 / 1e6, "note": "algorithmic bytes / time; cache-resident matrix, not an HBM rate"}}
+        # the 4-lane instantiation of the tile kernel: the level-1 operator and the fine-to-coarse restriction (13-15 % of the kernel time)
+        try:
+            msl, bl = fam.bench_spmv_level(cz, which=0, level=1, r=rb, reps=50)
+            msr, br = fam.bench_spmv_level(cz, which=1, level=0, r=rb, reps=50)
+            roof["level1"] = {"kernel": "spmv_tile_kernel<true, 4, 2>: level-1 operator product, r columns", "us_per_launch": msl * 1e3,
+                              "algorithmic_bytes": int(bl), "achieved": bl / msl / 1e6, "frac": bl / msl / 1e6 / HBM_PEAK_GBS, "unit": "GB/s"}
+            roof["restriction"] = {"kernel": "spmv_tile_kernel<true, 4, 2> (unit coefficients): restriction level 0 -> 1, r columns",
+                                   "us_per_launch": msr * 1e3, "algorithmic_bytes": int(br), "achieved": br / msr / 1e6,
+                                   "frac": br / msr / 1e6 / HBM_PEAK_GBS, "unit": "GB/s"}
+        except Exception as e:          # noqa: BLE001  (a hierarchy without a tiled level 1)
+            roof["level1"] = {"error": str(e)}
         out = {
             "metric": "eigenpairs/sec", "value": n_eig * args.steps / dt, "unit": "eigenpairs/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"annular combustor Helmholtz NLEVP (P1), preset {args.preset}: d={d}, "
-                                   f"L(w)=w^2 M+K+w Y C+n exp(-i w tau) Q, Beyn l={args.l} K=1 N={args.N}/edge "
+                                   f"L(w)=w^2 M+K+w Y C+n exp(-i w tau) Q, Beyn l={args.l} K={K} N={args.N}/edge "
                                    f"({4 * args.N} shifted systems x {args.l} columns), contour 150..1000 Hz x +-150 Hz, inner tol {args.tol:g}",
                        "parallelism": ((f"{args.rb} snapshot points solved first, split by probe column over {world} GPU(s) "
                                         f"({args.l // world} columns each), their solutions all-gathered; " if args.l % world == 0 else
@@ -277,6 +307,8 @@ def main():
             "eigenpairs": n_eig, "eigenvalues_hz": [[float(x.real), float(x.imag)] for x in np.sort_complex(Om[good] / 2 / np.pi)],
             "eig_residual_max": float(r[good].max()) if n_eig else None, "n_inside_before_residual_test": int(len(Om)),
             "singular_values": [float(s) for s in S],
+            # the count certifies itself: singular value number n_inside against the next one (Hankel matrix d*K x l*K, beyn.jl:85-95)
+            "rank_gap": (float(S[n_eig - 1] / S[n_eig]) if 0 < n_eig < len(S) else None),
             "value_cold": int((first[1][1] <= 1e-6).sum()) / (t_setup + t_first) if first is not None else None,
             "cold": {"solver_setup_seconds": t_setup, "first_pass_seconds": t_first, "upload_seconds": t_upload,
                      "problem_build_seconds": t_build, "first_pass_breakdown_seconds": {k: round(v, 4) for k, v in tim_first.items()},

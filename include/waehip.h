@@ -176,6 +176,13 @@ int wae_eig_residuals(wae_family *h, int32_t n, const double *coeff_table, const
  *   mode 1: the store holds slot0 raw snapshots (e.g. all-gathered from several GPUs): orthonormalise them per
  *           column (in place), project every term, then process the npts points with projected initial guesses.
  *   mode 2: as mode 1 with the basis as mode 0 calls left it (no rebuild).
+ *   mode 3: solve the npts points from ZERO guesses, accumulate their moment contributions and write their solutions RAW into the
+ *           store slots slot0 .. slot0+npts-1; the handle's basis is not touched.  (A multi-GPU rank's share of the snapshot
+ *           points as full-width batches; another rank -- or mode 4 -- builds the basis.)
+ *   mode 4: the store holds slot0 raw snapshots of THIS call's l columns: orthonormalise them per column (in place) and project
+ *           every term that has a non-zero coefficient in the table (npts rows) -- then return: no system is solved, the
+ *           moments are not touched.  With mode 3 and the exchanges of wae_rb_export / wae_rb_import this is the "hybrid" split
+ *           of the snapshot phase over G GPUs: points for the solves, probe columns for the basis.
  *   (Environment WAE_RB_ENRICH=<n>: in modes 1/2 append a chunk of points that still needed more than n iterations to
  *   the basis while the store has room.  Off by default: it did not pay on the benchmark contour.)
  *   Q_dev : device pointer of the snapshot store, or 0 for a store owned by the handle; a caller-owned store is
@@ -276,10 +283,28 @@ int wae_p1_shape_sensitivity(int32_t device, int64_t npoints, const double *poin
                              const int32_t *pair_pt_s, const int32_t *pair_tri, int64_t ntets, int64_t ntris, const double *omega,
                              const double *omegaY, const double *v, const double *v_adj, double h, double *out_t, double *out_s);
 
+/* Flame part of the same sensitivity (a :flame entry in dscrp; shape_sensitivity.jl:62-141 with Helmholtz.jl:292-344,464-487):
+ * per (surface point, flame tetrahedron touching it) pair and coordinate, |det J| of the tetrahedron with the point moved by +h
+ * and -h (det_pm[pair][3][2]) and, per pair, the sum of conj(v_adj) over the tetrahedron's nodes (ssum, complex); per listed
+ * vertex of the reference tetrahedron (pair_pt_r) and coordinate, sum_b (grad(phi_b).n_ref) v_b on the reference tetrahedron with
+ * that vertex moved by +h / -h (g_pm[pair][3][2], complex) and the undisplaced value g0.  The caller (helmholtz/assemble.py,
+ * julia) sums the pairs of a point in order and forms  -v_adj' (Q+ - Q-)/(2h) v  with Q = S (x) g,  S_a = |det J|/24,
+ * g_b = -(nglobal_scaled / volume of the point's flame tetrahedra) grad(phi_b).n_ref  -- the reference re-discretises the flame
+ * domain REDUCED to the simplices at the point, volume included. */
+int wae_p1_shape_sensitivity_flame(int32_t device, int64_t npoints, const double *points, int64_t ntets, const int32_t *tets, int64_t npair,
+                                   const int32_t *pair_pt, const int32_t *pair_tet, int32_t ref_tet, int64_t npair_r, const int32_t *pair_pt_r,
+                                   const double *n_ref, const double *v, const double *v_adj, double h, double *det_pm, double *ssum,
+                                   double *g_pm, double *g0);
+
 /* -- measurement helpers (bench.py) --------------------------------------------------------------------
  * Time `reps` launches of the fused multi-term SpMV on device-resident data with HIP events on the
  * library's own stream; r right-hand sides.  ms_out = average milliseconds per launch. */
 int wae_bench_spmv(wae_family *h, const double *coeffs, int32_t r, int32_t reps, double *ms_out);
+/* the same for an operator of the multigrid hierarchy (which = 0: level operator `level`, 1: restriction from `level`), with its
+ * algorithmic bytes per launch (SURVEY 8d layout: 16 + 4 bytes per nonzero and plane with a non-zero coefficient -- 8 + 4 for the
+ * real restriction -- row pointers, input and output vectors touched once): the roofline line of the level-1 kernels. */
+int wae_bench_spmv_level(wae_family *h, const double *coeffs, int32_t which, int32_t level, int32_t r, int32_t reps, double *ms_out,
+                         int64_t *bytes_out);
 /* device triad a = b + s*c over n doubles: measured streaming bandwidth in GB/s */
 int wae_bench_triad(int32_t device, int64_t n, int32_t reps, double *gbs_out);
 

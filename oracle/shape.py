@@ -142,3 +142,79 @@ def normal_sensitivity(normal_vectors, normed_sens):
         nvec = normal_vectors[:, t]
         out[t] = np.dot(nvec / np.linalg.norm(nvec), normed_sens[:, t])
     return out
+
+
+# ---- unit cells of discretely rotationally symmetric meshes (shape_sensitivity.jl:27-35, 84-128; Meshutils.jl:946-964) ----
+def get_cylindrics(pnt):
+    """shape_sensitivity.jl:381-390: columns e_r, e_phi, e_z."""
+    X = np.zeros((3, 3))
+    X[:, 2] = [0, 0, 1]
+    X[:, 0] = pnt
+    X[2, 0] = 0.0
+    X[:, 0] /= np.linalg.norm(X[:, 0])
+    X[:, 1] = np.cross(X[:, 2], X[:, 0])
+    return X
+
+
+def discrete_adjoint_shape_sensitivity_unit(mesh, dscrp, c_tet, surface_points, Lb, sol, nsector, nxbloch, DOS, b, naxis=0, h=1e-9):
+    """shape_sensitivity.jl:16-141 for ``mesh.dos.unit``: cylindrical displacement directions, a point of the reference Bloch
+    boundary moves together with its image point (masks of the twins merged, Meshutils.jl:946-964), axis points are skipped;
+    each re-discretisation of the reduced mesh (extended numbering, image points last) is folded by ``blochify`` into the
+    Bloch operator at wave number ``b`` (the reference sets b = 1 there, :122-125; here the caller's).  ``Lb``: the oracle
+    Bloch family of the unperturbed cell (normalisation of the adjoint vector).  Returns (3, npoints_ext)."""
+    from . import bloch as OB
+    w0 = sol.params[sol.eigval]
+    v0 = sol.v / np.sqrt(np.vdot(sol.v, sol.v))
+    saved = (Lb.active, Lb.mode, dict(Lb.params))
+    Lb.active, Lb.mode = [Lb.eigval], "all"
+    Lb.params["b"] = complex(b)
+    v0_adj = sol.v_adj / np.conj(np.vdot(sol.v_adj, Lb(w0, 1) @ v0))
+    Lb.active, Lb.mode, Lb.params = saved[0], saved[1], saved[2]
+    npts = mesh.points.shape[0]
+    sens = np.zeros((3, npts), dtype=complex)
+    Yv = complex(dscrp["Outlet"][1][1]) if "Outlet" in dscrp else 1e15
+    fl = dscrp.get("Flame")
+    nv, tv = (complex(fl[1][7]), complex(fl[1][8])) if fl is not None else (0.0, 0.0)
+
+    def folded(pts_h, local):
+        mh.points = pts_h
+        D = H.discretize_p1(mh, local, c_tet)
+        ext = {k: sp_zero for k in ("M", "K", "C", "Q")}
+        for t in D.terms:
+            if t.operator in ext:
+                ext[t.operator] = t.coeff
+        Lf = OB.bloch_family(ext, nsector, DOS, naxis, Y=Yv, n=nv, tau=tv, b=b)
+        for k, val in Lb.params.items():
+            if k in Lf.params and k not in ("ω", "λ"):
+                Lf.params[k] = val
+        Lf.params["b"] = complex(b)
+        return Lf(w0)
+
+    import scipy.sparse as sps
+    sp_zero = sps.csc_matrix((npts, npts), dtype=complex)
+    for p in surface_points:
+        if p < naxis:
+            continue
+        bloch = naxis <= p < naxis + nxbloch
+        pb = npts - nxbloch + (p - naxis)
+        moved = [p, pb] if bloch else [p]
+        tets = np.nonzero(np.isin(mesh.tetrahedra, moved).any(axis=1))[0]
+        tris = np.nonzero(np.isin(mesh.triangles, moved).any(axis=1))[0]
+        mh = H.Mesh()
+        mh.triangles, mh.tetrahedra = mesh.triangles, mesh.tetrahedra
+        mh.domains = {}
+        for dom in dscrp:
+            dd = copy.deepcopy(mesh.domains[dom])
+            ks = set(int(k) for k in (tris if dd["dimension"] == 2 else tets))
+            dd["simplices"] = [s for s in dd["simplices"] if int(s) in ks]
+            mh.domains[dom] = dd
+        local = {dom: val for dom, val in dscrp.items() if mh.domains[dom]["simplices"]}
+        for crd in range(3):
+            pr, pl = mesh.points.copy(), mesh.points.copy()
+            for q in moved:
+                X = get_cylindrics(mesh.points[q])
+                pr[q] += h * X[:, crd]
+                pl[q] -= h * X[:, crd]
+            Dmat = (folded(pr, local) - folded(pl, local)) / (2 * h)
+            sens[crd, p] = -np.vdot(v0_adj, Dmat @ v0)
+    return sens

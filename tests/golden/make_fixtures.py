@@ -187,7 +187,54 @@ def rijke_flame():
     print("wrote rijke_flame.npz", len(flame), "flame tetrahedra, reference tetrahedron", ref)
 
 
+def rijke_shape_flame():
+    """Shape gradient of the ACTIVE-flame mode of the Rijke tube (n = 1, tau = 1e-3: the eigenvalue of G5) through ALL of dscrp,
+    the flame domain included (shape_sensitivity.jl:62-141 re-discretises every domain reduced to the simplices at the point; the
+    flame's volume and nlocal are therefore those of the reduced domain, Helmholtz.jl:325).  Oracle restatement with full
+    re-discretisations (oracle/shape.py); points: wall points that touch flame tetrahedra, the vertices of the reference
+    tetrahedron (the branch in which the reference gradient itself moves), outlet points and other wall points.
+    Unpinned by the reference (no recorded shape gradient exists).  Output: rijke_shape_flame.npz."""
+    from oracle import helmholtz_p1 as H
+    from oracle import shape as OSH
+    from oracle import solvers as OS
+    mesh, Lo = H.rijke_tube(os.path.join(REF, "docs/src/Rijke_mm.msh"), n=1.0, tau=0.001)
+    gamma, rho, Tu, Tb, P0, R = 1.4, 1.225, 300.0, 1200.0, 101325.0, 287.05
+    Q02U0 = P0 * (Tb / Tu - 1) * (np.pi * 0.025 ** 2) * gamma / (gamma - 1)
+    c = H.generate_field(mesh, lambda x, y, z: np.sqrt(gamma * R * Tu) if z < 0.0 else np.sqrt(gamma * R * Tb))
+    x_ref, n_ref = [0.0, 0.0, -0.00101], [0.0, 0.0, 1.0]
+    dscrp = {"Interior": ("interior", ()), "Outlet": ("admittance", ("Y", 1e15)),
+             "Flame": ("flame", (gamma, rho, Q02U0, x_ref, n_ref, "n", "τ", 1.0, 0.001))}
+    sol, n, flag = OS.mslp(Lo, 2 * np.pi * (171 + 59j), maxiter=30, tol=1e-11)          # -> 1075.3 + 372.1i (G5)
+    assert abs(sol.params["ω"] - (1075.325211506839 + 372.1017670372039j)) < 1e-6, sol.params["ω"]
+    tets = np.asarray(mesh.tetrahedra)
+    tris = np.asarray(mesh.triangles)
+    flame = np.asarray(mesh.domains["Flame"]["simplices"], dtype=np.int64)
+    outlet = np.asarray(mesh.domains["Outlet"]["simplices"], dtype=np.int64)
+    ref = H.find_tetrahedron_containing_point(mesh, x_ref)
+    surf = np.unique(tris)
+    flame_pts = np.unique(tets[flame])
+    wall_flame = np.intersect1d(surf, flame_pts)
+    rng = np.random.default_rng(1)
+    pick = np.concatenate([rng.choice(wall_flame, min(8, len(wall_flame)), replace=False), tets[ref],
+                           rng.choice(np.unique(tris[outlet]), 2, replace=False),
+                           rng.choice(np.setdiff1d(surf, flame_pts), 4, replace=False)])
+    pick = np.array(list(dict.fromkeys(int(p) for p in pick)), dtype=np.int64)
+    tri_mask, tet_mask = OSH.adjacency(mesh, pick)
+    sens = OSH.discrete_adjoint_shape_sensitivity(mesh, dscrp, c, pick, tri_mask, tet_mask, Lo, sol)
+    d2 = {k: v for k, v in dscrp.items() if k != "Flame"}
+    sens_noflame = OSH.discrete_adjoint_shape_sensitivity(mesh, d2, c, pick, tri_mask, tet_mask, Lo, sol)
+    np.savez_compressed(os.path.join(HERE, "rijke_shape_flame.npz"), omega=np.array([sol.params["ω"]]), v=sol.v, v_adj=sol.v_adj,
+                        surface_points=pick, sens=sens[:, pick], sens_without_flame=sens_noflame[:, pick],
+                        in_flame=np.isin(pick, flame_pts), in_ref=np.isin(pick, tets[ref]))
+    print("wrote rijke_shape_flame.npz  omega =", sol.params["ω"], " points", len(pick), " touching the flame", int(np.isin(pick, flame_pts).sum()),
+          " on the reference tetrahedron", int(np.isin(pick, tets[ref]).sum()),
+          " largest flame contribution", np.abs(sens[:, pick] - sens_noflame[:, pick]).max(), " |sens| max", np.abs(sens[:, pick]).max())
+
+
 if __name__ == "__main__":
+    if "--shape-flame" in sys.argv:
+        rijke_shape_flame()
+        sys.exit(0)
     if "--flame" in sys.argv:
         rijke_flame()
         sys.exit(0)

@@ -714,6 +714,94 @@ def test_finite_difference_shape_sensitivity_confirms_the_adjoint_gradient():
     Lp._drop_device()
 
 
+def test_shape_sensitivity_with_an_active_flame_matches_oracle_fixture():
+    """SURVEY 8 row f4, second half: the discrete-adjoint shape gradient through ALL of dscrp -- interior, admittance boundary AND
+    the flame domain (shape_sensitivity.jl:62-141; Helmholtz.jl:292-344,464-487) -- for the active-flame mode of the Rijke tube
+    (n = 1, tau = 1e-3: the eigenvalue of G5), against the oracle's restatement with full re-discretisations
+    (tests/golden/rijke_shape_flame.npz, written by make_fixtures.py --shape-flame).  Points: 8 wall points that touch flame
+    tetrahedra, the 4 vertices of the reference tetrahedron (the reference gradient itself moves), outlet and plain wall
+    points.  As in the reference the flame's volume is that of the REDUCED domain at the point.  Both sides difference with
+    h = 1e-9.  Unpinned by the reference (no recorded shape gradient exists)."""
+    import os
+    from wae_amd.helmholtz.assemble import discrete_adjoint_shape_sensitivity
+    from wae_amd.nlevp import Solution
+    m = np.load(os.path.join(F.GOLDEN_DIR, "rijke_mesh.npz"))
+    fl = np.load(os.path.join(F.GOLDEN_DIR, "rijke_flame.npz"))
+    g = np.load(os.path.join(F.GOLDEN_DIR, "rijke_shape_flame.npz"))
+    Lp = helmholtz_family(F.rijke_terms(), n=1.0, tau=1e-3)
+    w0 = complex(g["omega"][0])
+    assert abs(w0 - c(G["G5"]["omega"])) <= 1e-6
+    sol = Solution({**Lp.params, "ω": w0}, g["v"], g["v_adj"], "ω")
+    flame = {"flame_tets": fl["flame_tets"], "ref_tet": int(fl["ref_tet"]), "n_ref": fl["n_ref"], "nglobal_scaled": float(fl["nglobal_scaled"])}
+    sens = discrete_adjoint_shape_sensitivity(m["points"], m["tetrahedra"], m["c_tet"], g["surface_points"], sol, Lp,
+                                              bnd_tris=m["outlet_triangles"], bnd_c=m["outlet_c"], Y=1e15, flame=flame)
+    want = g["sens"]
+    scale = np.abs(want).max(axis=0)
+    assert np.all(np.abs(sens - want).max(axis=0) <= 2e-5 * scale + 1e-6), np.abs(sens - want).max(axis=0) / scale
+    # the flame term is what is being tested: it carries most of the gradient at the points that touch the flame ...
+    part = np.abs(want - g["sens_without_flame"]).max(axis=0)
+    assert g["in_flame"].sum() >= 8 and np.all(part[g["in_flame"]] > 1e-3 * scale[g["in_flame"]]) and part.max() > 1e4
+    # ... and nothing where the point's reduced flame domain is empty
+    none = discrete_adjoint_shape_sensitivity(m["points"], m["tetrahedra"], m["c_tet"], g["surface_points"], sol, Lp,
+                                              bnd_tris=m["outlet_triangles"], bnd_c=m["outlet_c"], Y=1e15)
+    assert np.all(np.abs(none - g["sens_without_flame"]).max(axis=0) <= 2e-5 * np.abs(g["sens_without_flame"]).max(axis=0) + 1e-6)
+    assert np.array_equal(np.abs(sens - none).max(axis=0) > 0, g["in_flame"])
+    # the reference's own cross-check: re-solve the eigenvalue for the displaced point (two points that touch the flame)
+    from wae_amd.helmholtz import shape as SH
+    pick = g["surface_points"][np.nonzero(g["in_flame"])[0][:2]]
+    adj = SH.discrete_adjoint_shape_sensitivity(m["points"], m["tetrahedra"], m["c_tet"], pick, sol, Lp, bnd_tris=m["outlet_triangles"],
+                                                bnd_c=m["outlet_c"], Y=1e15, flame=flame)
+    Lp.solver_ref = w0.real
+    fd = SH.forward_finite_differences_shape_sensitivity(m["points"], m["tetrahedra"], m["c_tet"], pick, Lp, sol, bnd_tris=m["outlet_triangles"],
+                                                         bnd_c=m["outlet_c"], h=1e-7, flame=flame)
+    sc = np.abs(adj).max(axis=0)
+    assert np.all(np.abs(fd - adj).max(axis=0) <= 2e-2 * sc), (fd, adj)
+    Lp._drop_device()
+
+
+def test_unit_cell_shape_sensitivity_matches_oracle():
+    """SURVEY 8 row f4: shape sensitivity on the unit cell of a Bloch-periodic problem (shape_sensitivity.jl:27-35,84-128;
+    Meshutils.jl:946-964): cylindrical displacement directions, Bloch-boundary points move with their image points, the operator
+    derivative is folded by blochify.  Device route: the Cartesian kernels on the cell's extended mesh with Bloch-extended
+    eigenvectors, combined along e_r, e_phi, e_z (helmholtz/shape.py).  Oracle: the reference's loop restated with full
+    re-discretisations and the oracle's blochify (oracle/shape.py, oracle/bloch.py).  Small cell (12-fold ring, 128 unknowns), wave
+    number b = 1, the first azimuthal mode; points: two on the reference Bloch boundary, three others on the outlet, two that touch
+    the flame.  Unpinned by the reference."""
+    from oracle import bloch as OB
+    from oracle import helmholtz_p1 as H
+    from oracle import shape as OSH
+    from wae_amd.helmholtz import shape as SH
+    from wae_amd.helmholtz.bloch import bloch_family
+    cell = annulus.build_unit_cell(grid=(4, 8, 4), DOS=12, tau=2e-4)
+    m = cell["info"]["mesh"]
+    f0 = m["flames"][0]
+    ns, nxb, DOS = cell["nsector"], cell["nxbloch"], cell["DOS"]
+    L = bloch_family(cell, b=1)
+    L.solver_ref = 2 * np.pi * 430.0
+    sol, n, flag = mslp(L, 2 * np.pi * 430.0, maxiter=30, tol=1e-10)
+    assert flag in (0, 1, 2) and 350 < sol.params["ω"].real / 2 / np.pi < 480
+    mesh = H.Mesh()
+    mesh.points = cell["points"].copy()
+    mesh.tetrahedra = m["tets"].astype(np.int64)
+    mesh.triangles = m["outlet_tris"].astype(np.int64)
+    mesh.domains = {"Interior": {"dimension": 3, "simplices": list(range(len(m["tets"])))},
+                    "Outlet": {"dimension": 2, "simplices": list(range(len(m["outlet_tris"])))},
+                    "Flame": {"dimension": 3, "simplices": [int(t) for t in f0["flame_tets"]]}}
+    dscrp = {"Interior": ("interior", ()), "Outlet": ("admittance", ("Y", 1e15)),
+             "Flame": ("flame", (2.0, 1.0, f0["nglobal_scaled"], list(f0["x_ref"]), list(f0["n_ref"]), "n", "τ", 1.0, 2e-4))}
+    surf = np.unique(mesh.triangles)
+    pick = np.array(sorted(set(int(p) for p in np.concatenate([
+        surf[surf < nxb][:2], np.random.default_rng(0).choice(surf[(surf >= nxb) & (surf < ns)], 3, replace=False),
+        np.unique(mesh.tetrahedra[f0["flame_tets"]])[:2]]))))
+    Lb = OB.bloch_family(cell["terms_ext"], ns, DOS, 0, Y=1e15, n=1.0, tau=2e-4, b=1)
+    want = OSH.discrete_adjoint_shape_sensitivity_unit(mesh, dscrp, m["c_tet"], pick, Lb, sol, ns, nxb, DOS, 1)[:, pick]
+    got = SH.discrete_adjoint_shape_sensitivity_unit_cell(cell, pick, sol, L, b=1)
+    scale = np.abs(want).max(axis=0)
+    assert np.all(scale > 1.0)
+    assert np.all(np.abs(got - want).max(axis=0) <= 2e-5 * scale), np.abs(got - want).max(axis=0) / scale
+    L._drop_device()
+
+
 def test_unnormalised_basis_range_guard_branch():
     """The wide-batch GMRES keeps its basis unnormalised and re-normalises a vector only when its stored norm leaves
     [1e-100, 1e100] -- a branch ordinary problems never reach.  WAE_LAZY_LIMIT=3 (read once per process, hence the child

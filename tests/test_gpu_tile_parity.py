@@ -91,10 +91,11 @@ def test_tile_kernel_at_benchmark_size_against_scipy(preset, d_expect):
     L._drop_device()
 
 
-@pytest.mark.parametrize("tail", ["1", "4"])
-def test_persistent_work_list_forced_onto_a_small_problem(tail):
-    """tests/tile_worker.py under WAE_TILE_GRID=8: 35 fine tiles on "8 CUs" -- static + dynamic draw, stealing, tail parts"""
-    env = dict(os.environ, WAE_TILE_GRID="8", WAE_TILE_TAIL=tail)
+@pytest.mark.parametrize("tail,waves", [("1", "8"), ("4", "8"), ("4", "16")])
+def test_persistent_work_list_forced_onto_a_small_problem(tail, waves):
+    """tests/tile_worker.py under WAE_TILE_GRID=8: 35 fine tiles on "8 CUs" -- static + dynamic draw, stealing, tail parts.
+    waves = 16: the 16-wavefront form of the fine-level kernel (four lanes per row; an option, slower: DESIGN 4b)."""
+    env = dict(os.environ, WAE_TILE_GRID="8", WAE_TILE_TAIL=tail, WAE_TILE_WAVES=waves)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tile_worker.py")], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     res = json.loads(out.stdout.strip().split("\n")[-1])

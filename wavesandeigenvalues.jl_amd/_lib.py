@@ -36,7 +36,7 @@ _lib = None
 EXPORTS = [
     "wae_last_error", "wae_device_count", "wae_version", "wae_family_create", "wae_family_destroy",
     "wae_family_info", "wae_family_spmv_bytes", "wae_spmv_sum", "wae_spmv_sum_cols", "wae_spmv_sum_multi", "wae_solver_setup",
-    "wae_solve", "wae_solve_guess", "wae_beyn_moments", "wae_beyn_moments_mgpu", "wae_beyn_moments_rb", "wae_rb_export", "wae_rb_import", "wae_eig_residuals", "wae_arnoldi_shiftinvert", "wae_arnoldi_shiftinvert_batch", "wae_perturb", "wae_p1_assemble", "wae_p1_assemble_boundary", "wae_p1_assemble_flame", "wae_p1_info", "wae_p1_get", "wae_p1_free", "wae_p1_shape_sensitivity", "wae_bench_spmv", "wae_bench_triad", "wae_debug_spmv",
+    "wae_solve", "wae_solve_guess", "wae_beyn_moments", "wae_beyn_moments_mgpu", "wae_beyn_moments_rb", "wae_rb_export", "wae_rb_import", "wae_eig_residuals", "wae_arnoldi_shiftinvert", "wae_arnoldi_shiftinvert_batch", "wae_perturb", "wae_p1_assemble", "wae_p1_assemble_boundary", "wae_p1_assemble_flame", "wae_p1_info", "wae_p1_get", "wae_p1_free", "wae_p1_shape_sensitivity", "wae_p1_shape_sensitivity_flame", "wae_bench_spmv", "wae_bench_spmv_level", "wae_bench_triad", "wae_debug_spmv",
 ]
 
 
@@ -95,8 +95,11 @@ def lib():
     i32p = C.POINTER(C.c_int32)
     L.wae_p1_shape_sensitivity.argtypes = [C.c_int32, C.c_int64, dp, i32p, dp, C.c_int64, i32p, i32p, i32p, dp, C.c_int64, i32p, i32p,
                                            C.c_int64, C.c_int64, dp, dp, dp, dp, C.c_double, dp, dp]
+    L.wae_p1_shape_sensitivity_flame.argtypes = [C.c_int32, C.c_int64, dp, C.c_int64, i32p, C.c_int64, i32p, i32p, C.c_int32, C.c_int64, i32p, dp, dp, dp,
+                                                 C.c_double, dp, dp, dp, dp]
     L.wae_bench_spmv.argtypes = [C.c_void_p, dp, C.c_int32, C.c_int32, dp]
     L.wae_bench_triad.argtypes = [C.c_int32, C.c_int64, C.c_int32, dp]
+    L.wae_bench_spmv_level.argtypes = [C.c_void_p, dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp, C.POINTER(C.c_int64)]
     L.wae_debug_spmv.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, dp, C.c_int32, dp, dp, dp, dp, C.c_int32, C.c_int32, C.c_double,
                                  C.POINTER(C.c_uint8), C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     _lib = L

@@ -297,6 +297,82 @@ __global__ __launch_bounds__(256) void p1_flame_kernel(const int *__restrict__ t
 
 }  // namespace
 
+// Flame part of the discrete-adjoint shape sensitivity (shape_sensitivity.jl:62-141 with a :flame domain in dscrp).  The
+// reference re-discretises, per surface point, the flame tetrahedra that touch the point: Q = S (x) g with S_a = |det J|/24 on
+// their nodes (FEM.jl:2429-2431), nlocal = nglobal_scaled / (volume of THOSE tetrahedra) (Helmholtz.jl:325 on the reduced domain)
+// and g_b = -nlocal grad(phi_b).n_ref on the reference tetrahedron (FEM.jl:2442-2448).  Per (point, flame tetrahedron,
+// coordinate) this kernel returns |det J| with the point moved by +h and by -h, and per pair the sum of conj(v_adj) over the
+// tetrahedron's nodes: the host sums them per point (fixed order) and forms  -v_adj' (Q+ - Q-)/(2h) v.
+__global__ __launch_bounds__(256) void shape_flame_kernel(const double *__restrict__ pts, const int *__restrict__ tets, int64_t npair,
+                                                          const int *__restrict__ pair_pt, const int *__restrict__ pair_tet,
+                                                          const cplx *__restrict__ vadj, double h, double *__restrict__ det_pm,
+                                                          cplx *__restrict__ ssum) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= npair * 3) return;
+    const int64_t pr = e / 3;
+    const int crd = (int)(e - pr * 3);
+    const int t = pair_tet[pr], p = pair_pt[pr];
+    int vtx[4];
+    double X[4][3];
+    int a0 = -1;
+    cplx sa = {0.0, 0.0};
+    for (int a = 0; a < 4; ++a) {
+        vtx[a] = tets[(size_t)t * 4 + a];
+        if (vtx[a] == p) a0 = a;
+        for (int k = 0; k < 3; ++k) X[a][k] = pts[(size_t)vtx[a] * 3 + k];
+        const cplx y = vadj[vtx[a]];
+        sa.x += y.x; sa.y -= y.y;                              // conj(v_adj)
+    }
+    if (crd == 0) ssum[pr] = sa;
+    auto adet = [&]() {
+        double J[3][3];
+        for (int r = 0; r < 3; ++r)
+            for (int a = 0; a < 3; ++a) J[r][a] = X[a][r] - X[3][r];
+        return fabs(J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) + J[0][1] * (J[1][2] * J[2][0] - J[1][0] * J[2][2]) +
+                    J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]));
+    };
+    if (a0 < 0) { det_pm[e * 2] = det_pm[e * 2 + 1] = adet(); return; }
+    const double x0 = X[a0][crd];
+    X[a0][crd] = x0 + h; det_pm[e * 2] = adet();
+    X[a0][crd] = x0 - h; det_pm[e * 2 + 1] = adet();
+}
+// sum_b (grad(phi_b) . n_ref) v_b on the reference tetrahedron with vertex `p` moved by +h / -h along each coordinate (3 x 2
+// complex numbers per listed vertex), and undisplaced (g0)
+__global__ void shape_ref_kernel(const double *__restrict__ pts, const int *__restrict__ tets, int ref_tet, int64_t npair, const int *__restrict__ pair_pt,
+                                 double n0, double n1, double n2, const cplx *__restrict__ v, double h, cplx *__restrict__ g_pm, cplx *__restrict__ g0) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e > npair * 6) return;                                  // e == npair * 6: the undisplaced value
+    int vtx[4];
+    double X[4][3];
+    for (int a = 0; a < 4; ++a) {
+        vtx[a] = tets[(size_t)ref_tet * 4 + a];
+        for (int k = 0; k < 3; ++k) X[a][k] = pts[(size_t)vtx[a] * 3 + k];
+    }
+    if (e < npair * 6) {
+        const int64_t pr = e / 6;
+        const int crd = (int)((e - pr * 6) >> 1), sgn = (int)(e & 1);
+        for (int a = 0; a < 4; ++a)
+            if (vtx[a] == pair_pt[pr]) X[a][crd] += sgn ? -h : h;
+    }
+    double J[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int a = 0; a < 3; ++a) J[r][a] = X[a][r] - X[3][r];
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1], c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2], c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double id = 1.0 / (J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02);
+    double G[4][3];
+    G[0][0] = c00 * id; G[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id; G[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+    G[1][0] = c01 * id; G[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id; G[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+    G[2][0] = c02 * id; G[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id; G[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+    for (int k = 0; k < 3; ++k) G[3][k] = -(G[0][k] + G[1][k] + G[2][k]);
+    cplx acc = {0.0, 0.0};
+    for (int b = 0; b < 4; ++b) {
+        const double gb = G[b][0] * n0 + G[b][1] * n1 + G[b][2] * n2;
+        const cplx xb = v[vtx[b]];
+        acc.x += gb * xb.x; acc.y += gb * xb.y;
+    }
+    if (e < npair * 6) g_pm[e] = acc; else *g0 = acc;
+}
+
 extern "C" {
 
 int wae_p1_assemble_boundary(int32_t device, int64_t npoints, const double *points, int64_t ntris, const int32_t *tris, const double *c_tri, void **out) {
@@ -449,6 +525,56 @@ int wae_p1_shape_sensitivity(int32_t device, int64_t npoints, const double *poin
                                omegaY[0], omegaY[1], dv.p, dva.p, h, dout.p);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipMemcpy(out_s, dout.p, (size_t)npair_s * 3 * sizeof(cplx), hipMemcpyDeviceToHost));
+        }
+        return WAE_OK;
+    });
+}
+
+int wae_p1_shape_sensitivity_flame(int32_t device, int64_t npoints, const double *points, int64_t ntets, const int32_t *tets, int64_t npair,
+                                   const int32_t *pair_pt, const int32_t *pair_tet, int32_t ref_tet, int64_t npair_r, const int32_t *pair_pt_r,
+                                   const double *n_ref, const double *v, const double *v_adj, double h, double *det_pm, double *ssum,
+                                   double *g_pm, double *g0) {
+    return wae_guarded([&]() {
+        if (!(npoints > 0 && ntets > 0 && points && tets && n_ref && v && v_adj && h > 0.0 && g0)) throw WaeError(WAE_ERR_INVALID, "bad argument");
+        if (npair > 0 && !(pair_pt && pair_tet && det_pm && ssum)) throw WaeError(WAE_ERR_INVALID, "bad flame pair arguments");
+        if (npair_r > 0 && !(pair_pt_r && g_pm)) throw WaeError(WAE_ERR_INVALID, "bad reference pair arguments");
+        if (ref_tet < 0 || ref_tet >= ntets) throw WaeError(WAE_ERR_INVALID, "reference tetrahedron out of range");
+        for (int64_t i = 0; i < npair; ++i)
+            if (pair_tet[i] < 0 || pair_tet[i] >= ntets || pair_pt[i] < 0 || pair_pt[i] >= npoints) throw WaeError(WAE_ERR_INVALID, "pair index out of range");
+        for (int64_t i = 0; i < npair_r; ++i)
+            if (pair_pt_r[i] < 0 || pair_pt_r[i] >= npoints) throw WaeError(WAE_ERR_INVALID, "pair index out of range");
+        for (int64_t i = 0; i < ntets * 4; ++i)
+            if (tets[i] < 0 || tets[i] >= npoints) throw WaeError(WAE_ERR_INVALID, "tetrahedron refers to a point outside 0..npoints-1");
+        HIP_CHECK(hipSetDevice(device));
+        Dev<double> dpts((size_t)npoints * 3);
+        Dev<cplx> dv((size_t)npoints), dva((size_t)npoints);
+        Dev<int> dt((size_t)ntets * 4);
+        HIP_CHECK(hipMemcpy(dpts.p, points, (size_t)npoints * 3 * sizeof(double), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dv.p, v, (size_t)npoints * sizeof(cplx), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dva.p, v_adj, (size_t)npoints * sizeof(cplx), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dt.p, tets, (size_t)ntets * 4 * sizeof(int), hipMemcpyHostToDevice));
+        if (npair > 0) {
+            Dev<int> dpp((size_t)npair), dpt((size_t)npair);
+            Dev<double> ddet((size_t)npair * 6);
+            Dev<cplx> dss((size_t)npair);
+            HIP_CHECK(hipMemcpy(dpp.p, pair_pt, (size_t)npair * sizeof(int), hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(dpt.p, pair_tet, (size_t)npair * sizeof(int), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(shape_flame_kernel, dim3((unsigned)((npair * 3 + 255) / 256)), dim3(256), 0, 0, dpts.p, dt.p, npair, dpp.p, dpt.p, dva.p, h,
+                               ddet.p, dss.p);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipMemcpy(det_pm, ddet.p, (size_t)npair * 6 * sizeof(double), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(ssum, dss.p, (size_t)npair * sizeof(cplx), hipMemcpyDeviceToHost));
+        }
+        {
+            Dev<int> dpr((size_t)std::max<int64_t>(npair_r, 1));
+            Dev<cplx> dg((size_t)npair_r * 6 + 1);
+            if (npair_r > 0) HIP_CHECK(hipMemcpy(dpr.p, pair_pt_r, (size_t)npair_r * sizeof(int), hipMemcpyHostToDevice));
+            const int64_t nthr = npair_r * 6 + 1;
+            hipLaunchKernelGGL(shape_ref_kernel, dim3((unsigned)((nthr + 63) / 64)), dim3(64), 0, 0, dpts.p, dt.p, ref_tet, npair_r, dpr.p, n_ref[0], n_ref[1],
+                               n_ref[2], dv.p, h, dg.p, dg.p + (size_t)npair_r * 6);
+            HIP_CHECK(hipGetLastError());
+            if (npair_r > 0) HIP_CHECK(hipMemcpy(g_pm, dg.p, (size_t)npair_r * 6 * sizeof(cplx), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(g0, dg.p + (size_t)npair_r * 6, sizeof(cplx), hipMemcpyDeviceToHost));
         }
         return WAE_OK;
     });

@@ -475,8 +475,15 @@ template <int CTRL> __device__ __forceinline__ double lane_quad(double v) {     
 }
 // LPR = lanes per row: 2 (rows of up to 16 register-resident entries, 256-row tiles: the fine level) or 4 (up to 48, 128-row
 // tiles: the first coarse level, whose windows allow ~64 rows per tile anyway).
-template <bool UNI, int LPR, int NBUF>
-__global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td, const cplx *__restrict__ pc, int cps,
+// NWV = wavefronts per workgroup: 8, or 16 ("QUAD", round 3; fine level, one system per chunk): the tile keeps its 256 rows, its
+// windows and its storage (two entry halves per row), but every row is worked on by FOUR lanes -- lane 4 i + 2 c + h takes entry half
+// h and column half c (four of the chunk's eight columns) -- so that a lane carries 16 accumulator and 16 operand registers instead
+// of 32 and 64, the kernel fits 128 VGPRs, and four wavefronts per SIMD instead of two work on the chain barrier -> entries ->
+// window landed -> stores (that chain, not a bandwidth, is what the 8-wavefront form waits for: two wavefronts per SIMD sit in
+// s_waitcnt half of their time).  Per wavefront and chunk half the LDS reads and FMAs; the two c lanes of a half read the same
+// matrix entries (one coalesced request).
+template <bool UNI, int LPR, int NBUF, int NWV = 8, int KRT = (LPR == 2 ? 8 : 12)>
+__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 4) void spmv_tile_kernel(OpDev op, TileDev td, const cplx *__restrict__ pc, int cps,
                                                           const cplx *__restrict__ X, cplx *Y, const cplx *B, double jac_w,
                                                           int nb, int mode, const unsigned char *__restrict__ cmask, int spc_all, int csplit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
@@ -561,8 +568,15 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
         }
         if (!ok) { leave(); return; }
     }
-    constexpr int KR = LPR == 2 ? 8 : 12;                    // register-resident entries per lane (16 / 48 per row)
-    constexpr int NW = NBUF > 2 ? 7 : 10;                    // 64 window rows per workgroup step: windows up to 448 / 640 rows in one sweep
+    constexpr int KR = KRT;                                  // register-resident entries per lane (16 / 48 per row; 16 with NWV = 16)
+    constexpr int WSTEP = 8 * NWV;                           // window rows per workgroup step (8 per wave instruction)
+    constexpr int NTHR = 64 * NWV;
+    constexpr int NW = NBUF > 2 ? 7 : 640 / WSTEP;           // windows up to 448 / 640 rows in one sweep
+    constexpr bool QUAD = NWV == 16;                         // four lanes per row: (entry half h) x (column half c); LPR = 4 (16 rows per wavefront)
+    static_assert(!QUAD || (LPR == 4 && UNI && NBUF == 2 && KRT == 8), "QUAD: LPR = 4, one system per chunk, two buffers, 8 entries per lane");
+    const int qh = lane & 1, qc = (lane >> 1) & 1, qrot = (lane >> 2) & 3;     // (QUAD) this lane's halves, and the rotation of its row
+    // column of result j of this lane: QUAD keeps positions 2 h + j of its column half (position s <-> column 4 c + (s + qrot) mod 4)
+    auto ocol = [&](int j) { return QUAD ? 4 * qc + ((2 * qh + j + qrot) & 3) : (rot_out + j) & 7; };
     const GroupDev G0 = op.g[0];
     const TileGroupDev T0 = td.g0;
     // ---- per-tile state
@@ -578,7 +592,8 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
     typedef const __attribute__((address_space(4))) int *kint_p;
     const kint_p k_sptr = (kint_p)(uintptr_t)T0.sptr, k_win = (kint_p)(uintptr_t)td.win_ptr, k_row = (kint_p)(uintptr_t)td.row_ptr;
     auto request_scalars = [&](int t, int (&raw)[6]) {
-        raw[0] = k_sptr[t * 8 + wv]; raw[1] = k_sptr[t * 8 + wv + 1];
+        const int sl = QUAD ? t * 8 + (wv >> 1) : t * NWV + wv;     // (QUAD: the storage has 8 slices of 32 rows per tile; a wavefront takes half of one)
+        raw[0] = k_sptr[sl]; raw[1] = k_sptr[sl + 1];
         raw[2] = k_win[t]; raw[3] = k_win[t + 1];
         raw[4] = k_row[t]; raw[5] = k_row[t + 1];
     };
@@ -595,7 +610,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
     auto load_list = [&](int (&g_)[NW], int w0_, int W_) {
         const int *wl = td.win_cols + w0_;
 #pragma unroll
-        for (int u = 0; u < NW; ++u) { const int i = wv * 8 + 64 * u + (lane >> 3); g_[u] = wl[i < W_ ? i : W_ - 1]; }
+        for (int u = 0; u < NW; ++u) { const int i = wv * 8 + WSTEP * u + (lane >> 3); g_[u] = wl[i < W_ ? i : W_ - 1]; }
     };
     auto load_matrix = [&]() {                               // this lane's share of its row of the bulk group -> registers
 #pragma unroll
@@ -604,7 +619,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
         const double2 *__restrict__ v2 = (const double2 *)T0.svals;
 #pragma unroll
         for (int u = 0; u < KR; ++u)
-            if (u < n0) { const int e = s00 + lane + 64 * u; ixr[u] = si[e]; avr[u] = v2[e]; }   // (uniform; absent entries stay (0, 0.0))
+            if (u < n0) { const int e = s00 + (QUAD ? 32 * (wv & 1) + 2 * (lane >> 2) + qh : lane) + 64 * u; ixr[u] = si[e]; avr[u] = v2[e]; }   // (uniform; absent entries stay (0, 0.0))
         const int lr = wv * RPW + lane / LPR;
         side = (td.nside && lr < nrows) ? td.side_of_row[r0 + lr] : -1;
         dslot = (T0.dslot && lr < nrows) ? T0.dslot[r0 + lr] : 0xFFFFu;
@@ -639,7 +654,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
             default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         }
     };
-    auto pieces_of = [&](int W_) { const int left = W_ - wv * 8; return left <= 0 ? 0 : (left + 63) / 64 <= NW ? (left + 63) / 64 : 99; };
+    auto pieces_of = [&](int W_) { const int left = W_ - wv * 8; return left <= 0 ? 0 : (left + WSTEP - 1) / WSTEP <= NW ? (left + WSTEP - 1) / WSTEP : 99; };
     // Gather of a window into buffer b, piece by piece (rows past W duplicate the last one into the slack of the 8-row granule:
     // no per-lane predicate).  The pieces of the NEXT window are issued between the entries of the compute phase: a wavefront
     // that issues its ten pieces back to back sits in the issue queue for ~1.2 k cycles.
@@ -649,11 +664,11 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
         return X + bc;
     };
     auto issue_piece = [&](const cplx *Xc, int b, const int (&g_)[NW], int W_, int u) {   // u: compile-time piece number
-        const int r = wv * 8 + 64 * u;
+        const int r = wv * 8 + WSTEP * u;
         if (r < W_) glds16(Xc + (size_t)g_[u] * nb, lds_base + (unsigned)b * (unsigned)wslots * 128u + (unsigned)r * 128u);   // (uniform)
     };
     auto issue_rest = [&](const cplx *Xc, int b, int w0_, int W_) {   // (windows beyond NW sweeps: only with WAE_TILE_WCAP > 640)
-        for (int rb = wv * 8 + 64 * NW; rb < W_; rb += 64) {
+        for (int rb = wv * 8 + WSTEP * NW; rb < W_; rb += WSTEP) {
             const int i = rb + (lane >> 3);
             glds16(Xc + (size_t)td.win_cols[w0_ + (i < W_ ? i : W_ - 1)] * nb, lds_base + (unsigned)b * (unsigned)wslots * 128u + (unsigned)rb * 128u);
         }
@@ -671,7 +686,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
     int buf = 0;                                             // buffer of the current chunk's window; the windows of the chunks that
     bool wn0 = false, wn1 = false, wn2 = false;              // follow sit in buf + 1, buf + 2 (mod NBUF): wn_k = "has been requested"
     if (spc_all)
-        for (int i = tid; i < nch_all * 8 * npl; i += 512) {
+        for (int i = tid; i < nch_all * 8 * npl; i += NTHR) {
             const int cc = i / npl, q = i - cc * npl;
             spc0[i] = pc[(size_t)((cc < nb ? cc : nb - 1) / cps) * npl + q];
         }
@@ -733,7 +748,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
         __syncthreads();                                     // everybody's share of this chunk's window has landed (each wavefront
                                                              // waited for its own before its last stores); every wavefront is done
         if (!spc_all) {                                      // with the buffer of the previous chunk and the previous coefficients
-            for (int i = tid; i < 8 * npl; i += 512) {
+            for (int i = tid; i < 8 * npl; i += NTHR) {
                 const int cc = i / npl, q = i - cc * npl;
                 int bb = col0 + cc;
                 if (bb >= nb) bb = nb - 1;
@@ -764,7 +779,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
         auto epilogue_loads = [&]() {                        // right-hand sides of the fused modes: requested together
 #pragma unroll
             for (int j = 0; j < NOUT; ++j) {
-                const int c = (rot_out + j) & 7;
+                const int c = ocol(j);
                 const int b = col0 + c < nb ? col0 + c : nb - 1;
                 const size_t e = (size_t)row * nb + b;
                 bv[j] = need_b ? B[e] : cplx{0.0, 0.0};
@@ -893,9 +908,9 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
         if (n0 > 0) {                                        // the bulk group: mass + stiffness on one pattern, 16 B + 2 B per nonzero
             const cplx c0 = td.unit ? cplx{1.0, 0.0} : spc[G0.plane0], c1p = td.unit ? cplx{0.0, 0.0} : spc[G0.plane0 + 1];
             auto fetch = [&](cplx (&x)[8], unsigned ix) {    // the 8 operands of one entry: 8 ds_read_b128, rotated column order
-                const cplx *wr = win + ix * 8;
+                const cplx *wr = win + ix * 8;               // (QUAD: the four of this lane's column half)
 #pragma unroll
-                for (int s = 0; s < 8; ++s) x[s] = wr[(s + rot) & 7];
+                for (int s = 0; s < (QUAD ? 4 : 8); ++s) x[s] = wr[QUAD ? 4 * qc + ((s + qrot) & 3) : (s + rot) & 7];
             };
             auto apply = [&](const cplx (&x)[8], double2 a) {
                 if (SPLIT) {
@@ -907,7 +922,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
                 } else {
                     const cplx m = {fma(c0.x, a.x, c1p.x * a.y), fma(c0.y, a.x, c1p.y * a.y)};
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) cfma(acc[s], m, x[s]);
+                    for (int s = 0; s < (QUAD ? 4 : 8); ++s) cfma(acc[s], m, x[s]);
                 }
             };
             const unsigned short *__restrict__ si = T0.sidx;
@@ -916,7 +931,8 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
             // ahead of the window pieces (vector-memory operations complete in order)
             unsigned ixs = 0;
             double2 avs = {0.0, 0.0};
-            if (n0 > KR) { const int e = s00 + lane + 64 * KR; ixs = si[e]; avs = v2[e]; }
+            const int mlane = QUAD ? 32 * (wv & 1) + 2 * (lane >> 2) + qh : lane;      // this lane's place in its slice of the storage
+            if (n0 > KR) { const int e = s00 + mlane + 64 * KR; ixs = si[e]; avs = v2[e]; }
             // register-resident part, software-pipelined by hand: the operands of entry u+1 are requested before the FMAs of
             // entry u, two operand sets alternate; absent entries are (slot 0, 0.0).  The scheduling fences pin that order --
             // left alone hipcc hoists 32 reads, runs out of registers and then issues the rest two at a time behind
@@ -925,10 +941,19 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
             fetch(xa, ixr[0]);
 #pragma unroll
             for (int u = 0; u < KR; ++u) {
-                if (u + 1 < KR) { if (u & 1) fetch(xa, ixr[u + 1]); else fetch(xb, ixr[u + 1]); }
-                __builtin_amdgcn_sched_barrier(0);
-                if (u & 1) apply(xb, avr[u]); else apply(xa, avr[u]);
+                if constexpr (!QUAD) {
+                    if (u + 1 < KR) { if (u & 1) fetch(xa, ixr[u + 1]); else fetch(xb, ixr[u + 1]); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (u & 1) apply(xb, avr[u]); else apply(xa, avr[u]);
+                } else {                                     // (one operand set: four wavefronts per SIMD cover the LDS latency)
+                    if (u > 0) fetch(xa, ixr[u]);
+                    apply(xa, avr[u]);
+                }
                 // (the FMAs are pure arithmetic: only an operand dependence keeps them from sinking below the later reads)
+                if constexpr (QUAD)
+                    asm volatile("" : "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[1].x), "+v"(acc[1].y), "+v"(acc[2].x), "+v"(acc[2].y),
+                                      "+v"(acc[3].x), "+v"(acc[3].y) : : "memory");
+                else
                 asm volatile("" : "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[1].x), "+v"(acc[1].y), "+v"(acc[2].x), "+v"(acc[2].y),
                                   "+v"(acc[3].x), "+v"(acc[3].y), "+v"(acc[4].x), "+v"(acc[4].y), "+v"(acc[5].x), "+v"(acc[5].y),
                                   "+v"(acc[6].x), "+v"(acc[6].y), "+v"(acc[7].x), "+v"(acc[7].y) : : "memory");
@@ -947,7 +972,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
             for (int k = KR; k < n0; ++k) {
                 const unsigned ixc = ixs;
                 const double2 avc = avs;
-                if (k + 1 < n0) { const int e = s00 + lane + 64 * (k + 1); ixs = si[e]; avs = v2[e]; }
+                if (k + 1 < n0) { const int e = s00 + mlane + 64 * (k + 1); ixs = si[e]; avs = v2[e]; }
                 cplx x[8];
                 fetch(x, ixc);
                 apply(x, avc);
@@ -959,6 +984,14 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
         TILE_STAMP(3);
         // the partial sums of a row meet; afterwards each lane keeps NOUT results: those of the columns (rot_out + j) mod 8
         auto meet = [&](const cplx (&a)[8], cplx (&r)[NOUT]) {
+            if constexpr (QUAD) {                            // the two entry halves of a (row, column half) meet; lane h keeps positions 2 h, 2 h + 1
+#pragma unroll
+                for (int j = 0; j < NOUT; ++j) {
+                    const cplx lo = {a[j].x + lane_quad<0xB1>(a[j].x), a[j].y + lane_quad<0xB1>(a[j].y)};
+                    const cplx hi = {a[j + 2].x + lane_quad<0xB1>(a[j + 2].x), a[j + 2].y + lane_quad<0xB1>(a[j + 2].y)};
+                    r[j] = qh ? hi : lo;
+                }
+            } else
             if (LPR == 2) {
 #pragma unroll
                 for (int j = 0; j < NOUT; ++j) {
@@ -993,12 +1026,12 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
         if (NBUF == 2) epilogue_loads();
         if (mode == MODE_JAC && dslot != 0xFFFFu) {          // the row's own X: it is in the window (1 GB per sweep not read again)
 #pragma unroll
-            for (int j = 0; j < NOUT; ++j) xv[j] = win[dslot * 8 + ((rot_out + j) & 7)];
+            for (int j = 0; j < NOUT; ++j) xv[j] = win[dslot * 8 + ocol(j)];
         }
         if (side >= 0) {                                     // the other groups' part of this row (spmv_side_kernel)
 #pragma unroll
             for (int j = 0; j < NOUT; ++j) {
-                const int c = (rot_out + j) & 7;
+                const int c = ocol(j);
                 const int b = col0 + c < nb ? col0 + c : nb - 1;
                 const cplx sv = td.side_acc[(size_t)side * nb + b];
                 res[j].x += sv.x; res[j].y += sv.y;
@@ -1007,7 +1040,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
         cplx out[NOUT], b2[NOUT];
 #pragma unroll
         for (int j = 0; j < NOUT; ++j) {
-            const int c = (rot_out + j) & 7;
+            const int c = ocol(j);
             const cplx av = res[j];
             b2[j] = cplx{0.0, 0.0};
             // (three buffers: av is A x - b, or A x + b, already: bz stands in for the right-hand side)
@@ -1063,7 +1096,7 @@ __global__ __launch_bounds__(512, 1) void spmv_tile_kernel(OpDev op, TileDev td,
         if (live) {
 #pragma unroll
             for (int j = 0; j < NOUT; ++j) {
-                const int b = col0 + ((rot_out + j) & 7);
+                const int b = col0 + ocol(j);
                 if (b >= nb) continue;
                 const size_t e = (size_t)row * nb + b;
                 Y[e] = out[j];
@@ -1136,6 +1169,7 @@ static void launch_spmv_tile(const OpDev &op, const TileDev &td, const cplx *pc,
         HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<false, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<true, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<false, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_CHECK(hipFuncSetAttribute((const void *)spmv_tile_kernel<true, 4, 2, 16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     static int ncu_dev[64] = {0};                            // CUs per device (devices of a node may differ; under the lock)
@@ -1170,6 +1204,11 @@ static void launch_spmv_tile(const OpDev &op, const TileDev &td, const cplx *pc,
         HIP_CHECK(hipGetLastError());
     }
 #define WAE_TILE_LAUNCH(U, L, N) hipLaunchKernelGGL((spmv_tile_kernel<U, L, N>), grid, dim3(512), shm, st, op, td, pc, cps, X, Y, B, jac_w, nb, mode, cmask, spc_all, csplit)
+    // QUAD form (16 wavefronts, four lanes per row): the same tile storage as the 2-lane form; one system per chunk only
+    static const int waves16 = getenv("WAE_TILE_WAVES") ? atoi(getenv("WAE_TILE_WAVES")) == 16 : 0;
+    if (waves16 && td.lpr == 2 && nbuf == 2 && cps % 8 == 0 && !td.unit)
+        hipLaunchKernelGGL((spmv_tile_kernel<true, 4, 2, 16, 8>), grid, dim3(1024), shm, st, op, td, pc, cps, X, Y, B, jac_w, nb, mode, cmask, spc_all, csplit);
+    else
     if (td.lpr == 4) { if (cps % 8 == 0) WAE_TILE_LAUNCH(true, 4, 2); else WAE_TILE_LAUNCH(false, 4, 2); }
     else if (nbuf == 3) { if (cps % 8 == 0) WAE_TILE_LAUNCH(true, 2, 3); else WAE_TILE_LAUNCH(false, 2, 3); }
     else { if (cps % 8 == 0) WAE_TILE_LAUNCH(true, 2, 2); else WAE_TILE_LAUNCH(false, 2, 2); }

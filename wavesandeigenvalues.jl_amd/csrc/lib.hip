@@ -299,7 +299,7 @@ static std::vector<int> build_levelop(LevelOp &L, const std::vector<CsrZ> &plane
 // tile-local storage of an operator whose rows have been cut into tiles (tiles.h): windows and the bulk group (two real planes on
 // one pattern).  U: pattern that defines the windows (every column any plane of the operator touches).
 static bool build_tiles_core(TileStore &T, const std::vector<const CsrZ *> &bulk, const Pattern &U, const std::vector<int> &row_ptr, int lpr,
-                             hipStream_t st, const char *what, int nbuf = 2) {
+                             hipStream_t st, const char *what, int nbuf = 2, int nwaves = 8) {
     T = TileStore();
     if (row_ptr.size() < 2) return false;
     const TileWindows W = build_windows(U, row_ptr);
@@ -312,7 +312,7 @@ static bool build_tiles_core(TileStore &T, const std::vector<const CsrZ *> &bulk
     T.win_cols.upload(W.win_cols.data(), W.win_cols.size(), st);
     memset(&T.dev, 0, sizeof(T.dev));
     {
-        const TileGroupHost H = build_tile_group(bulk, true, row_ptr, W, lpr);
+        const TileGroupHost H = build_tile_group(bulk, true, row_ptr, W, lpr, nwaves);
         T.sptr.upload(H.sptr.data(), H.sptr.size(), st);
         T.sidx.upload(H.sidx.data(), H.sidx.size(), st);
         T.svals.upload(H.svals.data(), H.svals.size(), st);
@@ -324,8 +324,8 @@ static bool build_tiles_core(TileStore &T, const std::vector<const CsrZ *> &bulk
         T.dev.g0.dslot = T.dslot.p;
         if (getenv("WAE_SETUP_DEBUG")) {
             int over = 0, full = 0;                          // slices longer than the register-resident entries per lane
-            for (size_t i = 0; i + 1 < H.sptr.size(); ++i) over += (H.sptr[i + 1] - H.sptr[i]) / 64 > (lpr == 2 ? 8 : 12);
-            for (int t = 0; t < nt; ++t) full += row_ptr[t + 1] - row_ptr[t] == 512 / lpr;
+            for (size_t i = 0; i + 1 < H.sptr.size(); ++i) over += (H.sptr[i + 1] - H.sptr[i]) / 64 > (nwaves == 16 ? 4 : (lpr == 2 ? 8 : 12));
+            for (int t = 0; t < nt; ++t) full += row_ptr[t + 1] - row_ptr[t] == 64 * nwaves / lpr;
             fprintf(stderr, "[tiles] %s: %d tiles (%d lanes per row, %d window buffers), %.1f rows and %.1f window rows per tile on average, %d full tiles, largest window %d\n",
                     what, nt, lpr, (nbuf == 3 && lpr == 2 && wmax <= 400) ? 3 : 2, (double)row_ptr[nt] / nt, (double)W.win_ptr[nt] / nt, full, wmax);
             fprintf(stderr, "[tiles] %s: %lld nonzeros in %lld slots (%.3f filled), %d of %zu slices stream entries\n", what,
@@ -339,6 +339,7 @@ static bool build_tiles_core(TileStore &T, const std::vector<const CsrZ *> &bulk
     T.dev.ntiles = nt;
     T.dev.wmax = wmax;
     T.dev.lpr = lpr;
+    T.dev.nwaves = nwaves;
     T.dev.nbuf = (nbuf == 3 && lpr == 2 && wmax <= 400) ? 3 : 2;
     T.dev.row_ptr = T.row_ptr.p;
     T.dev.win_ptr = T.win_ptr.p;
@@ -348,7 +349,7 @@ static bool build_tiles_core(TileStore &T, const std::vector<const CsrZ *> &bulk
 }
 // ... of a level operator; planes in the level's numbering
 static void build_level_tiles(LevelOp &L, const std::vector<CsrZ> &planes, const std::vector<int> &slot_plane, const std::vector<int> &row_ptr,
-                              hipStream_t st, int lpr = 2, int nbuf = 2) {
+                              hipStream_t st, int lpr = 2, int nbuf = 2, int nwaves = 8) {
     TileStore &T = L.tiles;
     T = TileStore();
     if (L.groups.empty() || !L.groups[0].is_real || L.groups[0].nplanes != 2) return;   // the tile kernel's bulk group: two real planes
@@ -357,7 +358,7 @@ static void build_level_tiles(LevelOp &L, const std::vector<CsrZ> &planes, const
         const GroupHost &G = L.groups[0];
         std::vector<const CsrZ *> mats;
         for (int q = 0; q < G.nplanes; ++q) mats.push_back(&planes[slot_plane[G.plane0 + q]]);
-        if (!build_tiles_core(T, mats, union_pattern(planes), row_ptr, lpr, st, "operator", nbuf)) return;
+        if (!build_tiles_core(T, mats, union_pattern(planes), row_ptr, lpr, st, "operator", nbuf, nwaves)) return;
     }
     T.all_symmetric = true;
     for (size_t g = 0; g < ng; ++g) T.all_symmetric = T.all_symmetric && L.groups[g].symmetric;
@@ -1551,8 +1552,9 @@ int wae_family_create(wae_family **out, int64_t d, int32_t T, int32_t index_byte
         h->ops.resize(1);
         h->slot_plane.resize(1);
         h->slot_plane[0] = build_levelop(h->ops[0], h->planes0, h->stream);
-        if (!h->tile_row_ptr.empty())
+        if (!h->tile_row_ptr.empty()) {
             build_level_tiles(h->ops[0], h->planes0, h->slot_plane[0], h->tile_row_ptr, h->stream, 2, getenv("WAE_TILE_NBUF") ? atoi(getenv("WAE_TILE_NBUF")) : 2);
+        }
         cplx one = {1.0, 0.0};
         h->one_dev.upload(&one, 1, h->stream);
         HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -2148,8 +2150,9 @@ int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const doub
     return guarded([&]() {
         WAE_REQUIRE(h && npts >= 0 && (npts == 0 || (z && w && coeff_table)) && (V || mode == 2) && l > 0 && K > 0, "bad argument");
         WAE_REQUIRE(A_out || out_dev, "no output buffer");
-        WAE_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (take snapshots), 1 (rebuild the basis from the store, use it) or 2 (use it)");
-        WAE_REQUIRE(nbasis >= 0 && slot0 >= 0 && (mode == 2 || slot0 + (mode == 0 ? npts : 0) <= nbasis), "snapshot slots out of range");
+        WAE_REQUIRE(mode >= 0 && mode <= 4, "mode must be 0 (take snapshots), 1 (rebuild the basis from the store, use it), 2 (use it), "
+                                            "3 (solve from zero, store raw) or 4 (build the basis from the store, solve nothing)");
+        WAE_REQUIRE(nbasis >= 0 && slot0 >= 0 && (mode == 2 || slot0 + ((mode == 0 || mode == 3) ? npts : 0) <= nbasis), "snapshot slots out of range");
         WAE_REQUIRE(!accumulate || out_dev, "accumulate needs a device-resident moment buffer");
         if (l_total <= 0) { l_total = l; col0 = 0; }
         WAE_REQUIRE(col0 >= 0 && col0 + l <= l_total, "column slice out of range");
@@ -2192,10 +2195,20 @@ int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const doub
         // vectors cost more than the iterations they saved (measured with thresholds 3, 6, 9); WAE_RB_ENRICH=<its> enables
         static const int enrich_its = getenv("WAE_RB_ENRICH") ? atoi(getenv("WAE_RB_ENRICH")) : (1 << 30);
         double t_guess = 0.0, t_solve = 0.0, t_append = 0.0;
-        if ((mode == 0 && slot0 == 0) || mode == 1) {
+        if ((mode == 0 && slot0 == 0) || mode == 1 || mode == 4) {
             launch_colmajor_to_inter(h->io_a.p, d, l, h->W.p, l, st, h->perm());
             rb_reset(h, Q, nbasis, l, coeff_table, npts, h->W.p);
-            if (mode == 1) rb_append(h, slot0);    // the store holds slot0 raw snapshots (e.g. all-gathered)
+            if (mode == 1 || mode == 4) rb_append(h, slot0);    // the store holds slot0 raw snapshots (e.g. gathered from other ranks)
+            if (mode == 4) {                       // basis built (the coefficient table only said which terms take part): nothing to solve
+                HIP_CHECK(hipStreamSynchronize(st));
+                Aown.release();
+                li.seconds = now_s() - t0;
+                li.levels = (int)h->ops.size();
+                if (info) *info = li;
+                return (int)WAE_OK;
+            }
+        } else if (mode == 3) {
+            // raw snapshots: the handle's basis is not touched
         } else {
             WAE_REQUIRE(R.Q == Q && R.l == l && R.cap == nbasis, "the basis in the handle belongs to another store / shape");
             WAE_REQUIRE(mode != 0 || slot0 == R.S, "mode 0 appends: slot0 must equal the number of snapshots taken so far");
@@ -2204,7 +2217,7 @@ int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const doub
 
         // with a fixed basis (modes 1/2, no enrichment) the coefficients of the next chunk's guesses are computed on a helper
         // thread while the device solves the current chunk
-        const bool fixed_basis = mode != 0 && enrich_its >= (1 << 30);
+        const bool fixed_basis = (mode == 1 || mode == 2) && enrich_its >= (1 << 30);
         std::future<std::vector<cplx>> next_Y;
         auto launch_coeffs = [&](int q0) {
             const int nq = std::min(spc, npts - q0);
@@ -2235,7 +2248,7 @@ int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const doub
             h->zw_dev.upload(zw.data(), zw.size(), st);
             HIP_CHECK(hipStreamSynchronize(st));
             if (bt.nb != rep_nb) { launch_replicate(h->io_a.p, d, l, h->Bs.p, bt.nb, st, h->perm()); rep_nb = bt.nb; }   // same right-hand sides for every chunk
-            const bool guess = R.S > 0;            // mode 0 is progressive: later snapshot chunks start from the earlier ones
+            const bool guess = mode != 3 && R.S > 0;   // mode 0 is progressive: later snapshot chunks start from the earlier ones
             const double ta = now_s();
             if (guess) {
                 std::vector<cplx> Y;
@@ -2254,6 +2267,10 @@ int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const doub
             const double tc = now_s();
             // mode 0 keeps every solution; modes 1/2 enrich the basis where the guesses were poor (a region of the
             // contour close to poles outside it), as long as the store has room
+            if (mode == 3) {                       // raw solutions into the caller's slots; no basis work (another rank builds it)
+                for (int s = 0; s < ns; ++s)
+                    launch_extract_cols(h->Xs.p, bt.nb, s * l, l, Q + (size_t)(slot0 + p0 + s) * vecl, d, st);
+            } else
             if (mode == 0 || (its > enrich_its && R.S + ns <= R.cap)) {
                 for (int s = 0; s < ns; ++s)
                     launch_extract_cols(h->Xs.p, bt.nb, s * l, l, Q + (size_t)(R.S + s) * vecl, d, st);
@@ -2734,6 +2751,65 @@ int wae_debug_spmv(wae_family *h, int32_t which, int32_t level, int32_t mode, co
             HIP_CHECK(hipMemcpyAsync(B2, yc.p, cout * sizeof(cplx), hipMemcpyDeviceToHost, st));
         }
         HIP_CHECK(hipStreamSynchronize(st));
+        return WAE_OK;
+    });
+}
+
+int wae_bench_spmv_level(wae_family *h, const double *coeffs, int32_t which, int32_t level, int32_t r, int32_t reps, double *ms_out,
+                         int64_t *bytes_out) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && coeffs && (which == 0 || which == 1) && level >= 0 && r > 0 && r <= 256 && reps > 0 && ms_out, "bad argument");
+        require_solver(h);
+        WAE_REQUIRE(which == 0 ? (level == 0 || level < (int)h->ops.size() - 1) : level < (int)h->xfer.size(), "no such level");
+        HIP_CHECK(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        const int64_t n_in = which == 0 ? h->ops[level].n : h->xfer[level].nf, n_out = which == 0 ? h->ops[level].n : h->xfer[level].nc;
+        DevBuf<cplx> x, y, pcd;
+        x.alloc((size_t)n_in * r); y.alloc((size_t)n_out * r);
+        std::vector<cplx> hx((size_t)n_in * r);
+        uint64_t sd = 0x9E3779B97F4A7C15ull;
+        for (auto &v : hx) { sd ^= sd << 13; sd ^= sd >> 7; sd ^= sd << 17; v.x = (double)(sd & 0xFFFFF) / 524288.0 - 1.0; v.y = (double)((sd >> 20) & 0xFFFFF) / 524288.0 - 1.0; }
+        HIP_CHECK(hipMemcpyAsync(x.p, hx.data(), hx.size() * sizeof(cplx), hipMemcpyHostToDevice, st));
+        OpDev A;
+        const cplx *pcp = h->one_dev.p;
+        int64_t bytes = 2;
+        if (which == 0) {
+            std::vector<zc> pc;
+            plane_coeffs(h, coeffs, WAE_OP_N, pc);
+            std::vector<cplx> tab(h->nplanes);
+            bytes = 0;
+            for (int q = 0; q < h->nplanes; ++q) {
+                const zc c = pc[h->slot_plane[level][q]];
+                tab[q] = cplx{c.real(), c.imag()};
+            }
+            pcd.upload(tab.data(), tab.size(), st);
+            pcp = pcd.p;
+            A = h->ops[level].dev(WAE_OP_N);
+            bytes = 0;
+            for (size_t g = 0; g < h->ops[level].groups.size(); ++g) {
+                const GroupHost &G = h->ops[level].groups[g];
+                for (int q = 0; q < G.nplanes; ++q)
+                    if (tab[G.plane0 + q].x != 0.0 || tab[G.plane0 + q].y != 0.0) bytes += G.nnz * 20 + (n_out + 1) * 4;
+            }
+        } else {
+            A = h->xfer[level].devR();
+            bytes = (int64_t)h->xfer[level].r_col.n * 12 + (n_out + 1) * 4;       // real values: 8 + 4 bytes per entry
+        }
+        bytes += (int64_t)r * (n_in + n_out) * 16;
+        if (bytes_out) *bytes_out = bytes;
+        for (int i = 0; i < 3; ++i) launch_spmv(A, pcp, 1 << 30, x.p, y.p, nullptr, 0.0, r, MODE_AX, st);
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) launch_spmv(A, pcp, 1 << 30, x.p, y.p, nullptr, 0.0, r, MODE_AX, st);
+        HIP_CHECK(hipEventRecord(e1, st));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        *ms_out = (double)ms / reps;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
         return WAE_OK;
     });
 }

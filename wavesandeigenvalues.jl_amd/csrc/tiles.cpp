@@ -278,7 +278,9 @@ TileWindows build_windows(const Pattern &U, const std::vector<int> &row_ptr) {
     return W;
 }
 
-TileGroupHost build_tile_group(const std::vector<const CsrZ *> &mats, bool is_real, const std::vector<int> &row_ptr, const TileWindows &W, int lpr) {
+TileGroupHost build_tile_group(const std::vector<const CsrZ *> &mats, bool is_real, const std::vector<int> &row_ptr, const TileWindows &W, int lpr,
+                               int slices) {
+    const int TILE_SLICES = slices;                           // (shadows the default: 8 wavefronts per tile, or 16)
     TileGroupHost T;
     const CsrZ &A = *mats[0];
     const int np = (int)mats.size();

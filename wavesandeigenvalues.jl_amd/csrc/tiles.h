@@ -28,9 +28,9 @@ CsrZ permute_symmetric(const CsrZ &A, const std::vector<int> &perm, const std::v
 // Tile-local storage of one pattern group: per (tile, wavefront) a slice of 64 / lpr rows, lpr lanes per row (lane lpr i + h
 // holds the entries h, h + lpr, ... of row i), padded to 1 / lpr of the longest row of the slice and stored entry-major
 // ([k][lane]) so that the lanes read coalesced; column indices are 16-bit positions in the tile's window.
-constexpr int TILE_SLICES = 8;                 // wavefronts per tile
+constexpr int TILE_SLICES = 8;                 // wavefronts per tile (default; build_tile_group takes the number)
 struct TileGroupHost {
-    std::vector<int> sptr;                 // TILE_SLICES*ntiles + 1 entry offsets (multiples of 64)
+    std::vector<int> sptr;                 // slices*ntiles + 1 entry offsets (multiples of 64)
     std::vector<unsigned short> sidx;      // local column index per entry
     std::vector<double> svals;             // [entry][nplanes] doubles (real group) or [entry][nplanes][2]
     std::vector<unsigned short> dslot;     // per row: window slot of the row's own column, 0xFFFF if the row has no such entry
@@ -40,4 +40,5 @@ struct TileWindows {
 };
 TileWindows build_windows(const Pattern &U, const std::vector<int> &row_ptr);
 // mats: the planes of one pattern group (same pattern); is_real: store real parts only
-TileGroupHost build_tile_group(const std::vector<const CsrZ *> &mats, bool is_real, const std::vector<int> &row_ptr, const TileWindows &W, int lpr);
+TileGroupHost build_tile_group(const std::vector<const CsrZ *> &mats, bool is_real, const std::vector<int> &row_ptr, const TileWindows &W, int lpr,
+                               int slices = TILE_SLICES);

@@ -80,7 +80,8 @@ struct TileGroupDev {
 struct TileDev {
     int ntiles;
     int wmax;                       // largest window
-    int lpr;                        // lanes per row: 2 (tiles of up to 256 rows) or 4 (up to 128 rows)
+    int lpr;                        // lanes per row: 2 (tiles of up to 256 rows) or 4 (up to 128 rows; 256 with 16 wavefronts)
+    int nwaves;                     // wavefronts per workgroup (slices per tile): 8, or 16 (lpr = 4 on the fine level)
     int nbuf;                       // window buffers in LDS: 2 (windows up to 608 rows) or 3 (up to 400: two windows in flight; lpr = 2 only)
     int unit;                       // the operator is plane 0 itself (coefficients 1, 0: the restriction), no coefficient table is read
     const int *row_ptr;             // ntiles+1

@@ -138,6 +138,7 @@ def _assemble(pts, tets, nz, n_sector, flame_sectors, ref_offset):
     frac = ang / (2 * np.pi / n_sector) - sector
     in_flame = (ctr[:, 2] > FLAME_Z0) & (ctr[:, 2] < FLAME_Z1) & (frac > 0.25) & (frac < 0.75)
     QI, QJ, QV = [], [], []
+    flames = []                                               # per flame: its tetrahedra, reference tetrahedron, (γ-1)/ρ·Q02U0
     n_ref = np.array([0.0, 0.0, 1.0])
     r_mid = 0.5 * (R_IN + R_OUT)
     for f in flame_sectors:
@@ -163,13 +164,19 @@ def _assemble(pts, tets, nz, n_sector, flame_sectors, ref_offset):
                 ref = it
                 break
         assert ref >= 0, "reference point not found"
+        flames.append({"flame_tets": sel.astype(np.int32), "ref_tet": int(ref), "n_ref": n_ref.copy(), "x_ref": x_ref.copy(),
+                       "nglobal_scaled": float((gamma - 1) / rho * Q02U0), "volume": float(vol)})
         g = -nlocal * (G[ref] @ n_ref)                         # FEM.jl:2442-2448, Helmholtz.jl:482
         QI.append(np.repeat(S_nodes, 4)); QJ.append(np.tile(tets[ref], len(S_nodes)))
         QV.append(np.outer(S_vals, g).ravel())
     Q = _coo_to_csr(np.concatenate(QI), np.concatenate(QJ), np.concatenate(QV).astype(complex), d)
 
     return ({"M": M, "K": K, "C": C, "Q": Q},
-            {"ntets": len(tets), "ntri_outlet": len(tri), "nflame_tets": int(in_flame.sum())})
+            {"ntets": len(tets), "ntri_outlet": len(tri), "nflame_tets": int(in_flame.sum()),
+             # the mesh description behind the matrices (shape sensitivities re-discretise simplices): tetrahedra, speed of sound,
+             # outlet triangles with the speed of sound of the tetrahedron behind each, flames
+             "mesh": {"tets": tets.astype(np.int32), "c_tet": c_tet, "outlet_tris": tri.astype(np.int32), "outlet_c": c_tet[t_idx],
+                      "flames": flames}})
 
 
 def build_unit_cell(grid=(8, 26, 7), DOS=N_SECTOR, Y=1e15, n=1.0, tau=1e-3):

@@ -83,28 +83,36 @@ def assemble_p1_flame(points, tets, flame_tets, ref_tet, n_ref, nglobal_scaled, 
 
 
 def discrete_adjoint_shape_sensitivity(points, tets, c_tet, surface_points, sol, L, bnd_tris=None, bnd_c=None, Y=None, h=1e-9,
-                                       device=0):
+                                       device=0, flame=None, v_ext=None):
     """sens = discrete_adjoint_shape_sensitivity(...)   (src/shape_sensitivity.jl:16-141, full mesh, P1)
 
     Sensitivity of the eigenvalue ``sol.params[sol.eigval]`` to a displacement of every point in ``surface_points`` along
     x, y, z: -v_adj' (dL/dx) v with v'v = 1 and v_adj' L'(ω) v = 1 (the normalisation uses ``L``, the device-backed
     family).  The interior operators M, K (all tetrahedra touching the point) and, if given, the admittance boundary
-    ω·Y·C (``bnd_tris``: boundary triangles, ``bnd_c``: speed of sound at each, ``Y``) take part; a flame term does not
-    (its volume and reference gradient are not local to one point).  Returns a complex array (3, len(surface_points))."""
+    ω·Y·C (``bnd_tris``: boundary triangles, ``bnd_c``: speed of sound at each, ``Y``) take part, and -- round 3 -- the flame
+    term: ``flame`` = dict(flame_tets, ref_tet, n_ref, nglobal_scaled[, coeff]) as produced by ``flame_description`` / the
+    fixtures (``coeff``: the flame term's scalar n·exp(-iωτ) at ω; default: read from ``L``'s term with operator "Q").  As
+    in the reference the flame domain is re-discretised REDUCED to the tetrahedra at the point, its volume included
+    (``nlocal = nglobal_scaled / V_reduced``, Helmholtz.jl:325 on the reduced mesh of shape_sensitivity.jl:62-80).
+    ``v_ext`` = (v, v_adj) already normalised and given on ``points`` (the unit-cell route extends the sector vectors to the
+    image points and passes them here).  Returns a complex array (3, len(surface_points))."""
     pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
     tt = np.ascontiguousarray(tets, dtype=np.int32).reshape(-1, 4)
     cc = None if c_tet is None else np.ascontiguousarray(c_tet, dtype=np.float64)
     sp_ = np.asarray(surface_points, dtype=np.int64)
     w0 = complex(sol.params[sol.eigval])
-    v = np.asarray(sol.v, dtype=np.complex128)
-    v = v / np.sqrt(np.vdot(v, v))
-    saved = (L.active, L.mode, dict(L.params))
-    L.active, L.mode = [L.eigval], "all"
-    try:
-        va = np.asarray(sol.v_adj, dtype=np.complex128)
-        va = va / np.conj(np.vdot(va, L(w0, 1) @ v))
-    finally:
-        L.active, L.mode, L.params = saved
+    if v_ext is not None:
+        v, va = (np.asarray(x, dtype=np.complex128) for x in v_ext)
+    else:
+        v = np.asarray(sol.v, dtype=np.complex128)
+        v = v / np.sqrt(np.vdot(v, v))
+        saved = (L.active, L.mode, dict(L.params))
+        L.active, L.mode = [L.eigval], "all"
+        try:
+            va = np.asarray(sol.v_adj, dtype=np.complex128)
+            va = va / np.conj(np.vdot(va, L(w0, 1) @ v))
+        finally:
+            L.active, L.mode, L.params = saved
     v, va = np.ascontiguousarray(v), np.ascontiguousarray(va)
     # (point, simplex) adjacency pairs, in surface-point order
     lut = np.full(pts.shape[0], -1, dtype=np.int64)
@@ -145,4 +153,58 @@ def discrete_adjoint_shape_sensitivity(points, tets, c_tet, surface_points, sol,
     np.add.at(sens.T, own_t, out_t)                                   # per point, in pair order: deterministic
     if npair_s:
         np.add.at(sens.T, own_s, out_s)
+    if flame is not None:
+        sens += _flame_shape_part(pts, tt, sp_, lut, v, va, w0, L, flame, h, device)
     return sens
+
+
+def _flame_shape_part(pts, tt, sp_, lut, v, va, w0, L, flame, h, device):
+    """-v_adj' n e^{-iωτ} (Q₊ - Q₋)/(2h) v per surface point and coordinate (wae_p1_shape_sensitivity_flame + the per-point sums)."""
+    fl = np.asarray(flame["flame_tets"], dtype=np.int64)
+    ref = int(flame["ref_tet"])
+    nr = np.ascontiguousarray(flame["n_ref"], dtype=np.float64)
+    coeff = flame.get("coeff")
+    if coeff is None:
+        k = [i for i, t in enumerate(L.terms) if t.operator == "Q"]
+        assert len(k) == 1, "the family needs exactly one term with operator 'Q' (or pass flame['coeff'])"
+        saved = (L.active, L.mode, dict(L.params))
+        L.active, L.mode = [L.eigval], "all"
+        try:
+            coeff = complex(L.coefficients(w0)[k[0]])
+        finally:
+            L.active, L.mode, L.params = saved
+    loc = lut[tt[fl]]                                                 # (nflame, 4): position of each node in surface_points, or -1
+    it, ia = np.nonzero(loc >= 0)
+    pair_tet = fl[it].astype(np.int32)
+    pair_pt = tt[fl[it], ia].astype(np.int32)
+    own = loc[it, ia]
+    rsel = np.nonzero(lut[tt[ref]] >= 0)[0]
+    pair_pt_r = tt[ref][rsel].astype(np.int32)
+    own_r = lut[tt[ref]][rsel]
+    npair, npr = len(pair_tet), len(pair_pt_r)
+    det_pm = np.zeros((npair, 3, 2))
+    ssum = np.zeros(npair, dtype=np.complex128)
+    g_pm = np.zeros((npr, 3, 2), dtype=np.complex128)
+    g0 = np.zeros(1, dtype=np.complex128)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+
+    def P(a, t):
+        return a.ctypes.data_as(t) if a.size else None
+    _lib.check(_lib.lib().wae_p1_shape_sensitivity_flame(
+        int(device), pts.shape[0], pts.ctypes.data_as(dp), tt.shape[0], tt.ctypes.data_as(ip), npair, P(pair_pt, ip), P(pair_tet, ip), ref, npr,
+        P(pair_pt_r, ip), nr.ctypes.data_as(dp), v.view(np.float64).ctypes.data_as(dp), va.view(np.float64).ctypes.data_as(dp), float(h),
+        P(det_pm, dp), P(ssum.view(np.float64), dp), P(g_pm.view(np.float64), dp), g0.view(np.float64).ctypes.data_as(dp)))
+    ns = len(sp_)
+    a_pm = np.zeros((ns, 3, 2), dtype=np.complex128)                  # v_adj' S± per point and coordinate
+    V_pm = np.zeros((ns, 3, 2))                                       # volume of the point's flame tetrahedra
+    np.add.at(a_pm, own, det_pm / 24.0 * ssum[:, None, None])
+    np.add.at(V_pm, own, det_pm / 6.0)
+    b_pm = np.full((ns, 3, 2), g0[0], dtype=np.complex128)            # sum_b grad(phi_b).n_ref v_b on the reference tetrahedron
+    b_pm[own_r] = g_pm
+    out = np.zeros((3, ns), dtype=np.complex128)
+    has = V_pm[:, 0, 0] > 0                                           # points without a flame tetrahedron: empty domain, no term
+    nl = np.zeros_like(V_pm)
+    nl[has] = float(flame["nglobal_scaled"]) / V_pm[has]
+    q = a_pm * (-nl * b_pm)                                           # v_adj' Q± v  (g = -nlocal grad.n_ref)
+    out[:, has] = (-coeff * (q[has, :, 0] - q[has, :, 1]) / (2 * h)).T
+    return out

@@ -19,7 +19,7 @@ import numpy as np
 import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
-from .assemble import assemble_p1, discrete_adjoint_shape_sensitivity  # noqa: F401  (re-export)
+from .assemble import assemble_p1, assemble_p1_flame, discrete_adjoint_shape_sensitivity  # noqa: F401  (re-export)
 
 
 def boundary_triangles(tets):
@@ -145,11 +145,14 @@ def _boundary_mass(points, tris, c_tri, n):
 
 
 def forward_finite_differences_shape_sensitivity(points, tets, c_tet, surface_points, L, sol, bnd_tris=None, bnd_c=None, h=1e-9,
-                                                 device=0, maxiter=5, order=3, nev=3):
+                                                 device=0, maxiter=5, order=3, nev=3, flame=None):
     """Eigenvalue shift per unit displacement of every point in ``surface_points`` along x, y, z, by re-solving
     (src/shape_sensitivity.jl:238-337, full mesh): the family G = L + (D₊ − D₋), D± the discretisations of the simplices
     touching the point with the point moved by ±h, is solved with ``householder`` from the known eigenvalue and
     sens = (ω_new − ω₀)/(2h).  ``L`` must carry terms with operators "M", "K" and, if ``bnd_tris`` is given, "C".
+    ``flame`` (dict as for discrete_adjoint_shape_sensitivity): the flame operator "Q" of the tetrahedra at the point is
+    re-assembled on the device too (``assemble_p1_flame`` on the reduced flame domain, volume included -- what the reference's
+    ``discretize`` of the reduced mesh does).
     Returns (3, len(surface_points)) complex.  One device family and one eigen-solve per point and coordinate: a
     cross-check for a handful of points, not a production gradient (that is discrete_adjoint_shape_sensitivity)."""
     from ..nlevp.linopfam import LinearOperatorFamily, Term
@@ -173,6 +176,10 @@ def forward_finite_differences_shape_sensitivity(points, tets, c_tet, surface_po
                 D[sgn] = {"M": M, "K": K}
                 if len(ssel):
                     D[sgn]["C"] = _boundary_mass(ph, tri[ssel], np.asarray(bnd_c, dtype=np.float64)[ssel], n)
+                if flame is not None:
+                    fsel = np.intersect1d(np.asarray(flame["flame_tets"], dtype=np.int64), tsel)
+                    if len(fsel):
+                        D[sgn]["Q"], _ = assemble_p1_flame(ph, tt, fsel, flame["ref_tet"], flame["n_ref"], flame["nglobal_scaled"], device=device)
             G = LinearOperatorFamily([L.eigval, L.auxval], [0.0, complex(np.inf, 0)], device=device)   # shape_sensitivity.jl:311
             for k, val in L.params.items():
                 G.params[k] = val
@@ -186,3 +193,87 @@ def forward_finite_differences_shape_sensitivity(points, tets, c_tet, surface_po
             sens[crd, idx] = (complex(new_sol.params[new_sol.eigval]) - w0) / (2 * h)
             G._drop_device()
     return sens
+
+
+# ------------------------------------------------------------------------------------------------------
+# unit cells of discretely rotationally symmetric meshes (mesh.dos.unit; src/shape_sensitivity.jl:27-35,84-128)
+# ------------------------------------------------------------------------------------------------------
+def get_cylindrics(pnt):
+    """columns e_r, e_phi, e_z at ``pnt``  (src/shape_sensitivity.jl:381-390)"""
+    X = np.zeros((3, 3))
+    X[:, 2] = [0.0, 0.0, 1.0]
+    X[:2, 0] = pnt[:2]
+    X[:, 0] /= np.linalg.norm(X[:, 0])
+    X[:, 1] = np.cross(X[:, 2], X[:, 0])
+    return X
+
+
+def bloch_extend(v, b, nsector, nxbloch, DOS, naxis=0):
+    """unit-cell vector -> vector on the cell's EXTENDED numbering (image-plane nodes last): an image node carries its
+    reference twin's value times exp(i·b·2π/DOS) -- the map E_b with L_b = E_bᴴ L_ext E_b that ``blochify`` folds into the
+    "+"/"-" terms (src/Bloch.jl:4-113, src/Helmholtz.jl:89-91)."""
+    v = np.asarray(v, dtype=np.complex128)
+    out = np.zeros(nsector + nxbloch, dtype=np.complex128)
+    out[:nsector] = v
+    out[nsector:] = v[naxis:naxis + nxbloch] * np.exp(2j * np.pi / DOS * complex(b))
+    return out
+
+
+def discrete_adjoint_shape_sensitivity_unit_cell(cell, surface_points, sol, L, b=None, h=1e-9, device=0, flame=True):
+    """Shape sensitivity on the unit cell of a Bloch-periodic problem (``mesh.dos.unit``; src/shape_sensitivity.jl:27-35,84-128):
+    a surface point is displaced along e_r, e_phi, e_z (``get_cylindrics``), a point of the reference Bloch boundary together
+    with its image point (each along ITS cylindrical directions), points on the symmetry axis are skipped; the derivative of the
+    Bloch operator L_b(ω) is contracted with the unit-cell eigenvectors.
+
+    Here: with E_b the extension of a unit-cell vector to the cell's extended numbering (``bloch_extend``), L_b = E_bᴴ L_ext E_b
+    -- exactly what ``blochify`` folds -- so the sensitivity is -(E_b v_adj)ᴴ (dL_ext/dx) (E_b v): the Cartesian device kernel
+    on the cell's own mesh with extended vectors, for the point and its image; the cylindrical components are the directional
+    combinations Xᵀ·(Cartesian gradient) (a central difference along a unit direction differs from the combination of the three
+    axis differences by O(h²)).  ``cell``: dict of annulus.build_unit_cell; ``L``: its Bloch family; ``b``: Bloch wave number
+    (default ``sol.params['b']``; the reference evaluates at b = 1, shape_sensitivity.jl:122-125).
+    Returns (3, len(surface_points)): components along e_r, e_phi, e_z."""
+    m = cell["info"]["mesh"]
+    pts = np.asarray(cell["points"], dtype=np.float64)
+    ns, nxb, DOS, naxis = int(cell["nsector"]), int(cell["nxbloch"]), int(cell["DOS"]), int(cell.get("naxis", 0))
+    d_ext = pts.shape[0]
+    assert d_ext == ns + nxb
+    b = complex(sol.params.get("b", 0.0)) if b is None else complex(b)
+    w0 = complex(sol.params[sol.eigval])
+    v = np.asarray(sol.v, dtype=np.complex128)
+    v = v / np.sqrt(np.vdot(v, v))
+    saved = (L.active, L.mode, dict(L.params))
+    L.active, L.mode = [L.eigval], "all"
+    L.params["b"] = b
+    try:
+        va = np.asarray(sol.v_adj, dtype=np.complex128)
+        va = va / np.conj(np.vdot(va, L(w0, 1) @ v))
+        cQ = None
+        if flame and m["flames"]:
+            kq = [i for i, t in enumerate(L.terms) if t.operator == "Q" and t.symbol.endswith(")")]      # the base part n·exp(-iωτ)
+            cQ = complex(L.coefficients(w0)[kq[0]]) if kq else None
+    finally:
+        L.active, L.mode, L.params = saved
+    sp_ = np.asarray(surface_points, dtype=np.int64)
+    twin = lambda p: d_ext - nxb + (p - naxis)                  # noqa: E731   (shape_sensitivity.jl:88)
+    on_bloch = (sp_ >= naxis) & (sp_ < naxis + nxb)
+    allp = np.unique(np.concatenate([sp_, twin(sp_[on_bloch])]))
+    fl = None
+    if cQ is not None:
+        f0 = m["flames"][0]
+        touch = np.isin(m["tets"][f0["flame_tets"]], np.concatenate([np.arange(naxis, naxis + nxb), np.arange(ns, d_ext)])).any()
+        assert not touch, "flame tetrahedra on the Bloch boundary: the reduced flame domain of a point and its image would have to be merged"
+        fl = {**f0, "coeff": cQ}
+    Y = complex(cell["params"]["Y"])
+    cart = discrete_adjoint_shape_sensitivity(pts, m["tets"], m["c_tet"], allp, sol, L, bnd_tris=m["outlet_tris"], bnd_c=m["outlet_c"], Y=Y, h=h,
+                                              device=device, flame=fl,
+                                              v_ext=(bloch_extend(v, b, ns, nxb, DOS, naxis), bloch_extend(va, b, ns, nxb, DOS, naxis)))
+    pos = {int(p): i for i, p in enumerate(allp)}
+    out = np.zeros((3, len(sp_)), dtype=np.complex128)
+    for k, p in enumerate(sp_):
+        if p < naxis:
+            continue                                          # axis points are skipped (shape_sensitivity.jl:93-98)
+        out[:, k] = get_cylindrics(pts[p]).T @ cart[:, pos[int(p)]]
+        if naxis <= p < naxis + nxb:
+            q = twin(p)
+            out[:, k] += get_cylindrics(pts[q]).T @ cart[:, pos[int(q)]]
+    return out

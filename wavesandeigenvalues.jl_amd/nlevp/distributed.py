@@ -107,7 +107,7 @@ def _allgather_dev(local, world):
     return out
 
 
-def beyn_moments_distributed_rb(L, G, V, K, N, S, timings=None, extra=None):
+def beyn_moments_distributed_rb(L, G, V, K, N, S, timings=None, extra=None, zmap=None):
     """Sharded moments with snapshot-projection initial guesses (wae_beyn_moments_rb).  Two exchange steps.
 
     (1) Snapshot phase, split by PROBE COLUMN: every rank solves all S snapshot points for its l/world columns.  The
@@ -118,6 +118,10 @@ def beyn_moments_distributed_rb(L, G, V, K, N, S, timings=None, extra=None):
     projection; the partial moments (snapshot contributions in each rank's own columns included) are summed with one
     all-reduce.  When l is not divisible by the world size the snapshot POINTS are split instead and every rank
     rebuilds the basis from the gathered raw snapshots (mode 1).
+    zmap = (c, rho) (optional): the moments are taken in the variable z' = (z - c)/rho, A_p = sum_j w_j z'_j^p L(z_j)^{-1} V -- the
+    systems solved are the same, only the powers that weigh them change.  Beyn's method is invariant under this affine map (the
+    eigenvalues of the Hankel pencil are (omega - c)/rho; the caller maps them back); with raw powers of z ~ 2 pi 500 the K = 2
+    Hankel matrix has singular values of 1e12 and the eigenvectors lose a digit.
     Returns the flat float64 CUDA tensor of the column-major d x l x 2K moments (on every rank) and solver statistics."""
     import time
 
@@ -129,7 +133,9 @@ def beyn_moments_distributed_rb(L, G, V, K, N, S, timings=None, extra=None):
     zs, ws = gauss_points(G, N)
     from .beyn import coefficient_table, snapshot_split, spread_order
     fam = L.ensure_solver()
-    ct = coefficient_table(L, zs)
+    ct = coefficient_table(L, zs)                    # (the systems: true z)
+    if zmap is not None:                             # (the powers: mapped z)
+        zs = (np.asarray(zs, dtype=np.complex128) - complex(zmap[0])) / complex(zmap[1])
     buf = torch.zeros(d * l * 2 * K * 2, dtype=torch.float64, device=dev)
     torch.cuda.synchronize(dev)        # the library works on its own stream: torch's fill must have landed before it accumulates
     kw = dict(K=K, tol=L.solver_tol, maxit=L.solver_maxit, out_dev=buf.data_ptr())

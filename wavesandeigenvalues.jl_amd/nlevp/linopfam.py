@@ -344,6 +344,13 @@ class DeviceFamily:
                 lv += 1
         return out
 
+    def bench_spmv_level(self, coeffs, which=0, level=1, r=64, reps=20):
+        """(ms per launch, algorithmic bytes per launch) of a level operator / restriction of the hierarchy"""
+        c = np.ascontiguousarray(coeffs, dtype=np.complex128)
+        ms, nbytes = C.c_double(0), C.c_int64(0)
+        check(_lib.lib().wae_bench_spmv_level(self.handle, zptr(c), which, level, r, reps, C.byref(ms), C.byref(nbytes)))
+        return ms.value, nbytes.value
+
     def bench_spmv(self, coeffs, r=1, reps=20):
         c = np.ascontiguousarray(coeffs, dtype=np.complex128)
         ms = C.c_double(0)
