@@ -35,17 +35,19 @@ def _reference(l):
     return A
 
 
-@pytest.mark.parametrize("l,branch", [(4, "columns"), (3, "points")])
+@pytest.mark.parametrize("l,branch", [(4, "hybrid"), (4, "columns"), (3, "points")])
 def test_two_process_projected_guesses_match_single_process(tmp_path, l, branch):
-    """l = 4 on two ranks: the snapshot phase is split by probe column (bases all-gathered and imported); l = 3: not
-    divisible, the snapshot POINTS are split and every rank rebuilds the basis from the gathered raw snapshots."""
+    """l = 4 on two ranks, "hybrid" (the default): snapshot POINTS shared out for the solves (full-width batches from zero, mode 3), one
+    all-to-all of the raw solutions, probe COLUMNS shared out for the basis (mode 4), bases all-gathered and imported; "columns"
+    (WAE_SNAPSHOT_SPLIT=columns): every rank solves all snapshot points for its columns progressively; l = 3: not divisible,
+    the snapshot POINTS are split and every rank rebuilds the whole basis from the gathered raw snapshots."""
     A0 = _reference(l)
     port = _free_port()
     out = str(tmp_path / "rank0.npz")
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", WAE_SNAPSHOT_SPLIT="columns" if branch == "columns" else "hybrid")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_rb_worker.py"), out, str(l), "24"], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
@@ -102,18 +104,22 @@ def test_single_process_mgpu_entry_on_one_device(l, nsnap):
     L._drop_device()
 
 
-@pytest.mark.parametrize("l,nsnap,ngpu", [(4, 24, 2), (3, 24, 2), (4, 0, 2), (6, 24, 3), (5, 24, 3)])
-def test_single_process_mgpu_entry_with_several_virtual_ranks(monkeypatch, l, nsnap, ngpu):
+@pytest.mark.parametrize("l,nsnap,ngpu,split", [(4, 24, 2, "hybrid"), (4, 24, 2, "columns"), (3, 24, 2, "-"), (4, 0, 2, "-"), (6, 25, 3, "hybrid"),
+                                                (6, 24, 3, "columns"), (5, 24, 3, "-")])
+def test_single_process_mgpu_entry_with_several_virtual_ranks(monkeypatch, l, nsnap, ngpu, split):
     """The G > 1 logic of wae_beyn_moments_mgpu on a one-GPU box: WAE_MGPU_EXCHANGE=copy replaces the two RCCL collectives by
     device-to-device copies (and a fixed-order sum), which allows several handles on ONE device to act as ranks.  Everything else
     is the code an 8-GPU node runs: a host thread and a stream per rank, column shares (l divisible by the rank count: the basis
     slabs gathered and merged back into column order by merge_slabs_kernel with G > 1, the projected terms interleaved, wae_rb_import
-    on every rank) or point shares (raw snapshots gathered, every rank rebuilds the basis, slot0 = the used snapshot count),
-    round-robin projected phase, reduction to rank 0.  Against the plain single-GPU moments (<= 1e-8)."""
+    on every rank) -- with the snapshot phase shared out "hybrid" (points for the solves, columns for the basis: modes 3 and 4,
+    slice_cols_kernel; 25 snapshots on 3 ranks: one joins the remaining points) or by "columns" -- or point shares (raw snapshots
+    gathered, every rank rebuilds the basis, slot0 = the used snapshot count), round-robin projected phase, reduction to rank 0.
+    Against the plain single-GPU moments (<= 1e-8)."""
     from wae_amd import _lib
     from wae_amd.helmholtz.family import annulus_family
     from wae_amd.nlevp.distributed import beyn_moments_mgpu
     monkeypatch.setenv("WAE_MGPU_EXCHANGE", "copy")
+    monkeypatch.setenv("WAE_SNAPSHOT_SPLIT", "columns" if split == "columns" else "hybrid")
     A0 = _reference(l)
     fams = []
     for _ in range(ngpu):

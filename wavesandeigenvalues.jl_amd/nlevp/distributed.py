@@ -107,6 +107,22 @@ def _allgather_dev(local, world):
     return out
 
 
+def _alltoall_dev(send, world):
+    """all-to-all of equal pieces of a flat device tensor (piece r goes to rank r; the result holds the pieces of ranks 0, 1, ...);
+    through an all-gather on the host under gloo (which has no all-to-all)"""
+    import torch
+    dd = _dist()
+    if dd.get_backend() == "nccl":
+        out = torch.empty_like(send)
+        dd.all_to_all_single(out, send)                      # RCCL over xGMI, device to device
+        return out
+    n = send.numel() // world
+    parts = [torch.empty(send.numel(), dtype=send.dtype) for _ in range(world)]
+    dd.all_gather(parts, send.cpu())
+    rank = dd.get_rank()
+    return torch.cat([p[rank * n:(rank + 1) * n] for p in parts]).to(send.device)
+
+
 def beyn_moments_distributed_rb(L, G, V, K, N, S, timings=None, extra=None, zmap=None):
     """Sharded moments with snapshot-projection initial guesses (wae_beyn_moments_rb).  Two exchange steps.
 
@@ -140,19 +156,46 @@ def beyn_moments_distributed_rb(L, G, V, K, N, S, timings=None, extra=None, zmap
     torch.cuda.synchronize(dev)        # the library works on its own stream: torch's fill must have landed before it accumulates
     kw = dict(K=K, tol=L.solver_tol, maxit=L.solver_maxit, out_dev=buf.data_ptr())
     by_column = world > 1 and l % world == 0
+    # how the snapshot phase is shared out when the probe columns divide over the ranks (WAE_SNAPSHOT_SPLIT):
+    #   "hybrid" (default): POINTS for the solves -- a rank's S/world snapshot points x all l columns are full-width batches from
+    #       zero guesses (mode 3) --, one all-to-all of the raw solutions, COLUMNS for the basis -- every rank orthonormalises and
+    #       projects all S snapshots of its l/world columns (mode 4) -- then the exchange of the finished bases as below;
+    #   "columns": every rank solves all S points for its columns progressively (mode 0): fewer, longer, narrower recurrences.
+    import os
+    split = os.environ.get("WAE_SNAPSHOT_SPLIT", "hybrid")
+    hybrid = by_column and split == "hybrid" and int(S) >= world
     t0 = time.perf_counter()
     if by_column or world == 1:
         S = min(int(S), len(zs))
+        if hybrid:
+            S = (S // world) * world                              # equal shares (the all-to-all wants equal sizes)
         idx, rest = snapshot_split(len(zs), S)
         idx = spread_order(idx)
         S = len(idx)
         ls = l // world
         c0 = rank * ls
         cap = S + (0 if (extra is None or world > 1) else int(extra))
-        local = torch.empty(cap * d * ls * 2, dtype=torch.float64, device=dev)
-        _, err = _guard(fam.beyn_moments_rb, zs[idx], ws[idx], ct[idx], V[:, c0:c0 + ls], 0, cap, Q_dev=local.data_ptr(), l_total=l, col0=c0, **kw)
-        fail_together(err, "snapshot phase")
-        i0 = dict(fam.last_info)
+        if hybrid:
+            per = S // world
+            mine = idx[rank::world]
+            raw = torch.empty(per * d * l * 2, dtype=torch.float64, device=dev)
+            _, err = _guard(fam.beyn_moments_rb, zs[mine], ws[mine], ct[mine], V, 3, per, Q_dev=raw.data_ptr(), **kw)
+            fail_together(err, "snapshot phase (solves)")
+            i0 = dict(fam.last_info)
+            torch.cuda.synchronize(dev)
+            send = raw.view(per, d, world, ls, 2).permute(2, 0, 1, 3, 4).contiguous()      # [destination rank][s][row][c_local]
+            del raw
+            local = _alltoall_dev(send.view(-1), world)                                    # [source rank][s][row][c_local] = S x d x ls
+            del send
+            order = np.concatenate([idx[r::world] for r in range(world)])                   # snapshot point behind every slot
+            _, err = _guard(fam.beyn_moments_rb, zs[order], ws[order], ct[order], V[:, c0:c0 + ls], 4, S, slot0=S, Q_dev=local.data_ptr(),
+                            accumulate=True, l_total=l, col0=c0, **kw)
+            fail_together(err, "snapshot phase (basis)")
+        else:
+            local = torch.empty(cap * d * ls * 2, dtype=torch.float64, device=dev)
+            _, err = _guard(fam.beyn_moments_rb, zs[idx], ws[idx], ct[idx], V[:, c0:c0 + ls], 0, cap, Q_dev=local.data_ptr(), l_total=l, col0=c0, **kw)
+            fail_together(err, "snapshot phase")
+            i0 = dict(fam.last_info)
         snap_cols = S * ls
         t1 = time.perf_counter()
         if world > 1:
@@ -211,7 +254,7 @@ def beyn_moments_distributed_rb(L, G, V, K, N, S, timings=None, extra=None, zmap
             "relres_max": max(i0["relres_max"], i1["relres_max"]), "seconds": i0["seconds"] + i1["seconds"],
             "snapshot_iters": i0["iters_total"], "projected_iters": i1["iters_total"], "snapshots": S,
             "snapshot_columns": snap_cols, "projected_columns": len(mine2) * l,
-            "snapshot_split": "columns" if by_column else ("points" if world > 1 else "none")}
+            "snapshot_split": ("hybrid" if hybrid else "columns") if by_column else ("points" if world > 1 else "none")}
     return buf, info
 
 
