@@ -302,17 +302,19 @@ extern "C" int wae_beyn_moments_mgpu(wae_family *const *handles, int32_t ngpu, i
             }));
         } else if (l % ngpu == 0) {
             // The probe columns divide over the devices.  Snapshot phase, WAE_SNAPSHOT_SPLIT:
-            //   "hybrid" (default): POINTS for the solves -- device g solves its Sb / ngpu snapshot points for ALL l columns as
-            //       full-width batches from zero guesses (mode 3) --, the raw solutions are gathered, and COLUMNS for the basis:
-            //       device g orthonormalises and projects all Sb snapshots of ITS l / ngpu columns (mode 4);
-            //   "columns": device g solves all S points for its columns progressively (mode 0) -- fewer, longer, narrower
-            //       recurrences (one rank's share of the 1M-unknown case at 8 GPUs: 0.40 s against 0.18 s ideal).
+            //   "columns" (default): device g solves all S points for its columns progressively (mode 0) -- fewer, longer, narrower
+            //       recurrences (one rank's share of the 1M-unknown case at 8 GPUs: 0.35 s against 0.16 s ideal);
+            //   "hybrid": POINTS for the solves -- device g solves its Sb / ngpu snapshot points for ALL l columns as full-width
+            //       batches from zero guesses (mode 3) --, the raw solutions are gathered, and COLUMNS for the basis: device g
+            //       orthonormalises and projects all Sb snapshots of ITS l / ngpu columns (mode 4).  Measured (dev/c3_rank_share.py):
+            //       0.36 s at 8 GPUs, 0.63 at 4, 1.38 at 2 against 0.35 / 0.54 / 0.90: without the progressive guesses the solves
+            //       need half as many iterations again.  An option, not the default.
             // Either way each device then holds a finished basis for its columns: (2) all-gather of the basis vectors, exchange of
             // the small projected terms on the host; (3) the remaining points round-robin, every system from the projection on
             // the full basis.
             const int ls = l / ngpu;
             const char *se = getenv("WAE_SNAPSHOT_SPLIT");
-            const bool hybrid = S >= ngpu && !(se && std::string(se) == "columns");
+            const bool hybrid = S >= ngpu && se && std::string(se) == "hybrid";
             const int Sb = hybrid ? (S / ngpu) * ngpu : S;      // snapshots in the basis (equal shares); the others join the remaining points
             if (hybrid)
                 for (int i = Sb; i < S; ++i) rest.push_back(snap[i]);

@@ -157,12 +157,15 @@ def beyn_moments_distributed_rb(L, G, V, K, N, S, timings=None, extra=None, zmap
     kw = dict(K=K, tol=L.solver_tol, maxit=L.solver_maxit, out_dev=buf.data_ptr())
     by_column = world > 1 and l % world == 0
     # how the snapshot phase is shared out when the probe columns divide over the ranks (WAE_SNAPSHOT_SPLIT):
-    #   "hybrid" (default): POINTS for the solves -- a rank's S/world snapshot points x all l columns are full-width batches from
-    #       zero guesses (mode 3) --, one all-to-all of the raw solutions, COLUMNS for the basis -- every rank orthonormalises and
-    #       projects all S snapshots of its l/world columns (mode 4) -- then the exchange of the finished bases as below;
-    #   "columns": every rank solves all S points for its columns progressively (mode 0): fewer, longer, narrower recurrences.
+    #   "columns" (default): every rank solves all S points for its l/world columns progressively (mode 0);
+    #   "hybrid": POINTS for the solves -- a rank's S/world snapshot points x all l columns are full-width batches from zero
+    #       guesses (mode 3) --, one all-to-all of the raw solutions, COLUMNS for the basis -- every rank orthonormalises and
+    #       projects all S snapshots of its l/world columns (mode 4) -- then the exchange of the finished bases as below.
+    # Measured rank shares at 1M unknowns (dev/c3_rank_share.py, profiles/r03_rank_share.json; S = 40, l = 8): columns 0.90 / 0.54 /
+    # 0.35 s at 2 / 4 / 8 ranks, hybrid 1.38 / 0.63 / 0.36 s: the progressive guesses save more iterations (759 against 1 135
+    # column-iterations at 8 ranks) than the narrow batches cost, and the slice basis is another 0.08-0.13 s.  Hence the default.
     import os
-    split = os.environ.get("WAE_SNAPSHOT_SPLIT", "hybrid")
+    split = os.environ.get("WAE_SNAPSHOT_SPLIT", "columns")
     hybrid = by_column and split == "hybrid" and int(S) >= world
     t0 = time.perf_counter()
     if by_column or world == 1:
