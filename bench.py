@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--restart", type=int, default=40)
     ap.add_argument("--sweeps", type=int, default=1)
+    ap.add_argument("--jacw", type=float, default=0.8, help="Jacobi weight of the V-cycle's smoother")
     ap.add_argument("--n", type=float, default=1.0)
     ap.add_argument("--tau", type=float, default=2e-4)
     ap.add_argument("--rb", type=int, default=-1,
@@ -145,7 +146,7 @@ def main():
     L.solver_tol = args.tol
     L.solver_maxit = 400
     L.solver_ref = 2 * np.pi * float(os.environ.get("WAE_REF_HZ", "500"))
-    L.solver_opts = {"batch": args.batch, "restart": args.restart, "sweeps": args.sweeps,
+    L.solver_opts = {"batch": args.batch, "restart": args.restart, "sweeps": args.sweeps, "jacobi_weight": args.jacw,
                      # workspace hints: the snapshot store of the passes to come is mapped during the set-up
                      "probe_columns": args.l // world if (world > 1 and args.l % world == 0) else args.l, "snapshots": args.rb}
     from wae_amd.nlevp.distributed import warm_up_dense_linalg

@@ -575,9 +575,12 @@ static cplx *vcycle(wae_family *h, const Batch &bt, int l, const cplx *b, const 
     launch_prolong_add(h->xfer[l].p_ptr.p, h->xfer[l].p_col.p, h->xfer[l].p_val.p, h->xfer[l].nf, xc, x, bt.nb, st, cm);
     static const int post_coarse = getenv("WAE_VC_POST_COARSE") ? atoi(getenv("WAE_VC_POST_COARSE")) : 1;
     const int npost = (l >= 1 && !post_coarse) ? 0 : h->nsweeps;
+    // (WAE_JAC_POST: a post-smoothing weight of its own -- two sweeps with different weights form a degree-2 polynomial smoother)
+    static const double w_post_env = getenv("WAE_JAC_POST") ? atof(getenv("WAE_JAC_POST")) : 0.0;
+    const double w_post = w_post_env > 0.0 ? w_post_env : h->jac_w;
     for (int s = 0; s < npost; ++s) {
         cplx *dst = (final_out && s == npost - 1) ? final_out : t;
-        launch_spmv(A, pc, bt.cps, x, dst, b, h->jac_w, bt.nb, MODE_JAC, st, cm);
+        launch_spmv(A, pc, bt.cps, x, dst, b, w_post, bt.nb, MODE_JAC, st, cm);
         if (dst == t) std::swap(x, t); else x = dst;
     }
     if (final_out && x != final_out) { launch_copy(x, final_out, (size_t)h->ops[l].n * bt.nb, st); x = final_out; }
