@@ -198,7 +198,8 @@ def test_G1_householder_and_G2_perturbation():
     sol, n, flag = householder(Lp, 340 * 2 * np.pi, maxiter=20, tol=1e-11)
     w = c(G["G1"]["omega"])
     assert abs(sol.params["ω"] - w) < 1e-10 * abs(w)
-    assert flag in (-1, 0, 1) and 4 <= n <= 12       # see the note on the 1e-11 floor in test_G5
+    # the reference records 7 / 6 / 5 iterations for this call (three notebook runs) and a converged flag; the device path: 7
+    assert flag in (0, 1) and 5 <= n <= 9
     first = next(i for i, zk in enumerate(sol.history) if abs(zk - w) < 1e-9 * abs(w))
     assert first <= G["G1"]["iterations"] - 2
     for mine, ref in zip(sol.history, G["G1"]["iterates"]):
@@ -219,7 +220,7 @@ def test_G5_mslp_active_flame():
     assert abs(sol.params["ω"] - w) < 1e-10 * abs(w)
     # the reference stops after 8 iterations at |Δω| <= 1e-11 (absolute, ~1e-14 relative): whether the last
     # iterates dip below that floor is rounding noise, so pin the convergence history instead of the final count
-    assert flag in (0, 1, 2) and n <= 14
+    assert flag in (0, 1) and n <= G["G5"]["iterations"] + 2          # (the reference: 8 iterations; the device path: 8)
     first = next(i for i, zk in enumerate(sol.history) if abs(zk - w) < 1e-9 * abs(w))
     assert first <= G["G5"]["iterations"] - 1
     # padesolve = the same iteration with householder's flags; order 2 exercises the in-loop perturbation solve
@@ -899,7 +900,7 @@ def test_saved_family_and_solution_files_drive_the_device(tmp_path):
         assert len(L.terms) == 5 and L._fam is None                    # nothing on the device until it is used
         L.solver_ref = 340 * 2 * np.pi
         sol, n, flag = householder(L, 340 * 2 * np.pi, maxiter=20, tol=1e-11)
-        assert abs(sol.params["ω"] - w) < 1e-10 * abs(w) and flag in (-1, 0, 1)
+        assert abs(sol.params["ω"] - w) < 1e-10 * abs(w) and flag in (0, 1) and 5 <= n <= 9      # (as test_G1: the reference 7 / 6 / 5)
         for mine, ref in zip(sol.history, G["G1"]["iterates"]):
             assert abs(mine - c(ref)) < 1e-6 * abs(c(ref))
         perturb_fast_(sol, L, "τ", 8)

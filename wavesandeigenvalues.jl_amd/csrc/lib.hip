@@ -877,7 +877,9 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
     // small matrix is not something to build a projector from)
     const bool deflate = guess_dir != nullptr && env_defl && h->ops.size() > 1;
     const int off = deflate ? 1 : 0;
-    const int m = (int)std::min<size_t>(150, h->V.n / vec - 1) - off;
+    // (recurrence length of the narrow batches: WAE_GMRES_NARROW_M, default 150 -- the basis buffer of the wide batches holds it)
+    static const int narrow_m = getenv("WAE_GMRES_NARROW_M") ? std::max(10, atoi(getenv("WAE_GMRES_NARROW_M"))) : 150;
+    const int m = (int)std::min<size_t>((size_t)narrow_m, h->V.n / vec - 1) - off;
     static const char *env_re = getenv("WAE_REORTH");
     const bool reorth = env_re ? atoi(env_re) != 0 : nb <= 8;
     // wide batches, single Gram-Schmidt pass: unnormalised basis (see the inner loop); WAE_LAZY=0 restores the normalisation pass
@@ -2671,12 +2673,17 @@ int wae_bench_spmv(wae_family *h, const double *coeffs, int32_t r, int32_t reps,
             for (int q = 0; q < h->nplanes; ++q) { const zc c = pc[h->slot_plane[0][q]]; tab[(size_t)sidx * h->nplanes + q] = cplx{c.real(), c.imag()}; }
         pcd.upload(tab.data(), tab.size(), st);
         const OpDev A = h->ops[0].dev(WAE_OP_N);
-        for (int i = 0; i < 3; ++i) launch_spmv(A, pcd.p, cps, x.p, y.p, nullptr, 0.0, r, MODE_AX, st);
+        // WAE_BENCH_MODE (diagnostic): the fused form timed -- 0 A X (default), 1 residual, 2 Jacobi sweep, 6 product + first sweep
+        const int bmode = getenv("WAE_BENCH_MODE") ? atoi(getenv("WAE_BENCH_MODE")) : MODE_AX;
+        DevBuf<cplx> bb;
+        if (bmode != MODE_AX) { bb.alloc(cnt); HIP_CHECK(hipMemcpyAsync(bb.p, hx.data(), cnt * sizeof(cplx), hipMemcpyHostToDevice, st)); }
+        auto one = [&]() { launch_spmv(A, pcd.p, cps, x.p, y.p, bmode != MODE_AX ? bb.p : nullptr, 0.8, r, bmode, st); };
+        for (int i = 0; i < 3; ++i) one();
         hipEvent_t e0, e1;
         HIP_CHECK(hipEventCreate(&e0));
         HIP_CHECK(hipEventCreate(&e1));
         HIP_CHECK(hipEventRecord(e0, st));
-        for (int i = 0; i < reps; ++i) launch_spmv(A, pcd.p, cps, x.p, y.p, nullptr, 0.0, r, MODE_AX, st);
+        for (int i = 0; i < reps; ++i) one();
         HIP_CHECK(hipEventRecord(e1, st));
         HIP_CHECK(hipEventSynchronize(e1));
         float ms = 0.f;
