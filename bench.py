@@ -329,7 +329,8 @@ def main():
             tol_beyn = L.solver_tol
             L.solver_tol = 1e-12                  # the Ritz test of the shift-invert Arnoldi (1e-12) needs inner solves at least as accurate
             try:
-                outs = householder_many(L, list(Om[good]), maxiter=6, tol=1e-8 * 2 * np.pi, v0s=P_host) if n_eig else []
+                nstats = {}
+                outs = householder_many(L, list(Om[good]), maxiter=6, tol=1e-8 * 2 * np.pi, v0s=P_host, stats=nstats) if n_eig else []
             finally:
                 L.solver_tol = tol_beyn
             t_newton = time.time() - t0n
@@ -339,6 +340,7 @@ def main():
                              "eigenpairs_refined_per_sec": len(conv) / t_newton if t_newton > 0 else None, "seconds": t_newton,
                              "refined": len(conv), "of": len(outs), "newton_steps": [int(o[1]) for o in outs],
                              "largest_relative_shift_from_beyn_estimate": float(max(shift)) if shift else None,
+                             "phases": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in nstats.items()},
                              "spmv_r1": roof["r1"], "spmv_r8": roof["r8"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.l, args.N, max(n_eig, 1), d, args.tau, args.n, budget_s=args.cpu_budget)

@@ -457,7 +457,7 @@ def count_poles_and_zeros(L, G, N=16, output=False):
 # or eight), so refining 8 estimates together costs about as much as refining one.  Same iteration as `householder`
 # (Householder.jl:70-192) per start value; only the order of the device work changes.
 # ------------------------------------------------------------------------------------------------------
-def eigs_many(fam, cA, cM, v0s, op, sigmas, nev=1, tol=1e-12, maxiter=300, stol=1e-12, smax=400):
+def eigs_many(fam, cA, cM, v0s, op, sigmas, nev=1, tol=1e-12, maxiter=300, stol=1e-12, smax=400, stats=None):
     """`eigs` for nsys operator pairs (A_s - sigma_s M, M) in lock-step.  cA: (nsys, T) coefficient rows, cM: (T,).
     Returns per system (lam[nev], V[d, nev], gap) or an EigsError instance."""
     cA = np.asarray(cA, dtype=np.complex128)
@@ -473,6 +473,8 @@ def eigs_many(fam, cA, cM, v0s, op, sigmas, nev=1, tol=1e-12, maxiter=300, stol=
         H, V = fam.arnoldi_batch(cAs[pending], cM, step, V0[:, pending], op=op, tol=stol, maxit=smax,
                                  ritz_tol=tol if nev == 1 else 0.0, quiet=True)
         total += step
+        if stats is not None:
+            stats["inner_column_iterations"] = stats.get("inner_column_iterations", 0) + int(fam.last_info.get("iters_total", 0))
         failed = fam.last_info["n_unconverged"] > 0 and fam.last_info["relres_max"] > 1e-4
         still = []
         for q, s in enumerate(pending):
@@ -504,9 +506,14 @@ def eigs_many(fam, cA, cM, v0s, op, sigmas, nev=1, tol=1e-12, maxiter=300, stol=
     return out
 
 
-def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, v0s=None, v0s_adj=None, output=False):
+def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, v0s=None, v0s_adj=None, output=False, stats=None):
     """[(sol, n, flag), ...] = householder_many(L, zs; ...): `householder` for several start values, the device work
-    (two shift-invert Arnoldi processes per Newton step and start value) batched over the start values."""
+    (two shift-invert Arnoldi processes per Newton step and start value) batched over the start values.
+    stats (optional dict): receives the seconds spent in the right / left Arnoldi processes and in the perturbation step, the
+    number of lock-step Newton rounds and the inner (Krylov) column-iterations."""
+    import time as _time
+    st_ = {"right_arnoldi_seconds": 0.0, "left_arnoldi_seconds": 0.0, "perturbation_seconds": 0.0, "newton_rounds": 0,
+           "inner_column_iterations": 0}
     zs = [complex(z) for z in zs]
     ns = len(zs)
     d = L.size()
@@ -540,8 +547,13 @@ def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, orde
             sig.append(1e-5 * gp if (np.isfinite(gp) and lp < 1e-4 * gp) else 0.0)
         cA = np.array(cA)
         try:
-            right = eigs_many(fam, cA, cM, V[:, act], OP_N, sig, stol=L.solver_tol, smax=L.solver_maxit)
-            left = eigs_many(fam, cA, cM, W[:, act], OP_C, sig, stol=L.solver_tol, smax=L.solver_maxit)
+            st_["newton_rounds"] += 1
+            t_ = _time.perf_counter()
+            right = eigs_many(fam, cA, cM, V[:, act], OP_N, sig, stol=L.solver_tol, smax=L.solver_maxit, stats=st_)
+            st_["right_arnoldi_seconds"] += _time.perf_counter() - t_
+            t_ = _time.perf_counter()
+            left = eigs_many(fam, cA, cM, W[:, act], OP_C, sig, stol=L.solver_tol, smax=L.solver_maxit, stats=st_)
+            st_["left_arnoldi_seconds"] += _time.perf_counter() - t_
         except WaeError as e:
             for s in act:
                 flag[s] = -6 if e.code == -2 else -2
@@ -558,9 +570,11 @@ def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, orde
             L.params[L.auxval] = lam_r[0]
             L.active = [L.auxval, L.eigval]
             try:
+                t_ = _time.perf_counter()
                 sol = Solution(L.params, v_r[:, 0], v_l[:, 0], L.auxval)
                 perturb_(sol, L, L.eigval, order, mode="householder")
                 dz = upd(sol.eigval_pert[f"{L.eigval}/Taylor"])
+                st_["perturbation_seconds"] += _time.perf_counter() - t_
             except WaeError as e:
                 flag[s] = -6 if e.code == -2 else -2
                 continue
@@ -596,4 +610,6 @@ def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, orde
         sol.history = hist[s]
         out.append((sol, n[s], f))
     L.active, L.mode = active, mode
+    if stats is not None:
+        stats.update(st_)
     return out
