@@ -194,7 +194,9 @@ def main():
         res = None
         if rank == 0:
             t.append(time.time())
-            Om, Pd, S = moments2eigs_device(buf, (d, args.l, 2 * K))       # SVD on the GPU, small eig on the host
+            # SVD on the GPU, small eig on the host; K > 1: through the Gram matrix (the Hankel matrix is rank-deficient by construction:
+            # Householder QR of the 2d x 16 matrix alone took 0.12 s of a pass), directions above 1e-6 sigma_1 kept (beyn.jl:92-95 `tol`)
+            Om, Pd, S = moments2eigs_device(buf, (d, args.l, 2 * K), gram_rel_tol=1e-6 if K > 1 else 0.0)
             if zmap is not None:
                 Om = zmap[0] + zmap[1] * Om                                  # back from the mapped variable of the moments
             mask = np.array([inpoly(w, G) for w in Om], dtype=bool)         # pos_test (beyn.jl:104-107)

@@ -2,7 +2,7 @@
 """profiles/<TAG>_spmv_traffic_<PRESET>.json and the csv copies from gpurun_out/prof_<TAG>_<PRESET>/ (dev/collect_spmv_profile.sh)."""
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ALG = {"C3": 2643060688, "C2": None}
 for preset in ("C3", "C2"):
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{preset}")
@@ -26,6 +26,8 @@ for preset in ("C3", "C2"):
     json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_spmv_traffic_{preset}.json"), "w"), indent=1)
     for name, dst in (("fetch/fetch_counter_collection.csv", f"{tag}_spmv_pmc_{preset}_FETCH_SIZE.csv"),
                       ("write/write_counter_collection.csv", f"{tag}_spmv_pmc_{preset}_WRITE_SIZE.csv"),
-                      ("stats/stats_kernel_stats.csv", f"{tag}_spmv_only_{preset}_kernel_stats.csv")):
-        shutil.copy(os.path.join(src, name), os.path.join(ROOT, "profiles", dst))
+                      ("stats/stats_kernel_stats.csv", f"{tag}_spmv_only_{preset}_kernel_stats.csv"),
+                      ("sq/sq_counter_collection.csv", f"{tag}_spmv_pmc_{preset}_SQ.csv"), ("lds/lds_counter_collection.csv", f"{tag}_spmv_pmc_{preset}_LDS.csv")):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(ROOT, "profiles", dst))
     print(preset, json.dumps(out["kernels"], indent=1), "traffic GB", traffic / 1e9)
