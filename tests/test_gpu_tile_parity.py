@@ -91,11 +91,15 @@ def test_tile_kernel_at_benchmark_size_against_scipy(preset, d_expect):
     L._drop_device()
 
 
-@pytest.mark.parametrize("tail,waves", [("1", "8"), ("4", "8"), ("4", "16")])
-def test_persistent_work_list_forced_onto_a_small_problem(tail, waves):
+@pytest.mark.parametrize("tail,waves,long_row", [("1", "8", ""), ("4", "8", "12"), ("4", "16", "")])
+def test_persistent_work_list_forced_onto_a_small_problem(tail, waves, long_row):
     """tests/tile_worker.py under WAE_TILE_GRID=8: 35 fine tiles on "8 CUs" -- static + dynamic draw, stealing, tail parts.
-    waves = 16: the 16-wavefront form of the fine-level kernel (four lanes per row; an option, slower: DESIGN 4b)."""
+    waves = 16: the 16-wavefront form of the fine-level kernel (four lanes per row; an option, slower: DESIGN 4b).
+    long_row = 12 (WAE_LONG_ROW): the rows of the TRANSPOSED flame term with more than 12 entries take the long-side-row path of the
+    tile kernel's transposed orientation (op = C checks of the worker), as the reference nodes' rows do at the benchmark sizes."""
     env = dict(os.environ, WAE_TILE_GRID="8", WAE_TILE_TAIL=tail, WAE_TILE_WAVES=waves)
+    if long_row:
+        env["WAE_LONG_ROW"] = long_row
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tile_worker.py")], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     res = json.loads(out.stdout.strip().split("\n")[-1])

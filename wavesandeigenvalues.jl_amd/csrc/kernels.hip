@@ -430,6 +430,33 @@ __global__ __launch_bounds__(256) void spmv_side_kernel(TileDev td, int npl, int
     td.side_acc[(size_t)i * nb + b] = acc;
 }
 
+// Long side rows (TileDev::nlong_side; the transposed orientation of a flame term): side_acc[ls_side[li]][b] = the row's sum, one
+// workgroup per (row, 8-column chunk) as spmv_long_kernel; runs after spmv_side_kernel, which wrote zeros there (empty CSR rows).
+__global__ __launch_bounds__(256) void spmv_side_long_kernel(TileDev td, int npl, int conj, const cplx *__restrict__ pc, int cps,
+                                                             const cplx *__restrict__ X, int nb, const unsigned char *__restrict__ cmask) {
+    __shared__ cplx red[256];
+    const int li = blockIdx.x, ch = blockIdx.y;
+    if (cmask && !cmask[ch]) return;
+    const int tid = threadIdx.x, c = tid & 7, seg = tid >> 3;
+    const int b = ch * 8 + c;
+    const int bb = b < nb ? b : nb - 1;
+    const cplx *mypc = pc + (size_t)(bb / cps) * npl;
+    const double sg = conj ? -1.0 : 1.0;
+    cplx acc = {0.0, 0.0};
+    for (int p = td.ls_ptr[li] + seg; p < td.ls_ptr[li + 1]; p += 32) {
+        cplx a = td.ls_val[p];
+        a.y *= sg;
+        cfma(acc, cmul(mypc[td.ls_slot[p]], a), X[(size_t)td.ls_col[p] * nb + bb]);
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int off = 128; off >= 8; off >>= 1) {
+        if (tid < off) { red[tid].x += red[tid + off].x; red[tid].y += red[tid + off].y; }
+        __syncthreads();
+    }
+    if (tid < 8 && b < nb) td.side_acc[(size_t)td.ls_side[li] * nb + b] = red[tid];
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Tile kernel for batch widths >= 8 on an operator whose rows have been renumbered into tiles (tiles.h): the fine level (LPR = 2
 // lanes per row), the first coarse level and the fine-to-coarse restriction (LPR = 4).  DESIGN.md 4b tells how it got here.
@@ -1202,6 +1229,11 @@ static void launch_spmv_tile(const OpDev &op, const TileDev &td, const cplx *pc,
         hipLaunchKernelGGL(spmv_side_kernel, dim3((unsigned)((td.nside + 31) / 32), (unsigned)nchunks), dim3(256), 0, st, td, op.nplanes_total,
                            op.conj_diag, pc, cps, X, nb, cmask);
         HIP_CHECK(hipGetLastError());
+        if (td.nlong_side) {
+            hipLaunchKernelGGL(spmv_side_long_kernel, dim3((unsigned)td.nlong_side, (unsigned)nchunks), dim3(256), 0, st, td, op.nplanes_total,
+                               op.conj_diag, pc, cps, X, nb, cmask);
+            HIP_CHECK(hipGetLastError());
+        }
     }
 #define WAE_TILE_LAUNCH(U, L, N) hipLaunchKernelGGL((spmv_tile_kernel<U, L, N>), grid, dim3(512), shm, st, op, td, pc, cps, X, Y, B, jac_w, nb, mode, cmask, spc_all, csplit)
     // QUAD form (16 wavefronts, four lanes per row): the same tile storage as the 2-lane form; one system per chunk only

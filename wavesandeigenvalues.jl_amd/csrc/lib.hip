@@ -26,7 +26,7 @@ OpDev LevelOp::dev(int op) const {
     o.n = n;
     o.diag = diag.p;
     o.conj_diag = (op == WAE_OP_C) ? 1 : 0;
-    o.tiles = (tiles.ready && (op == WAE_OP_N || tiles.all_symmetric)) ? &tiles.dev : nullptr;
+    o.tiles = !tiles.ready ? nullptr : (op == WAE_OP_N || tiles.all_symmetric) ? &tiles.dev : (tiles.ready_t ? &tiles.dev_t : nullptr);
     {
         const LongRows &LR = (op == WAE_OP_N) ? long_n : long_t;
         o.nlong = LR.n;
@@ -362,44 +362,122 @@ static void build_level_tiles(LevelOp &L, const std::vector<CsrZ> &planes, const
     }
     T.all_symmetric = true;
     for (size_t g = 0; g < ng; ++g) T.all_symmetric = T.all_symmetric && L.groups[g].symmetric;
-    {   // side rows: every entry of the other groups, row by row (level numbering), plane slot and complex value per entry
+    // side rows: every entry of the other groups, row by row (level numbering), plane slot and complex value per entry.  transposed:
+    // the entries of the groups' transposes (symmetric groups as they are); rows longer than the long-row limit keep an empty CSR row
+    // and go to the long list instead
+    struct SideHost {
+        std::vector<int> of_row, ptr, col, slot, ls_ptr, ls_col, ls_slot, ls_side;
+        std::vector<cplx> val, ls_val;
+        int nside = 0;
+    };
+    auto build_side = [&](bool transposed) {
+        SideHost S;
         const int64_t n = L.n;
+        const int limit = getenv("WAE_LONG_ROW") ? std::max(1, atoi(getenv("WAE_LONG_ROW"))) : WAE_LONG_ROW;
+        std::vector<CsrZ> trs;                                 // transposes of the non-symmetric planes, in (group, plane) order
+        std::vector<const CsrZ *> src;                         // per (group >= 1, plane): the matrix to take rows from
+        std::vector<int> src_slot;
+        for (size_t g = 1; g < ng; ++g)
+            for (int q = 0; q < L.groups[g].nplanes; ++q) {
+                const CsrZ &A = planes[slot_plane[L.groups[g].plane0 + q]];
+                src_slot.push_back(L.groups[g].plane0 + q);
+                if (transposed && !L.groups[g].symmetric) trs.push_back(csr_transpose(A));
+            }
+        size_t it = 0;
+        for (size_t g = 1; g < ng; ++g)
+            for (int q = 0; q < L.groups[g].nplanes; ++q)
+                src.push_back(transposed && !L.groups[g].symmetric ? &trs[it++] : &planes[slot_plane[L.groups[g].plane0 + q]]);
         std::vector<int> count((size_t)n, 0);
-        for (size_t g = 1; g < ng; ++g)
-            for (int q = 0; q < L.groups[g].nplanes; ++q) {
-                const CsrZ &A = planes[slot_plane[L.groups[g].plane0 + q]];
-                for (int64_t i = 0; i < n; ++i) count[(size_t)i] += A.ptr[i + 1] - A.ptr[i];
-            }
-        std::vector<int> of_row((size_t)n, -1), ptr(1, 0);
+        for (const CsrZ *A : src)
+            for (int64_t i = 0; i < n; ++i) count[(size_t)i] += A->ptr[i + 1] - A->ptr[i];
+        S.of_row.assign((size_t)n, -1);
+        S.ptr.assign(1, 0);
+        S.ls_ptr.assign(1, 0);
+        std::vector<char> is_long((size_t)n, 0);
         for (int64_t i = 0; i < n; ++i)
-            if (count[(size_t)i]) { of_row[(size_t)i] = (int)ptr.size() - 1; ptr.push_back(ptr.back() + count[(size_t)i]); }
-        const int nside = (int)ptr.size() - 1;
-        std::vector<int> col((size_t)ptr.back()), slot((size_t)ptr.back()), fill(ptr.begin(), ptr.end() - 1);
-        std::vector<cplx> val((size_t)ptr.back());
-        for (size_t g = 1; g < ng; ++g)
-            for (int q = 0; q < L.groups[g].nplanes; ++q) {
-                const CsrZ &A = planes[slot_plane[L.groups[g].plane0 + q]];
-                for (int64_t i = 0; i < n; ++i)
-                    for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) {
-                        const int e = fill[(size_t)of_row[(size_t)i]]++;
-                        col[(size_t)e] = A.col[p]; slot[(size_t)e] = L.groups[g].plane0 + q; val[(size_t)e] = cplx{A.val[p].real(), A.val[p].imag()};
-                    }
+            if (count[(size_t)i]) {
+                S.of_row[(size_t)i] = (int)S.ptr.size() - 1;
+                is_long[(size_t)i] = transposed && count[(size_t)i] > limit;
+                S.ptr.push_back(S.ptr.back() + (is_long[(size_t)i] ? 0 : count[(size_t)i]));
             }
-        T.side_of_row.upload(of_row.data(), of_row.size(), st);
-        T.side_ptr.upload(ptr.data(), ptr.size(), st);
-        if (nside) {
-            T.side_col.upload(col.data(), col.size(), st);
-            T.side_slot.upload(slot.data(), slot.size(), st);
-            T.side_val.upload(val.data(), val.size(), st);
-            T.side_acc.alloc((size_t)nside * 256);           // batch widths up to 256 columns
+        S.nside = (int)S.ptr.size() - 1;
+        S.col.resize((size_t)S.ptr.back()); S.slot.resize((size_t)S.ptr.back()); S.val.resize((size_t)S.ptr.back());
+        std::vector<int> fill(S.ptr.begin(), S.ptr.end() - 1);
+        for (int64_t i = 0; i < n; ++i) {                      // (long rows: one list per row, entries in (plane, column) order)
+            if (!is_long[(size_t)i]) continue;
+            for (size_t k = 0; k < src.size(); ++k)
+                for (int p = src[k]->ptr[i]; p < src[k]->ptr[i + 1]; ++p) {
+                    S.ls_col.push_back(src[k]->col[p]); S.ls_slot.push_back(src_slot[k]);
+                    S.ls_val.push_back(cplx{src[k]->val[p].real(), src[k]->val[p].imag()});
+                }
+            S.ls_ptr.push_back((int)S.ls_col.size());
+            S.ls_side.push_back(S.of_row[(size_t)i]);
+        }
+        for (size_t k = 0; k < src.size(); ++k) {
+            const CsrZ &A = *src[k];
+            for (int64_t i = 0; i < n; ++i) {
+                if (is_long[(size_t)i]) continue;
+                for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) {
+                    const int e = fill[(size_t)S.of_row[(size_t)i]]++;
+                    S.col[(size_t)e] = A.col[p]; S.slot[(size_t)e] = src_slot[k]; S.val[(size_t)e] = cplx{A.val[p].real(), A.val[p].imag()};
+                }
+            }
+        }
+        return S;
+    };
+    {
+        const SideHost S = build_side(false);
+        T.side_of_row.upload(S.of_row.data(), S.of_row.size(), st);
+        T.side_ptr.upload(S.ptr.data(), S.ptr.size(), st);
+        if (S.nside) {
+            T.side_col.upload(S.col.data(), S.col.size(), st);
+            T.side_slot.upload(S.slot.data(), S.slot.size(), st);
+            T.side_val.upload(S.val.data(), S.val.size(), st);
+            T.side_acc.alloc((size_t)S.nside * 256);         // batch widths up to 256 columns
         }
         HIP_CHECK(hipStreamSynchronize(st));
-        T.dev.nside = nside;
+        T.dev.nside = S.nside;
         T.dev.side_of_row = T.side_of_row.p;
         T.dev.side_ptr = T.side_ptr.p; T.dev.side_col = T.side_col.p; T.dev.side_slot = T.side_slot.p;
         T.dev.side_val = T.side_val.p; T.dev.side_acc = T.side_acc.p;
+        T.dev.nlong_side = 0;
         if (getenv("WAE_SETUP_DEBUG"))
-            fprintf(stderr, "[tiles] %d side rows with %d entries of the other %zu groups\n", nside, ptr.back(), ng - 1);
+            fprintf(stderr, "[tiles] %d side rows with %d entries of the other %zu groups\n", S.nside, S.ptr.back(), ng - 1);
+    }
+    // The transposed orientation (op = T / C on a family with a non-symmetric term -- the flame term of the adjoint solves): the bulk
+    // group must be symmetric (the tile storage itself is shared), the side rows are those of the other groups' transposes.
+    static const bool tile_t_on = !(getenv("WAE_TILE_TRANSPOSED") && atoi(getenv("WAE_TILE_TRANSPOSED")) == 0);
+    if (!T.all_symmetric && L.groups[0].symmetric && tile_t_on) {
+        const SideHost S = build_side(true);
+        T.t_side_of_row.upload(S.of_row.data(), S.of_row.size(), st);
+        T.t_side_ptr.upload(S.ptr.data(), S.ptr.size(), st);
+        if (S.nside) {
+            T.t_side_col.upload(S.col.data(), S.col.size(), st);
+            T.t_side_slot.upload(S.slot.data(), S.slot.size(), st);
+            T.t_side_val.upload(S.val.data(), S.val.size(), st);
+            T.t_side_acc.alloc((size_t)S.nside * 256);
+        }
+        const int nls = (int)S.ls_side.size();
+        if (nls) {
+            T.t_ls_ptr.upload(S.ls_ptr.data(), S.ls_ptr.size(), st);
+            T.t_ls_col.upload(S.ls_col.data(), S.ls_col.size(), st);
+            T.t_ls_slot.upload(S.ls_slot.data(), S.ls_slot.size(), st);
+            T.t_ls_val.upload(S.ls_val.data(), S.ls_val.size(), st);
+            T.t_ls_side.upload(S.ls_side.data(), S.ls_side.size(), st);
+        }
+        HIP_CHECK(hipStreamSynchronize(st));
+        T.dev_t = T.dev;
+        T.dev_t.nside = S.nside;
+        T.dev_t.side_of_row = T.t_side_of_row.p;
+        T.dev_t.side_ptr = T.t_side_ptr.p; T.dev_t.side_col = T.t_side_col.p; T.dev_t.side_slot = T.t_side_slot.p;
+        T.dev_t.side_val = T.t_side_val.p; T.dev_t.side_acc = T.t_side_acc.p;
+        T.dev_t.nlong_side = nls;
+        T.dev_t.ls_ptr = T.t_ls_ptr.p; T.dev_t.ls_col = T.t_ls_col.p; T.dev_t.ls_slot = T.t_ls_slot.p; T.dev_t.ls_val = T.t_ls_val.p;
+        T.dev_t.ls_side = T.t_ls_side.p;
+        T.ready_t = true;
+        if (getenv("WAE_SETUP_DEBUG"))
+            fprintf(stderr, "[tiles] transposed orientation: %d side rows with %d entries, %d long rows with %d entries\n", S.nside, S.ptr.back(), nls,
+                    S.ls_ptr.back());
     }
     T.ready = true;
 }

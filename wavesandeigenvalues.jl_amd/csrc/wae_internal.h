@@ -96,6 +96,11 @@ struct TileDev {
     const int *side_ptr, *side_col, *side_slot;      // CSR over the side rows; slot = plane index in the coefficient table
     const cplx *side_val;
     cplx *side_acc;                 // [nside][nb]
+    // side rows with more than WAE_LONG_ROW entries (the transposed orientation of a flame term: the reference nodes' rows hold one
+    // entry per flame node) are summed by a workgroup each (spmv_side_long_kernel) into their side_acc row; their CSR rows are empty
+    int nlong_side;
+    const int *ls_ptr, *ls_col, *ls_slot, *ls_side;   // per long side row: entry offsets; per entry: column, plane slot; side-row index
+    const cplx *ls_val;
 };
 struct OpDev {
     int ngroups;
@@ -170,6 +175,12 @@ struct TileStore {                  // device arrays behind a TileDev
     TileDev dev;
     bool ready = false;
     bool all_symmetric = false;     // every group symmetric: the N-orientation tiles serve op = T/C as well
+    // transposed orientation (round 3): the bulk group is symmetric, so the tile storage itself serves op = T/C; only the side rows
+    // (rows of the other groups' TRANSPOSES) are their own
+    DevBuf<int> t_side_of_row, t_side_ptr, t_side_col, t_side_slot, t_ls_ptr, t_ls_col, t_ls_slot, t_ls_side;
+    DevBuf<cplx> t_side_val, t_side_acc, t_ls_val;
+    TileDev dev_t;
+    bool ready_t = false;
 };
 
 struct LongRows {                   // device arrays of the long rows of one orientation (see OpDev)
