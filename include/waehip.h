@@ -224,8 +224,10 @@ int wae_arnoldi_shiftinvert(wae_family *h, const double *coeffsA, const double *
  * is latency-bound.  coeffsA, coeffsM: nsys x T; v0: d x nsys column-major; H_out: nsys blocks of (m+1) x m;
  * V_out: nsys blocks of d x (m+1), column-major.  A column whose Krylov space becomes invariant stops (its later H
  * entries and basis vectors are zero).  ritz_tol > 0: stop as soon as the dominant Ritz pair of every process has a
- * relative residual |h_{k+1,k}| |y_k| / |theta| <= ritz_tol (the H columns and basis vectors of the steps not taken
- * are zero); 0: always m steps. */
+ * relative residual |h_{k+1,k}| |y_k| / |theta| <= ritz_tol (the H columns of the steps not taken are zero, their basis
+ * vectors in V_out are NOT written -- 128 MB of host memory each at 1M DoF and 8 systems; pass zeroed or scratch storage);
+ * the inner solves of the later steps are then relaxed as the Ritz residual falls (inexact Arnoldi: step k is solved to
+ * tol / (10 x relative Ritz residual after step k-1), at most 1e-3).  0: always m steps, every solve to tol. */
 int wae_arnoldi_shiftinvert_batch(wae_family *h, int32_t nsys, const double *coeffsA, const double *coeffsM, int32_t m, const double *v0,
                                   int32_t op, double tol, int32_t maxit, double ritz_tol, double *H_out, double *V_out,
                                   wae_solve_info *info);

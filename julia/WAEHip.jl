@@ -118,8 +118,14 @@ function Base.:*(A::Operator, X::StridedVecOrMat{ComplexF64})
     return Y
 end
 
-function ensure_solver!(fam::DeviceFamily; zref=nothing, opts=Float64[])
+# probe_columns / snapshots: workspace hints (opts[8], opts[9] of wae_solver_setup) for the contour integrals that will follow --
+# the snapshot store is then mapped during the set-up instead of during the first `compute_moment_matrices`.
+function ensure_solver!(fam::DeviceFamily; zref=nothing, opts=Float64[], probe_columns::Int=0, snapshots::Int=0)
     fam.solver_ready && return
+    if probe_columns > 0 || snapshots > 0
+        opts = vcat(Float64.(opts), fill(0.0, max(0, 8 - length(opts))))[1:8]      # 0: keep the library's default
+        opts = vcat(opts, Float64[probe_columns, snapshots])
+    end
     L = fam.L
     z = zref === nothing ? L.params[L.eigval] : zref
     isfinite(z) || (z = 0.0im)

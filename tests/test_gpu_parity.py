@@ -1059,3 +1059,23 @@ def test_coarse_level_and_restriction_tiles_agree_with_the_untiled_hierarchy(mon
         for other in ("0", "3buf"):
             assert relerr(sols[("1", r)], sols[(other, r)]) < 1e-9
             assert abs(iters[("1", r)] - iters[(other, r)]) <= 2
+
+
+def test_pair_steps_of_the_narrow_recurrence():
+    """tests/narrow_worker.py with the pair steps of the narrow batches forced on (WAE_NARROW_PAIR=1) and off (=0) on the 8 736-DoF
+    annulus: solves against a sparse LU (op N and C, 1 / 8 columns, from zero and next to an eigenvalue with a guess direction)
+    and one Newton-type refinement; both settings must pass and agree on the eigenvalue."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for pair in ("1", "0"):
+        env = dict(os.environ, WAE_NARROW_PAIR=pair)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "narrow_worker.py")], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        out[pair] = json.loads(r.stdout.strip().split("\n")[-1])
+        assert out[pair]["checks"] >= 20 and out[pair]["max_steps"] >= 20
+    w1, w0 = complex(*out["1"]["eig"]), complex(*out["0"]["eig"])
+    assert abs(w1 - w0) <= 1e-8 * abs(w0), (w1, w0)

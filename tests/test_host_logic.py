@@ -1,6 +1,7 @@
 """CPU tests of the host-side mirror (no GPU): coefficient evaluation, functor semantics, partitions,
 Beyn host tail -- compared with the oracle restatement on the same inputs."""
 import numpy as np
+import pytest
 import scipy.sparse as sp
 
 from oracle import fixtures as F
@@ -104,3 +105,69 @@ def test_pade_estimate_pol_and_vector_pade_match_oracle():
     A, B = ON.pade_vector(so, "τ", 1, 1)
     Ap, Bp = sol.v_pert["τ/[1/1]"]
     assert np.allclose(A, Ap) and np.allclose(B, Bp)
+
+
+def test_gram_svd_of_a_rank_deficient_tall_matrix_matches_lapack():
+    """`_svd_by_gram` (the factorisation of the Hankel matrix B0 of beyn.jl:289-323 on the device path): a tall matrix with a
+    group of 7 singular values of order one and 9 more ten orders below (what the moments of a contour holding 7 eigenvalues look
+    like).  Both groups to 1e-6 relative (the lower one is only ever used as the rank gap), the kept triplets reproduce the matrix
+    to the noise level, the basis is orthonormal to rounding -- and the tall-skinny product helper against a plain product."""
+    import torch
+    from wae_amd.nlevp.distributed import _svd_by_gram, _tall_gram, moments2eigs_device
+    rng = np.random.default_rng(17)
+    d, n, k = 5000, 16, 7
+    Q1, _ = np.linalg.qr(rng.standard_normal((d, n)) + 1j * rng.standard_normal((d, n)))
+    Q2, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    s = np.concatenate([np.linspace(3.0, 0.2, k), 1e-10 * np.linspace(2.0, 0.1, n - k)])
+    B0 = (Q1 * s) @ Q2.conj().T
+    t = torch.from_numpy(B0)
+    assert np.allclose(_tall_gram(t, t).numpy(), B0.conj().T @ B0, atol=1e-13)
+    assert np.allclose(_tall_gram(t[:700], t[:700]).numpy(), B0[:700].conj().T @ B0[:700], atol=1e-13)      # ragged last block
+    U, S, Wh, Sall = _svd_by_gram(t, 1e-6)
+    assert U.shape == (d, k) and S.shape == (k,) and Wh.shape == (k, n)
+    assert np.allclose(S.numpy(), s[:k], rtol=1e-12)
+    assert np.allclose(Sall.numpy()[:k], s[:k], rtol=1e-12) and np.allclose(Sall.numpy()[k:], s[k:], rtol=1e-6)
+    Un = U.numpy()
+    assert np.linalg.norm(Un.conj().T @ Un - np.eye(k)) < 1e-13
+    assert np.linalg.norm((Un * S.numpy()) @ Wh.numpy() - B0) < 1e-9
+    _, s_l, _ = np.linalg.svd(B0, full_matrices=False)
+    assert np.allclose(Sall.numpy()[:k], s_l[:k], rtol=1e-12)
+    # a threshold below what one Gram matrix resolves (1e-8 of the largest): the second group is taken by a second stage
+    U2, S2, Wh2, Sall2 = _svd_by_gram(t, 1e-12)
+    assert U2.shape == (d, n) and np.allclose(S2.numpy(), s, rtol=1e-6) and len(Sall2) == n
+    assert np.linalg.norm(U2.numpy().conj().T @ U2.numpy() - np.eye(n)) < 1e-12
+    assert np.linalg.norm((U2.numpy() * S2.numpy()) @ Wh2.numpy() - B0) < 1e-14
+    with pytest.raises(ValueError):
+        _svd_by_gram(torch.zeros((50, 4), dtype=torch.complex128), 1e-6)
+    # the whole host tail through both factorisations: K = 2 moments of a diagonal problem, eigenvalues agree
+    lam = np.array([0.3 + 0.1j, -0.2 + 0.4j, 0.1 - 0.5j])
+    dd, l = 600, 4
+    V = rng.standard_normal((dd, 3)) + 1j * rng.standard_normal((dd, 3))
+    W = rng.standard_normal((3, l)) + 1j * rng.standard_normal((3, l))
+    A = np.stack([(V * lam ** p) @ W for p in range(4)], axis=2)                         # (d, l, 2K), A_p = V Λ^p W
+    buf = torch.from_numpy(np.ascontiguousarray(A.transpose(2, 1, 0)).view(np.float64).reshape(-1).copy())
+    Om_q, _, S_q = moments2eigs_device(buf, (dd, l, 4), tol_sigma=1e-8)
+    Om_g, P_g, S_g = moments2eigs_device(buf, (dd, l, 4), gram_rel_tol=1e-8)
+    assert len(Om_g) == 3 and np.allclose(np.sort_complex(Om_g), np.sort_complex(lam), atol=1e-10)
+    assert np.allclose(np.sort_complex(Om_q), np.sort_complex(lam), atol=1e-10)
+    assert np.allclose(S_g[:3], S_q[:3], rtol=1e-10) and P_g.shape == (dd, 3)
+
+
+def test_conjugate_span_start_of_the_left_processes():
+    """`householder_many` without adjoint start vectors: conj(v) for an isolated mode (what `householder` starts from,
+    Householder.jl:84-86), the bi-orthogonal combination for a spinning pair, whose members have v^T v = 0."""
+    from wae_amd.nlevp.local_solvers import _conjugate_span_start
+    n = 400
+    phi = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    spin_p, spin_m = np.exp(3j * phi), np.exp(-3j * phi)                # a degenerate pair: each is the other's conjugate
+    lone = np.cos(5 * phi) * (1 + 0.2j)
+    V = np.stack([spin_p, lone, spin_m], axis=1)
+    W = _conjugate_span_start(V)
+    B = W.conj().T @ V                                                   # W^H V: diagonal = bi-orthogonal
+    assert np.allclose(B - np.diag(np.diag(B)), 0, atol=1e-10) and np.all(np.abs(np.diag(B)) > 0.5)
+    # the plain conjugates are orthogonal to the spinning modes they are supposed to pair with
+    assert abs(np.vdot(np.conj(spin_p), spin_p)) < 1e-9 * n
+    assert np.allclose(_conjugate_span_start(V[:, 1:2]), np.conj(V[:, 1:2]))       # one vector: the reference's start
+    # numerically dependent start vectors: falls back to the plain conjugates
+    Vd = np.stack([spin_p, spin_p * (1 + 1e-13)], axis=1)
+    assert np.allclose(_conjugate_span_start(Vd), np.conj(Vd))

@@ -323,6 +323,46 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
             if (agg[gcol[p]] < 0) agg[gcol[p]] = na;
         ++na;
     }
+    // (experiment, WAE_AMG_MERGE=1: the aggregates are merged in strongly connected pairs -- about twice as large, half as many
+    // coarse unknowns; greedy matching in aggregate order, deterministic)
+    static const int merge_env = getenv("WAE_AMG_MERGE") ? atoi(getenv("WAE_AMG_MERGE")) : 0;
+    if (merge_env && visit != nullptr && na > 1) {                 // (fine level only: `visit` is passed for it)
+        std::vector<int> mate(na, -1);
+        std::vector<std::vector<int>> nbrs(na);
+        for (int64_t i = 0; i < n; ++i) {
+            const int a = agg[i];
+            if (a < 0) continue;
+            for (int p = gptr[i]; p < gptr[i + 1]; ++p) {
+                const int b = agg[gcol[p]];
+                if (b >= 0 && b != a) nbrs[a].push_back(b);
+            }
+        }
+        for (int a = 0; a < na; ++a) {
+            if (mate[a] >= 0) continue;
+            // the free neighbour with the most strong couplings
+            std::sort(nbrs[a].begin(), nbrs[a].end());
+            int best = -1, bestc = 0;
+            for (size_t k = 0; k < nbrs[a].size();) {
+                size_t e = k;
+                while (e < nbrs[a].size() && nbrs[a][e] == nbrs[a][k]) ++e;
+                const int b = nbrs[a][k], c = (int)(e - k);
+                if (mate[b] < 0 && b != a && c > bestc) { best = b; bestc = c; }
+                k = e;
+            }
+            if (best >= 0) { mate[a] = best; mate[best] = a; }
+            else mate[a] = a;
+        }
+        std::vector<int> relabel(na, -1);
+        int nn = 0;
+        for (int a = 0; a < na; ++a) {
+            if (relabel[a] >= 0) continue;
+            relabel[a] = nn;
+            if (mate[a] != a && mate[a] >= 0) relabel[mate[a]] = nn;
+            ++nn;
+        }
+        for (int64_t i = 0; i < n; ++i) if (agg[i] >= 0) agg[i] = relabel[agg[i]];
+        na = nn;
+    }
     // tentative prolongator (piecewise constant)
     CsrD Pt;
     Pt.n = n; Pt.m = na;

@@ -465,12 +465,17 @@ def eigs_many(fam, cA, cM, v0s, op, sigmas, nev=1, tol=1e-12, maxiter=300, stol=
     step = int(min(d, max(6, 2 * nev + 2)))
     cAs = cA - np.asarray(sigmas, dtype=np.complex128)[:, None] * cM[None, :]
     sig_out = np.conj(sigmas) if op == OP_C else np.asarray(sigmas)
-    V0 = np.asfortranarray(np.asarray(v0s, dtype=np.complex128).reshape(d, nsys)).copy()
+    if isinstance(v0s, (list, tuple)):                    # columns given one by one (views): one copy into column-major storage
+        V0 = np.empty((d, nsys), dtype=np.complex128, order="F")
+        for q, col in enumerate(v0s):
+            V0[:, q] = col
+    else:
+        V0 = np.array(np.asarray(v0s, dtype=np.complex128).reshape(d, nsys), order="F")
     out = [None] * nsys
     pending = list(range(nsys))
     total = 0
     while pending and total < maxiter:
-        H, V = fam.arnoldi_batch(cAs[pending], cM, step, V0[:, pending], op=op, tol=stol, maxit=smax,
+        H, V = fam.arnoldi_batch(cAs[pending], cM, step, V0 if len(pending) == nsys else V0[:, pending], op=op, tol=stol, maxit=smax,
                                  ritz_tol=tol if nev == 1 else 0.0, quiet=True)
         total += step
         if stats is not None:
@@ -506,6 +511,27 @@ def eigs_many(fam, cA, cM, v0s, op, sigmas, nev=1, tol=1e-12, maxiter=300, stol=
     return out
 
 
+def _conjugate_span_start(V):
+    """Start vectors of the left (adjoint) Arnoldi processes when the caller gives none.  `householder` starts from conj(v0)
+    (Householder.jl:84-86), the left eigenvector of a complex-symmetric L(z) -- as long as v0^T v0 != 0.  For a (nearly) degenerate
+    pair that fails: a spinning mode e^{im phi} of an annulus has v^T v = 0 and conj(v) is the OTHER mode of the pair, so the left
+    process starts orthogonal to what it looks for (four Arnoldi steps instead of two at 1M DoF).  With several start vectors at
+    hand the left vectors are taken from their conjugate span instead, bi-orthogonal to them in the bilinear form:
+    W = conj(V G^-1), G = V^T V -- conj(v0) up to scale for an isolated mode, the partner's conjugate for a spinning pair.  Only a
+    start: the converged left eigenvectors do not depend on it.  Falls back to conj(V) when G is numerically singular (dependent
+    start vectors, or a spinning mode without its partner)."""
+    ns = V.shape[1]
+    if ns < 2:
+        return np.conj(V)
+    nrm = np.linalg.norm(V, axis=0)
+    nrm[nrm == 0] = 1.0
+    Vn = V / nrm
+    G = Vn.T @ Vn
+    if not np.all(np.isfinite(G)) or np.linalg.svd(G, compute_uv=False)[-1] < 1e-6:      # (unit columns: |G_ij| <= 1, the bound is absolute)
+        return np.conj(V)
+    return np.conj(Vn @ np.linalg.inv(G))
+
+
 def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, v0s=None, v0s_adj=None, output=False, stats=None):
     """[(sol, n, flag), ...] = householder_many(L, zs; ...): `householder` for several start values, the device work
     (two shift-invert Arnoldi processes per Newton step and start value) batched over the start values.
@@ -519,8 +545,9 @@ def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, orde
     d = L.size()
     fam = L.ensure_solver()
     active, mode = L.active, L.mode
-    V = np.ones((d, ns), dtype=np.complex128) if v0s is None else np.array(v0s, dtype=np.complex128).reshape(d, ns)
-    W = np.conj(V) if v0s_adj is None else np.array(v0s_adj, dtype=np.complex128).reshape(d, ns)
+    # (column-major: every start value's vectors are contiguous -- the updates below touch 16 MB columns at 1M DoF)
+    V = np.ones((d, ns), dtype=np.complex128, order="F") if v0s is None else np.array(np.asarray(v0s, dtype=np.complex128).reshape(d, ns), order="F")
+    W = np.array(_conjugate_span_start(V) if v0s_adj is None else np.asarray(v0s_adj, dtype=np.complex128).reshape(d, ns), order="F")
     z = list(zs)
     z0 = [complex(np.inf)] * ns
     lam = [np.inf] * ns
@@ -549,10 +576,10 @@ def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, orde
         try:
             st_["newton_rounds"] += 1
             t_ = _time.perf_counter()
-            right = eigs_many(fam, cA, cM, V[:, act], OP_N, sig, stol=L.solver_tol, smax=L.solver_maxit, stats=st_)
+            right = eigs_many(fam, cA, cM, [V[:, s] for s in act], OP_N, sig, stol=L.solver_tol, smax=L.solver_maxit, stats=st_)
             st_["right_arnoldi_seconds"] += _time.perf_counter() - t_
             t_ = _time.perf_counter()
-            left = eigs_many(fam, cA, cM, W[:, act], OP_C, sig, stol=L.solver_tol, smax=L.solver_maxit, stats=st_)
+            left = eigs_many(fam, cA, cM, [W[:, s] for s in act], OP_C, sig, stol=L.solver_tol, smax=L.solver_maxit, stats=st_)
             st_["left_arnoldi_seconds"] += _time.perf_counter() - t_
         except WaeError as e:
             for s in act:
@@ -584,9 +611,38 @@ def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, orde
             if output:
                 print(s, n[s], "\t", abs(lam[s]), "\t", abs(dz), "\t", z[s])
             z[s] = z[s] + relax * dz
-            V[:, s] = (1 - relax) * V[:, s] + relax * v_r[:, 0]
-            W[:, s] = (1 - relax) * W[:, s] + relax * v_l[:, 0]
+            if relax == 1.0:
+                V[:, s] = v_r[:, 0]
+                W[:, s] = v_l[:, 0]
+            else:
+                V[:, s] = (1 - relax) * V[:, s] + relax * v_r[:, 0]
+                W[:, s] = (1 - relax) * W[:, s] + relax * v_l[:, 0]
             n[s] += 1
+    # Householder.jl:189-190 for all start values at once: v / sqrt(v' M v), v_adj / conj(v_adj' L'(z) v) -- two batched operator
+    # products (the same term coefficients `_normalise` forms one start value at a time)
+    t_ = _time.perf_counter()
+    cMn = np.zeros(T, dtype=np.complex128)
+    cMn[T - 1] = -1.0
+    MV = fam.spmv(cMn, V)
+    for s in range(ns):
+        V[:, s] *= 1.0 / np.sqrt(np.vdot(V[:, s], MV[:, s]))          # (a complex in-place division is ten times slower)
+    del MV
+    cD = np.zeros((ns, T), dtype=np.complex128)
+    saved_p = dict(L.params)
+    L.active, L.mode = [L.eigval], "all"
+    try:
+        for s in range(ns):
+            L.params[L.eigval] = z[s]
+            L.params[L.auxval] = lam[s] if np.isfinite(lam[s]) else 0
+            cD[s] = L.coefficients(z[s], 1)
+    finally:
+        L.active, L.mode = active, mode
+        L.params.update(saved_p)
+    DV = fam.spmv(cD, V)
+    for s in range(ns):
+        W[:, s] *= 1.0 / np.conj(np.vdot(W[:, s], DV[:, s]))
+    del DV
+    st_["normalisation_seconds"] = _time.perf_counter() - t_
     out = []
     for s in range(ns):
         f = flag[s]
@@ -605,8 +661,7 @@ def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, orde
             else:
                 f = -3
         L.active, L.mode = active, mode
-        v0, v0a = _normalise(L, V[:, s].copy(), W[:, s].copy())
-        sol = Solution(L.params, v0, v0a, L.eigval)
+        sol = Solution(L.params, V[:, s].copy(), W[:, s].copy(), L.eigval)
         sol.history = hist[s]
         out.append((sol, n[s], f))
     L.active, L.mode = active, mode
