@@ -2,6 +2,8 @@
 include/waehip.h declares (no compute without a GPU), and the product path fails loudly without a device."""
 import os
 import re
+import shutil
+import subprocess
 
 import numpy as np
 import pytest
@@ -164,3 +166,18 @@ def test_julia_ccall_signatures_match_the_header():
     code = "\n".join(ln.split("#")[0] for ln in code.split("\n"))
     for a, b in ("()", "[]", "{}"):
         assert code.count(a) == code.count(b), (a, code.count(a), code.count(b))
+
+
+def test_fused_galerkin_product_is_bit_identical(tmp_path):
+    """tests/abi/amg_check.cpp (host only): `galerkin_pair` -- the triple products R K P and R M P of the multigrid set-up formed in one
+    traversal of the shared pattern -- against two separate `galerkin` calls, bit for bit, for several thread counts."""
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    exe = str(tmp_path / "amg_check")
+    csrc = os.path.join(ROOT, "wavesandeigenvalues.jl_amd", "csrc")
+    cmd = ["hipcc", "-O1", "-std=c++17", "-I", csrc, "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "abi", "amg_check.cpp"),
+           os.path.join(csrc, "amg.cpp"), "-o", exe, "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "amg_check ok 18" in r.stdout, r.stdout + r.stderr

@@ -181,6 +181,87 @@ static void galerkin_rowwise(const CsrD &R, int64_t an, const std::vector<int> &
     }
     stitch(n, nparts, cptr, pcol, pval, ccol, cval);
 }
+// The same for NV matrices that share one pattern (K and M of a Helmholtz family: the two large planes): the index traversal -- what
+// the product costs -- is done once, every entry carries NV values.  Same operations on every value as galerkin_rowwise.
+template <int NV>
+static void galerkin_rowwise_multi(const CsrD &R, const std::vector<int> &aptr, const std::vector<int> &acol, const std::vector<zc> *const aval[NV],
+                                   const CsrD &P, std::vector<int> &cptr, std::vector<int> &ccol, std::vector<zc> *const cval[NV], int nthreads) {
+    struct Vals { zc v[NV]; };
+    const int64_t n = R.n, m = P.m;
+    cptr.assign(n + 1, 0);
+    const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(nthreads, n / 1024 + 1));
+    std::vector<std::vector<int>> pcol(nparts);
+    std::vector<std::vector<Vals>> pval(nparts);
+    auto body = [&](int64_t lo, int64_t hi, int part) {
+        std::vector<int> markC(m, -1), markT(m, -1), listC, listT;
+        std::vector<Vals> accC(m), accT(m);
+        int stamp = 0;
+        std::vector<int> &oc = pcol[part];
+        std::vector<Vals> &ov = pval[part];
+        for (int64_t I = lo; I < hi; ++I) {
+            listC.clear();
+            for (int p = R.ptr[I]; p < R.ptr[I + 1]; ++p) {
+                const int i = R.col[p];
+                const double r = R.val[p];
+                listT.clear();
+                ++stamp;
+                for (int q = aptr[i]; q < aptr[i + 1]; ++q) {
+                    const int k = acol[q];
+                    zc a[NV];
+                    for (int u = 0; u < NV; ++u) a[u] = (*aval[u])[q];
+                    for (int t = P.ptr[k]; t < P.ptr[k + 1]; ++t) {
+                        const int J = P.col[t];
+                        if (markT[J] != stamp) { markT[J] = stamp; for (int u = 0; u < NV; ++u) accT[J].v[u] = zc(0); listT.push_back(J); }
+                        for (int u = 0; u < NV; ++u) accT[J].v[u] += a[u] * zc(P.val[t]);
+                    }
+                }
+                for (int J : listT) {
+                    if (markC[J] != (int)I) { markC[J] = (int)I; for (int u = 0; u < NV; ++u) accC[J].v[u] = zc(0); listC.push_back(J); }
+                    for (int u = 0; u < NV; ++u) accC[J].v[u] += zc(r) * accT[J].v[u];
+                }
+            }
+            std::sort(listC.begin(), listC.end());
+            for (int J : listC) { oc.push_back(J); ov.push_back(accC[J]); }
+            cptr[I + 1] = (int)listC.size();
+        }
+    };
+    if (nparts == 1) body(0, n, 0);
+    else {
+        std::vector<std::future<void>> jobs;
+        for (int t = 0; t < nparts; ++t) {
+            const int64_t lo = n * t / nparts, hi = n * (t + 1) / nparts;
+            jobs.push_back(std::async(std::launch::async, [&body, lo, hi, t]() { body(lo, hi, t); }));
+        }
+        for (auto &j : jobs) j.get();
+    }
+    // row pointers, then the columns once and the NV value arrays
+    for (int64_t i = 0; i < n; ++i) cptr[i + 1] += cptr[i];
+    const size_t total = (size_t)cptr[n];
+    ccol.resize(total);
+    for (int u = 0; u < NV; ++u) cval[u]->resize(total);
+    {
+        std::vector<std::future<void>> jobs;
+        size_t off = 0;
+        for (int t = 0; t < nparts; ++t) {
+            const size_t cnt = pcol[t].size();
+            jobs.push_back(std::async(std::launch::async, [&, t, off, cnt]() {
+                std::copy(pcol[t].begin(), pcol[t].end(), ccol.begin() + off);
+                for (size_t e = 0; e < cnt; ++e)
+                    for (int u = 0; u < NV; ++u) (*cval[u])[off + e] = pval[t][e].v[u];
+            }));
+            off += cnt;
+        }
+        for (auto &j : jobs) j.get();
+    }
+}
+// two planes of one pattern at once (bit-identical to two galerkin() calls)
+void galerkin_pair(const CsrD &R, const CsrZ &A0, const CsrZ &A1, const CsrD &P, CsrZ &C0, CsrZ &C1, int nthreads) {
+    C0.n = C1.n = R.n; C0.m = C1.m = P.m;
+    const std::vector<zc> *const av[2] = {&A0.val, &A1.val};
+    std::vector<zc> *const cv[2] = {&C0.val, &C1.val};
+    galerkin_rowwise_multi<2>(R, A0.ptr, A0.col, av, P, C0.ptr, C0.col, cv, nthreads);
+    C1.ptr = C0.ptr; C1.col = C0.col;
+}
 // (worth it for short rows: fine level, 15 entries per row: 0.99 -> 0.45 s for the five products at 1M unknowns, 16 threads; the
 // first coarse level with 48 per row: 0.07 -> 0.16 s)
 static bool rowwise_on(int64_t rows, size_t nnz) {
@@ -557,9 +638,16 @@ void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, c
         {
             std::vector<std::future<void>> jobs;
             const int inner = std::max(1, setup_threads() / (int)(cur.size() + 1));     // threads per triple product
-            for (size_t q = 0; q < cur.size(); ++q)
-                jobs.push_back(std::async(std::launch::async, [&, q]() { next[q] = galerkin(R, cur[q], P, inner); }));
-            CsrD Snext = galerkin_real(R, S, P, inner);
+            // planes 0 and 1 with one pattern (K and M) and short rows: one traversal for both, with the threads of two products
+            static const bool pair_on = !(getenv("WAE_GALERKIN_PAIR") && atoi(getenv("WAE_GALERKIN_PAIR")) == 0);
+            const bool pair = pair_on && cur.size() >= 2 && rowwise_on(cur[0].n, cur[0].col.size()) && cur[0].ptr == cur[1].ptr && cur[0].col == cur[1].col;
+            // (threads: the pair and the shape matrix are the two long jobs -- half of the threads each; the other planes -- boundary
+            // and flame terms, a hundredth of the entries -- one thread each)
+            const int big = pair ? std::max(1, (setup_threads() - (int)cur.size() + 2) / 2) : inner;
+            if (pair) jobs.push_back(std::async(std::launch::async, [&]() { galerkin_pair(R, cur[0], cur[1], P, next[0], next[1], big); }));
+            for (size_t q = pair ? 2 : 0; q < cur.size(); ++q)
+                jobs.push_back(std::async(std::launch::async, [&, q]() { next[q] = galerkin(R, cur[q], P, pair ? 1 : inner); }));
+            CsrD Snext = galerkin_real(R, S, P, big);
             for (auto &j : jobs) j.get();
             S = std::move(Snext);
         }
