@@ -748,14 +748,13 @@ static void penalty_polish(wae_family *h, const Batch &bt, const cplx *B, cplx *
 // the per-column figures once per restart cycle.  Columns that converge between two looks are masked on the device at once
 // (their 8-column chunks are skipped by every kernel), so the overshoot costs launches, not traffic.
 static double now_s();
-static int gmres_wide(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double tol, int maxit, wae_solve_info *info, bool have_x0,
-                      int m_cap = 150) {
+static int gmres_wide(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double tol, int maxit, wae_solve_info *info, bool have_x0) {
     hipStream_t st = h->stream;
     const double t_dbg0 = now_s();
     const int nb = bt.nb;
     const int64_t n = h->d;
     const size_t vec = (size_t)n * nb;
-    const int m = (int)std::min<size_t>((size_t)m_cap, h->V.n / vec - 1);
+    const int m = (int)std::min<size_t>(150, h->V.n / vec - 1);
     const OpDev A = h->ops[0].dev(bt.op);
     const cplx *pc = pc_level(h, 0);
     cplx *hp = h->h_pinned;
@@ -995,14 +994,6 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
     const bool lazy = lazy_on && !reorth && nslots * nb <= 4096 && nslots * nb <= h->vsq.n;   // 4096: coefficients of one axpy launch
     static const bool dev_rec = !(getenv("WAE_GMRES_DEVICE") && atoi(getenv("WAE_GMRES_DEVICE")) == 0);
     if (dev_rec && lazy && !guess_dir && nb > 8 && nb <= 256) return gmres_wide(h, bt, B, X, tol, maxit, info, have_x0);
-    // (experiment) WAE_NARROW_WIDE=m: batches of 8 columns through the device recurrence too, restarted every m steps, no deflation
-    static const int narrow_wide = getenv("WAE_NARROW_WIDE") ? atoi(getenv("WAE_NARROW_WIDE")) : 0;
-    if (narrow_wide > 0 && dev_rec && nb >= 8 && nb <= 256) return gmres_wide(h, bt, B, X, tol, maxit, info, have_x0, narrow_wide);
-    // narrow batches: the Gram-Schmidt passes over a long recurrence outweigh the V-cycle several times, so a stronger (more
-    // expensive) preconditioner that shortens the recurrence pays there and not in the wide batches
-    static const int narrow_sweeps = getenv("WAE_NARROW_SWEEPS") ? atoi(getenv("WAE_NARROW_SWEEPS")) : 0;
-    struct SweepGuard { wae_family *h; int saved; ~SweepGuard() { h->nsweeps = saved; } } sweep_guard{h, h->nsweeps};
-    if (narrow_sweeps > 0 && nb <= 8) h->nsweeps = narrow_sweeps;
     std::vector<std::vector<double>> sv(lazy ? nslots : 0, std::vector<double>(nb, 1.0));
     const int pair_min = 4;
     const size_t PK = (size_t)(m + off + 3) * nb;             // one coefficient block of the pair steps
