@@ -884,7 +884,9 @@ static int gmres_wide(wae_family *h, const Batch &bt, const cplx *B, cplx *X, do
             }
             // look at the status words every ksync iterations -- every iteration once few columns are left (the end of the
             // cycle is near: an overshoot iteration is ~25 launches of fully masked kernels)
-            if (since_sync >= ksync || j == m || total_it >= maxit || status[0] <= nb / 4) {
+            // (from a projected guess most columns need one or two steps: the first four steps of such a cycle are looked at one by one --
+            // a look costs a 12-byte copy and a stream wait, a step run in vain 25 launches of partly masked kernels)
+            if (since_sync >= ((have_x0 && j <= 4) ? 1 : ksync) || j == m || total_it >= maxit || status[0] <= nb / 4) {
                 since_sync = 0;
                 HIP_CHECK(hipMemcpyAsync(status, S.status, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
                 HIP_CHECK(hipStreamSynchronize(st));
