@@ -150,7 +150,7 @@ def main():
                      # workspace hints: the snapshot store of the passes to come is mapped during the set-up
                      "probe_columns": args.l // world if (world > 1 and args.l % world == 0) else args.l, "snapshots": args.rb}
     from wae_amd.nlevp.distributed import warm_up_dense_linalg
-    warm_up_dense_linalg(torch.device("cuda", local), cols=args.l)     # (process-level library handles: not part of a solver call)
+    warm_up_dense_linalg(torch.device("cuda", local), cols=args.l, K=args.K)     # (process-level library handles: not part of a solver call)
     t0 = time.time()
     L.device()                                   # wae_family_create: conversion + upload of the term matrices
     torch.cuda.synchronize()

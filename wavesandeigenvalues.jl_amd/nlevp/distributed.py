@@ -289,16 +289,14 @@ def _tall_gram(A, B, rows=512):
     return out
 
 
-def warm_up_dense_linalg(device, rows=65536, cols=8):
-    """One tiny QR + SVD + batched product on `device`: creates the handles of the dense linear-algebra libraries torch calls for
-    the Hankel factorisation in moments2eigs_device (rocSOLVER / rocBLAS: ~0.3 s once per PROCESS).  Library initialisation, not
-    solver work: bench.py calls it before it starts the clock of the cold solver call."""
+def warm_up_dense_linalg(device, rows=65536, cols=8, K=1):
+    """One small run of the Hankel factorisation of `moments2eigs_device` on random moments of the caller's (l, K) shape: creates the
+    handles and loads the kernels of the dense linear-algebra libraries torch calls there (rocSOLVER / rocBLAS / the host LAPACK:
+    ~0.3 s once per PROCESS).  Library initialisation, not solver work: bench.py calls it before it starts the clock of the cold
+    solver call.  K = 1: the QR path; K > 1: the Gram path, as bench.py takes them."""
     import torch
-    A = torch.randn(rows, cols, dtype=torch.complex128, device=device)      # tall-skinny like the Hankel matrix: same kernels
-    Q, R = torch.linalg.qr(A)
-    U, S, Wh = torch.linalg.svd(R)
-    small = (_tall_gram(Q @ U, A) @ Wh.conj().T) / S.to(U.dtype)
-    (Q[:rows // 2] @ small).cpu()
+    buf = torch.randn(rows * cols * 2 * K * 2, dtype=torch.float64, device=device)
+    moments2eigs_device(buf, (rows, cols, 2 * K), gram_rel_tol=1e-6 if K > 1 else 0.0)
     torch.cuda.synchronize(device)
 
 
