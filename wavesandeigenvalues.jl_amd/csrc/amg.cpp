@@ -5,6 +5,7 @@
 #include <numeric>
 
 #include "amg.h"
+#include "hugemem.h"
 #include <chrono>
 #include <cstdlib>
 #include <functional>
@@ -66,6 +67,7 @@ template <class V> static void stitch(int64_t n, int nparts, std::vector<int> &p
                                       std::vector<int> &col, std::vector<V> &val) {
     (void)nparts;
     for (int64_t i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
+    huge_reserve(col, (size_t)ptr[n]); huge_reserve(val, (size_t)ptr[n]);
     col.resize((size_t)ptr[n]);
     val.resize((size_t)ptr[n]);
     // every part copies its own piece (the serial copy of 300 MB per product was a tenth of a second each at 1M unknowns)
@@ -144,6 +146,12 @@ static void galerkin_rowwise(const CsrD &R, int64_t an, const std::vector<int> &
         int stamp = 0;
         std::vector<int> &oc = pcol[part];
         std::vector<VC> &ov = pval[part];
+        {   // (estimate of this part's output: (R A P) has about as many entries as the rows of A that its R rows gather)
+            size_t est = 0;
+            for (int p = R.ptr[lo]; p < R.ptr[hi]; ++p) est += (size_t)(aptr[R.col[p] + 1] - aptr[R.col[p]]);
+            est = est / 6 + 1024;
+            huge_reserve(oc, est); huge_reserve(ov, est);
+        }
         for (int64_t I = lo; I < hi; ++I) {
             listC.clear();
             for (int p = R.ptr[I]; p < R.ptr[I + 1]; ++p) {
@@ -198,6 +206,12 @@ static void galerkin_rowwise_multi(const CsrD &R, const std::vector<int> &aptr, 
         int stamp = 0;
         std::vector<int> &oc = pcol[part];
         std::vector<Vals> &ov = pval[part];
+        {
+            size_t est = 0;
+            for (int p = R.ptr[lo]; p < R.ptr[hi]; ++p) est += (size_t)(aptr[R.col[p] + 1] - aptr[R.col[p]]);
+            est = est / 6 + 1024;
+            huge_reserve(oc, est); huge_reserve(ov, est);
+        }
         for (int64_t I = lo; I < hi; ++I) {
             listC.clear();
             for (int p = R.ptr[I]; p < R.ptr[I + 1]; ++p) {
@@ -237,8 +251,9 @@ static void galerkin_rowwise_multi(const CsrD &R, const std::vector<int> &aptr, 
     // row pointers, then the columns once and the NV value arrays
     for (int64_t i = 0; i < n; ++i) cptr[i + 1] += cptr[i];
     const size_t total = (size_t)cptr[n];
+    huge_reserve(ccol, total);
     ccol.resize(total);
-    for (int u = 0; u < NV; ++u) cval[u]->resize(total);
+    for (int u = 0; u < NV; ++u) { huge_reserve(*cval[u], total); cval[u]->resize(total); }
     {
         std::vector<std::future<void>> jobs;
         size_t off = 0;
@@ -311,22 +326,34 @@ CsrZ csr_lincomb(const std::vector<CsrZ> &planes, const std::vector<zc> &coef) {
     const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(setup_threads(), n / 4096 + 1));
     std::vector<std::vector<int>> pcol(nparts);
     std::vector<std::vector<zc>> pval(nparts);
+    (void)m;
     parallel_ranges(n, nparts, [&](int64_t lo, int64_t hi, int part) {
-        std::vector<int> marker(m, -1), list;
-        std::vector<zc> acc(m);
+        // a row's entries of all planes in one short list, ordered by column with the plane order kept among equal columns: the
+        // sums are formed in the order of the dense-accumulator version (acc = 0; acc += c_k a_k, k ascending) -- same bits -- without
+        // its two m-sized arrays per thread
+        std::vector<std::pair<int, zc>> row;
+        {   // (an upper bound of this part's output: no regrowth -- every doubling of a 100-MB vector is a copy and a set of fresh pages)
+            size_t bound = 0;
+            for (const CsrZ &A : planes) bound += (size_t)(A.ptr[hi] - A.ptr[lo]);
+            huge_reserve(pcol[part], bound); huge_reserve(pval[part], bound);
+        }
         for (int64_t i = lo; i < hi; ++i) {
-            list.clear();
+            row.clear();
             for (size_t k = 0; k < planes.size(); ++k) {
                 const CsrZ &A = planes[k];
-                for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) {
-                    const int c = A.col[p];
-                    if (marker[c] != (int)i) { marker[c] = (int)i; acc[c] = 0; list.push_back(c); }
-                    acc[c] += coef[k] * A.val[p];
-                }
+                for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) row.emplace_back(A.col[p], coef[k] * A.val[p]);
             }
-            std::sort(list.begin(), list.end());
-            for (int c : list) { pcol[part].push_back(c); pval[part].push_back(acc[c]); }
-            C.ptr[i + 1] = (int)list.size();
+            std::stable_sort(row.begin(), row.end(), [](const std::pair<int, zc> &x, const std::pair<int, zc> &y) { return x.first < y.first; });
+            int cnt = 0;
+            for (size_t e = 0; e < row.size();) {
+                zc acc = 0;
+                size_t f = e;
+                for (; f < row.size() && row[f].first == row[e].first; ++f) acc += row[f].second;
+                pcol[part].push_back(row[e].first); pval[part].push_back(acc);
+                ++cnt;
+                e = f;
+            }
+            C.ptr[i + 1] = cnt;
         }
     });
     stitch(n, nparts, C.ptr, pcol, pval, C.col, C.val);
@@ -350,6 +377,14 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
     // fine rows into tiles (tiles.h); visiting them in the CALLER's order keeps the aggregates -- and with them the whole
     // hierarchy and the iteration counts -- what they were before the renumbering.
     auto node = [&](int64_t k) -> int64_t { return visit ? (int64_t)(*visit)[k] : k; };
+    const bool pdbg = getenv("WAE_SETUP_DEBUG") != nullptr && n > 100000;
+    double tp0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    auto plap = [&](const char *what) {
+        if (!pdbg) return;
+        const double t = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        fprintf(stderr, "[amg]   (prolongator) %-16s %.3f s\n", what, t - tp0);
+        tp0 = t;
+    };
     std::vector<double> D(n);
     parallel_ranges(n, setup_threads(), [&](int64_t lo, int64_t hi, int) { for (int64_t i = lo; i < hi; ++i) D[i] = std::fabs(diag_of(S, i)); });
     // strength graph (symmetric criterion), restricted to non-skipped nodes
@@ -359,6 +394,7 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
         std::vector<std::vector<int>> pcol(nparts);
         parallel_ranges(n, nparts, [&](int64_t lo, int64_t hi, int part) {
             std::vector<int> &oc = pcol[part];
+            huge_reserve(oc, (size_t)(S.ptr[hi] - S.ptr[lo]));
             for (int64_t i = lo; i < hi; ++i) {
                 int cnt = 0;
                 if (!skip[i])
@@ -375,6 +411,7 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
         size_t off = 0;
         for (auto &v : pcol) { std::copy(v.begin(), v.end(), gcol.begin() + off); off += v.size(); }
     }
+    plap("strength graph");
     std::vector<int> agg(n, -1);
     int na = 0;
     for (int64_t k = 0; k < n; ++k) {   // pass 1: root nodes whose whole strong neighbourhood is free
@@ -444,6 +481,7 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
         for (int64_t i = 0; i < n; ++i) if (agg[i] >= 0) agg[i] = relabel[agg[i]];
         na = nn;
     }
+    plap("aggregation");
     // tentative prolongator (piecewise constant)
     CsrD Pt;
     Pt.n = n; Pt.m = na;
@@ -465,6 +503,7 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
         parallel_ranges(n, nparts, [&](int64_t lo, int64_t hi, int part) {
             std::vector<int> &oc = pcol[part];
             std::vector<double> &ov = pval[part];
+            huge_reserve(oc, (size_t)(S.ptr[hi] - S.ptr[lo]) + (size_t)(hi - lo)); huge_reserve(ov, (size_t)(S.ptr[hi] - S.ptr[lo]) + (size_t)(hi - lo));
             for (int64_t i = lo; i < hi; ++i) {
                 const size_t row0 = oc.size();
                 if (!skip[i]) {
@@ -495,13 +534,21 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
         });
         stitch(n, nparts, F.ptr, pcol, pval, F.col, F.val);
     }
+    plap("filtered matrix");
+    // F * P_tentative does not need the spectral radius: it runs on half of the host threads beside the power iteration
+    CsrD FP;
+    FP.n = n; FP.m = na;
+    const int th_half = std::max(1, setup_threads() / 2);
+    auto fp_job = std::async(std::launch::async, [&]() {
+        spgemm<double, double, double>(n, na, F.ptr, F.col, F.val, Pt.ptr, Pt.col, Pt.val, FP.ptr, FP.col, FP.val, th_half);
+    });
     // spectral radius of D^-1 F by power iteration
     std::vector<double> x(n), y(n);
     uint64_t lcg = 88172645463325252ull;
     for (int64_t i = 0; i < n; ++i) { lcg ^= lcg << 13; lcg ^= lcg >> 7; lcg ^= lcg << 17; x[i] = (double)(lcg % 2000) / 1000.0 - 1.0; }
     double rho = 1.0;
     for (int it = 0; it < 20; ++it) {
-        parallel_ranges(n, setup_threads(), [&](int64_t lo, int64_t hi, int) {
+        parallel_ranges(n, th_half, [&](int64_t lo, int64_t hi, int) {
             for (int64_t i = lo; i < hi; ++i) {
                 double s = 0.0;
                 for (int p = F.ptr[i]; p < F.ptr[i + 1]; ++p) s += F.val[p] * x[F.col[p]];
@@ -513,14 +560,14 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
         nrm = std::sqrt(nrm);
         if (nrm == 0.0) break;
         rho = nrm;
-        for (int64_t i = 0; i < n; ++i) x[i] = y[i] / nrm;
+        parallel_ranges(n, th_half, [&](int64_t lo, int64_t hi, int) { for (int64_t i = lo; i < hi; ++i) x[i] = y[i] / nrm; });
     }
     // note: with x normalised each sweep, ||D^-1 F x|| -> rho
     const double omega = (4.0 / 3.0) / rho;
     // P = Pt - omega * D^-1 F Pt
-    CsrD FP;
-    FP.n = n; FP.m = na;
-    spgemm<double, double, double>(n, na, F.ptr, F.col, F.val, Pt.ptr, Pt.col, Pt.val, FP.ptr, FP.col, FP.val, setup_threads());
+    plap("spectral radius");
+    fp_job.get();
+    plap("F * P_tentative (wait)");
     CsrD P;
     P.n = n; P.m = na;
     P.ptr.assign(n + 1, 0);
@@ -531,6 +578,7 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
         parallel_ranges(n, nparts, [&](int64_t lo, int64_t hi, int part) {
             std::vector<int> &oc = pcol[part];
             std::vector<double> &ov = pval[part];
+            huge_reserve(oc, (size_t)(FP.ptr[hi] - FP.ptr[lo]) + (size_t)(hi - lo)); huge_reserve(ov, (size_t)(FP.ptr[hi] - FP.ptr[lo]) + (size_t)(hi - lo));
             for (int64_t i = lo; i < hi; ++i) {
                 const size_t row0 = oc.size();
                 if (!skip[i]) {
@@ -554,6 +602,7 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
         });
         stitch(n, nparts, P.ptr, pcol, pval, P.col, P.val);
     }
+    plap("assembly");
     return P;
 }
 
@@ -587,6 +636,7 @@ void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, c
         parallel_ranges(n0, nparts, [&](int64_t lo, int64_t hi, int part) {
             std::vector<int> &oc = pcol[part];
             std::vector<double> &ov = pval[part];
+            huge_reserve(oc, (size_t)(Aref.ptr[hi] - Aref.ptr[lo])); huge_reserve(ov, (size_t)(Aref.ptr[hi] - Aref.ptr[lo]));
             for (int64_t i = lo; i < hi; ++i) {
                 int cnt = 0;
                 for (int p = Aref.ptr[i]; p < Aref.ptr[i + 1]; ++p) {
@@ -624,7 +674,7 @@ void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, c
     }
     if (penalty_rows) *penalty_rows = skip;
     lap("shape matrix + penalty rows");
-    std::vector<CsrZ> cur(planes);
+    const std::vector<CsrZ> *curp = &planes;               // the planes of the level being coarsened (no copies: `levels` is reserved)
     int64_t n = n0;
     while (n > opt.max_coarse && (int)levels.size() < opt.max_levels) {
         CsrD P = build_prolongator(S, skip, opt.theta, true, levels.empty() ? visit0 : nullptr);
@@ -632,7 +682,7 @@ void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, c
         if (P.m >= (int64_t)(0.9 * n) || P.m == 0) break;
         CsrD R = csr_transpose(P);
         AmgLevel L;
-        L.P = P; L.R = R;
+        const std::vector<CsrZ> &cur = *curp;
         // the triple products of the planes (and of the shape matrix) are independent: one host thread each
         std::vector<CsrZ> next(cur.size());
         {
@@ -652,11 +702,14 @@ void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, c
             S = std::move(Snext);
         }
         lap("galerkin products");
-        L.coarse_planes = next;
+        L.P = std::move(P); L.R = std::move(R);
+        L.coarse_planes = std::move(next);
         levels.push_back(std::move(L));
+        // (the callback -- and whatever it starts on other threads -- may change P and R of this level, not its planes: the next
+        // level is built from them)
         if (on_level) on_level(levels.back());
+        curp = &levels.back().coarse_planes;
         n = S.n;
         skip.assign(n, 0);
-        cur.swap(next);
     }
 }

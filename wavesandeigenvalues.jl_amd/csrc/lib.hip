@@ -191,24 +191,31 @@ static std::vector<int> build_levelop(LevelOp &L, const std::vector<CsrZ> &plane
         auto pack = [&](const std::vector<const CsrZ *> &mats, std::vector<double> &out) {
             const int64_t nnz = mats[0]->nnz();
             out.resize((size_t)nnz * np * w);
-            for (int k = 0; k < np; ++k)
-                for (int64_t p = 0; p < nnz; ++p) {
-                    const zc v = mats[k]->val[p];
-                    if (g.real) out[(size_t)p * np + k] = v.real();
-                    else { out[((size_t)p * np + k) * 2] = v.real(); out[((size_t)p * np + k) * 2 + 1] = v.imag(); }
-                }
+            const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(8, nnz / 262144));      // (host threads: entries in contiguous ranges)
+            std::vector<std::future<void>> jobs;
+            for (int t = 0; t < nth; ++t)
+                jobs.push_back(std::async(nth > 1 ? std::launch::async : std::launch::deferred, [&, t]() {
+                    const int64_t lo = nnz * t / nth, hi = nnz * (t + 1) / nth;
+                    for (int64_t p = lo; p < hi; ++p)
+                        for (int k = 0; k < np; ++k) {
+                            const zc v = mats[k]->val[p];
+                            if (g.real) out[(size_t)p * np + k] = v.real();
+                            else { out[((size_t)p * np + k) * 2] = v.real(); out[((size_t)p * np + k) * 2 + 1] = v.imag(); }
+                        }
+                }));
+            for (auto &j : jobs) j.get();
         };
         // long rows go to the level's long-row store (OpDev) and leave the group's CSR arrays
-        auto strip = [&](const std::vector<CsrZ> &src, std::vector<CsrZ> &kept, LongEntries &LE) {
+        auto strip = [&](const std::vector<const CsrZ *> &src, std::vector<CsrZ> &kept, LongEntries &LE) {
             kept.clear();
-            std::vector<char> is_long(src[0].n, 0);
+            std::vector<char> is_long(src[0]->n, 0);
             bool any = false;
             const int limit = getenv("WAE_LONG_ROW") ? std::max(1, atoi(getenv("WAE_LONG_ROW"))) : WAE_LONG_ROW;   // (tests lower it)
-            for (int64_t i = 0; i < src[0].n; ++i)
-                if (src[0].ptr[i + 1] - src[0].ptr[i] > limit) { is_long[i] = 1; any = true; }
+            for (int64_t i = 0; i < src[0]->n; ++i)
+                if (src[0]->ptr[i + 1] - src[0]->ptr[i] > limit) { is_long[i] = 1; any = true; }
             if (!any) return false;
             for (size_t k = 0; k < src.size(); ++k) {
-                const CsrZ &A = src[k];
+                const CsrZ &A = *src[k];
                 CsrZ B;
                 B.n = A.n; B.m = A.m;
                 B.ptr.assign(A.n + 1, 0);
@@ -225,17 +232,56 @@ static std::vector<int> build_levelop(LevelOp &L, const std::vector<CsrZ> &plane
             }
             return true;
         };
-        std::vector<CsrZ> own;
-        for (int q : g.members) own.push_back(planes[q]);
+        std::vector<const CsrZ *> own;
+        for (int q : g.members) own.push_back(&planes[q]);
         // transpose orientation.  Symmetry test: same pattern, and values that differ from their mirror entries by no more than
         // 1e-14 of the plane's largest entry -- a finite-element matrix assembled in floating point is symmetric only up to the
         // order of its element sums (K and M of the 200k..1M-DoF annulus: 1e-16 of the largest entry in half of the entries), and a
         // bitwise test sent every adjoint product of such a family through a second, transposed copy of the operator and past the
         // tile kernel.  A plane accepted here is applied in its stored orientation for op = T / C: the product then differs from the
         // exact transposed one by that assembly rounding, below the rounding of the product itself.
+        // The mirror entry a_ji is looked up in row j (sorted columns) on the host threads; the transposed copies are built only for
+        // a group that fails the test (or whose rows are not sorted: then the transpose decides, as it used to).
+        auto mirror_test = [](const CsrZ &P) -> int {           // 1 symmetric, 0 not, -1 unsorted rows (undecided)
+            if (P.n != P.m) return 0;
+            const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(16, P.n / 8192));
+            std::vector<double> vmax(nth, 0.0), dmax(nth, 0.0);
+            std::vector<int> verdict(nth, 1);
+            std::vector<std::future<void>> jobs;
+            for (int t = 0; t < nth; ++t)
+                jobs.push_back(std::async(nth > 1 ? std::launch::async : std::launch::deferred, [&, t]() {
+                    const int64_t lo = P.n * t / nth, hi = P.n * (t + 1) / nth;
+                    double vm = 0.0, dm = 0.0;                // (thread-local: the per-thread slots share cache lines)
+                    int vd = 1;
+                    for (int64_t i = lo; i < hi && vd == 1; ++i)
+                        for (int p = P.ptr[i]; p < P.ptr[i + 1]; ++p) {
+                            if (p > P.ptr[i] && P.col[p - 1] >= P.col[p]) { vd = -1; break; }
+                            const int j = P.col[p];
+                            vm = std::max(vm, std::norm(P.val[p]));
+                            if (j == i) continue;
+                            const int *b = P.col.data() + P.ptr[j], *e = P.col.data() + P.ptr[j + 1];
+                            const int *f = std::lower_bound(b, e, (int)i);
+                            if (f == e || *f != (int)i) { vd = 0; break; }
+                            dm = std::max(dm, std::norm(P.val[p] - P.val[(size_t)(f - P.col.data())]));
+                        }
+                    vmax[t] = std::sqrt(vm); dmax[t] = std::sqrt(dm); verdict[t] = vd;
+                }));
+            for (auto &j : jobs) j.get();
+            double vm = 0.0, dm = 0.0;
+            int v = 1;
+            for (int t = 0; t < nth; ++t) { vm = std::max(vm, vmax[t]); dm = std::max(dm, dmax[t]); if (verdict[t] == -1) v = -1; else if (verdict[t] == 0 && v == 1) v = 0; }
+            if (v == 1 && !(dm <= 1e-14 * vm)) v = 0;
+            return v;
+        };
         std::vector<CsrZ> tr;
         bool sym = (A0.n == A0.m);
-        {
+        bool undecided = false;
+        for (size_t k = 0; k < g.members.size() && sym; ++k) {
+            const int v = mirror_test(planes[g.members[k]]);
+            if (v == 0) sym = false;
+            if (v < 0) { undecided = true; break; }
+        }
+        if (!sym || undecided) {
             std::vector<std::future<CsrZ>> tj;
             for (int q : g.members) tj.push_back(std::async(std::launch::async, [&planes, q]() { return csr_transpose(planes[q]); }));
             for (size_t k = 0; k < tj.size(); ++k) {
@@ -259,24 +305,26 @@ static std::vector<int> build_levelop(LevelOp &L, const std::vector<CsrZ> &plane
             std::vector<CsrZ> dummy;
             strip(own, dummy, long_t);
         }
-        const std::vector<CsrZ> &src_n = stripped_n ? kept : own;
         std::vector<const CsrZ *> mats;
-        for (const CsrZ &M : src_n) mats.push_back(&M);
+        if (stripped_n) for (const CsrZ &M : kept) mats.push_back(&M);
+        else mats = own;
         std::vector<double> packed;
         pack(mats, packed);
-        G.rowptr.upload(src_n[0].ptr.data(), src_n[0].ptr.size(), st);
-        G.col.upload(src_n[0].col.data(), src_n[0].col.size(), st);
+        G.rowptr.upload(mats[0]->ptr.data(), mats[0]->ptr.size(), st);
+        G.col.upload(mats[0]->col.data(), mats[0]->col.size(), st);
         G.vals.upload(packed.data(), packed.size(), st);
         std::vector<CsrZ> kept_t;
+        std::vector<double> tp;
         if (!sym) {
-            const bool stripped_t = strip(tr, kept_t, long_t);
-            const std::vector<CsrZ> &src_t = stripped_t ? kept_t : tr;
+            std::vector<const CsrZ *> trp;
+            for (const CsrZ &t : tr) trp.push_back(&t);
+            const bool stripped_t = strip(trp, kept_t, long_t);
             std::vector<const CsrZ *> tm;
-            for (const CsrZ &t : src_t) tm.push_back(&t);
-            std::vector<double> tp;
+            if (stripped_t) for (const CsrZ &t : kept_t) tm.push_back(&t);
+            else tm = trp;
             pack(tm, tp);
-            G.rowptr_t.upload(src_t[0].ptr.data(), src_t[0].ptr.size(), st);
-            G.col_t.upload(src_t[0].col.data(), src_t[0].col.size(), st);
+            G.rowptr_t.upload(tm[0]->ptr.data(), tm[0]->ptr.size(), st);
+            G.col_t.upload(tm[0]->col.data(), tm[0]->col.size(), st);
             G.vals_t.upload(tp.data(), tp.size(), st);
         }
         HIP_CHECK(hipStreamSynchronize(st));   // host staging buffers die at scope end
@@ -2070,19 +2118,114 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
         // fine-level aggregation in the caller's node order (iperm[o] = internal index of the caller's node o)
         std::vector<int> visit0;
         if (!h->perm_h.empty()) { visit0.resize(h->perm_h.size()); for (size_t i = 0; i < h->perm_h.size(); ++i) visit0[h->perm_h[i]] = (int)i; }
-        // The tile plan of level 1 needs only that level's sparsity pattern: it is computed on a helper thread while the host
-        // builds the deeper levels (0.3 s at 1M unknowns, hidden behind the second prolongator and its triple products).
+        // Everything of level 1 -- tile plan, renumbering, operator groups, tile storage, the transfer operators of level 0 and the tile
+        // storage of the restriction -- needs only that level's planes and the first prolongator: it runs on a helper thread, with a
+        // stream of its own, while the host builds the deeper levels (round 3, second half: 0.7 s of work of which 0.15 s used to be
+        // hidden).  The level's operator is built into a local object and moved into the handle once the number of levels is known.
         const int tile1 = getenv("WAE_TILE_LEVEL1") ? atoi(getenv("WAE_TILE_LEVEL1")) : 1;      // (read per call: the tests switch it)
-        std::future<TilePlan> plan_job;
-        struct JoinPlan { std::future<TilePlan> &f; ~JoinPlan() { if (f.valid()) f.wait(); } } plan_join{plan_job};
         const bool want_plan = tile1 && !h->tile_row_ptr.empty();
+        struct Level1Work {
+            std::vector<int> row_ptr, perm, iperm;      // tile plan of level 1 (empty: no tiles)
+            int wmax = 0;
+            std::vector<CsrZ> planes;                    // the level's planes in the new numbering (amg_setup still reads the old ones)
+            LevelOp op;                                  // level-1 operator (groups + tiles)
+            std::vector<int> slot_plane;
+            Transfer xfer0;                              // P / R of level 0 (+ restriction tiles)
+            bool built = false;
+            double seconds = 0.0;
+        } l1;
+        std::future<void> l1_job;
+        struct JoinL1 { std::future<void> &f; ~JoinL1() { if (f.valid()) f.wait(); } } l1_join{l1_job};
+        auto upload_transfer = [](Transfer &X, const AmgLevel &L, hipStream_t s2) {
+            X.nf = L.P.n; X.nc = L.P.m;
+            X.p_ptr.upload(L.P.ptr.data(), L.P.ptr.size(), s2);
+            X.p_col.upload(L.P.col.data(), L.P.col.size(), s2);
+            X.p_val.upload(L.P.val.data(), L.P.val.size(), s2);
+            X.r_ptr.upload(L.R.ptr.data(), L.R.ptr.size(), s2);
+            X.r_col.upload(L.R.col.data(), L.R.col.size(), s2);
+            X.r_val.upload(L.R.val.data(), L.R.val.size(), s2);
+            HIP_CHECK(hipStreamSynchronize(s2));
+        };
+        auto rename_cols = [](CsrD &A, const std::vector<int> &ip) {            // column c -> ip[c], rows re-sorted
+            std::vector<std::pair<int, double>> row;
+            for (int64_t i = 0; i < A.n; ++i) {
+                row.clear();
+                for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) row.emplace_back(ip[A.col[p]], A.val[p]);
+                std::sort(row.begin(), row.end(), [](const std::pair<int, double> &x, const std::pair<int, double> &y) { return x.first < y.first; });
+                for (int p = A.ptr[i], k = 0; p < A.ptr[i + 1]; ++p, ++k) { A.col[p] = row[k].first; A.val[p] = row[k].second; }
+            }
+        };
+        auto permute_rows = [](CsrD &A, const std::vector<int> &pm) {           // new row i = old row pm[i]
+            CsrD B;
+            B.n = A.n; B.m = A.m;
+            B.ptr.assign(A.n + 1, 0);
+            B.col.reserve(A.col.size()); B.val.reserve(A.val.size());
+            for (int64_t i = 0; i < A.n; ++i) {
+                const int o = pm[i];
+                B.col.insert(B.col.end(), A.col.begin() + A.ptr[o], A.col.begin() + A.ptr[o + 1]);
+                B.val.insert(B.val.end(), A.val.begin() + A.ptr[o], A.val.begin() + A.ptr[o + 1]);
+                B.ptr[i + 1] = (int)B.col.size();
+            }
+            A = std::move(B);
+        };
         amg_setup(h->planes0, pc, ao, lv, &pen, excl ? &pc_shape : nullptr, visit0.empty() ? nullptr : &visit0,
                   [&](const AmgLevel &L) {
-                      if (!want_plan || plan_job.valid() || &L != &lv[0]) return;
-                      const int wcap = getenv("WAE_TILE_WCAP1") ? atoi(getenv("WAE_TILE_WCAP1")) : 608;        // (two window buffers)
-                      const int thick = getenv("WAE_TILE_THICK") ? atoi(getenv("WAE_TILE_THICK")) : 6;
-                      const std::vector<CsrZ> *pl = &L.coarse_planes;
-                      plan_job = std::async(std::launch::async, [pl, wcap, thick]() { return plan_tiles(union_pattern(*pl), 128, wcap, thick); });
+                      if (!want_plan || l1_job.valid() || &L != &lv[0]) return;
+                      // (the level object stays where it is -- amg_setup reserves its levels -- and nothing else touches it until the join)
+                      l1_job = std::async(std::launch::async, [&, h]() {
+                          const double tq0 = now_s();
+                          HIP_CHECK(hipSetDevice(h->device));
+                          hipStream_t s3;
+                          HIP_CHECK(hipStreamCreate(&s3));
+                          struct Del { hipStream_t s; ~Del() { (void)hipStreamDestroy(s); } } del{s3};
+                          const int wcap = getenv("WAE_TILE_WCAP1") ? atoi(getenv("WAE_TILE_WCAP1")) : 608;        // (two window buffers)
+                          const int thick = getenv("WAE_TILE_THICK") ? atoi(getenv("WAE_TILE_THICK")) : 6;
+                          AmgLevel &L0 = lv[0];
+                          const bool jdbg = getenv("WAE_SETUP_DEBUG") != nullptr;
+                          double tj = now_s();
+                          auto jlap = [&](const char *what) { if (jdbg) { const double t = now_s(); fprintf(stderr, "[setup]   (level-1 thread) %-22s %.3f s\n", what, t - tj); tj = t; } };
+                          TilePlan plan = plan_tiles(union_pattern(L0.coarse_planes), 128, wcap, thick);
+                          l1.wmax = plan.wmax;
+                          jlap("tile plan");
+                          if (!plan.perm.empty()) {
+                              // Level 1 renumbered into tiles as well (the numbering of a coarse level is nobody's business but the
+                              // hierarchy's): P of level 0 changes its columns, R its rows; the transfer to level 2 the other way round
+                              // (after the join, when it exists).
+                              l1.perm = plan.perm; l1.iperm = plan.iperm; l1.row_ptr = plan.row_ptr;
+                              std::vector<std::future<void>> pj;
+                              l1.planes.resize(L0.coarse_planes.size());
+                              for (size_t q = 0; q < L0.coarse_planes.size(); ++q)
+                                  pj.push_back(std::async(std::launch::async, [&L0, q, this_l1 = &l1]() {
+                                      this_l1->planes[q] = permute_symmetric(L0.coarse_planes[q], this_l1->perm, this_l1->iperm);
+                                  }));
+                              auto j1 = std::async(std::launch::async, [&]() { rename_cols(L0.P, l1.iperm); });
+                              permute_rows(L0.R, l1.perm);
+                              j1.get();
+                              for (auto &j : pj) j.get();
+                          }
+                          jlap("permutation");
+                          // the transfer operators and the restriction's tile storage beside the operator (a thread and a stream of their own)
+                          const bool with_tiles = !l1.row_ptr.empty();
+                          auto xj = std::async(std::launch::async, [&, h, with_tiles, wcap]() {
+                              HIP_CHECK(hipSetDevice(h->device));
+                              hipStream_t s2;
+                              HIP_CHECK(hipStreamCreate(&s2));
+                              struct Del2 { hipStream_t s; ~Del2() { (void)hipStreamDestroy(s); } } del2{s2};
+                              upload_transfer(l1.xfer0, L0, s2);
+                              const int tile_r = getenv("WAE_TILE_RESTRICT") ? atoi(getenv("WAE_TILE_RESTRICT")) : 1;
+                              if (with_tiles && tile_r) build_restriction_tiles(l1.xfer0, L0.R, wcap, s2);
+                          });
+                          const std::vector<CsrZ> &pl1 = l1.planes.empty() ? L0.coarse_planes : l1.planes;
+                          l1.slot_plane = build_levelop(l1.op, pl1, s3);
+                          jlap("operator groups");
+                          if (with_tiles) build_level_tiles(l1.op, pl1, l1.slot_plane, l1.row_ptr, s3, 4);
+                          HIP_CHECK(hipStreamSynchronize(s3));
+                          jlap("tile storage");
+                          xj.get();
+                          jlap("wait for the transfer");
+                          l1.built = true;
+                          l1.seconds = now_s() - tq0;
+                      });
                   });
         const double t_amg1 = now_s();
         if (getenv("WAE_SETUP_DEBUG")) {
@@ -2105,57 +2248,18 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
             fprintf(stderr, "[setup] %-34s %.3f s\n", what, t - t_lap);
             t_lap = t;
         };
-        // Level 1 renumbered into tiles as well (the numbering of a coarse level is nobody's business but the hierarchy's): its
-        // operator -- ~48 nonzeros per row, gathered from L2 at 1 KB per nonzero and launch -- then runs through the tile kernel.
-        // P of level 0 changes its columns, R its rows; the transfer to level 2 the other way round.
-        std::vector<int> tile1_row_ptr;
-        if (plan_job.valid() && lv.size() < 2) plan_job.get();           // (a two-level hierarchy: level 1 is the dense one)
-        if (plan_job.valid() && lv.size() >= 2) {
-            const double tq0 = now_s();
-            TilePlan plan = plan_job.get();
-            if (!plan.perm.empty()) {
-                const std::vector<int> &pm = plan.perm, &ip = plan.iperm;
-                {
-                    std::vector<std::future<void>> pj;
-                    for (CsrZ &A : lv[0].coarse_planes) pj.push_back(std::async(std::launch::async, [&A, &pm, &ip]() { A = permute_symmetric(A, pm, ip); }));
-                    for (auto &j : pj) j.get();
-                }
-                auto rename_cols = [&](CsrD &A) {            // column c -> ip[c], rows re-sorted
-                    std::vector<std::pair<int, double>> row;
-                    for (int64_t i = 0; i < A.n; ++i) {
-                        row.clear();
-                        for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) row.emplace_back(ip[A.col[p]], A.val[p]);
-                        std::sort(row.begin(), row.end(), [](const std::pair<int, double> &x, const std::pair<int, double> &y) { return x.first < y.first; });
-                        for (int p = A.ptr[i], k = 0; p < A.ptr[i + 1]; ++p, ++k) { A.col[p] = row[k].first; A.val[p] = row[k].second; }
-                    }
-                };
-                auto permute_rows = [&](CsrD &A) {           // new row i = old row pm[i]
-                    CsrD B;
-                    B.n = A.n; B.m = A.m;
-                    B.ptr.assign(A.n + 1, 0);
-                    B.col.reserve(A.col.size()); B.val.reserve(A.val.size());
-                    for (int64_t i = 0; i < A.n; ++i) {
-                        const int o = pm[i];
-                        B.col.insert(B.col.end(), A.col.begin() + A.ptr[o], A.col.begin() + A.ptr[o + 1]);
-                        B.val.insert(B.val.end(), A.val.begin() + A.ptr[o], A.val.begin() + A.ptr[o + 1]);
-                        B.ptr[i + 1] = (int)B.col.size();
-                    }
-                    A = std::move(B);
-                };
-                {
-                    auto j1 = std::async(std::launch::async, [&]() { rename_cols(lv[0].P); });
-                    auto j2 = std::async(std::launch::async, [&]() { permute_rows(lv[0].R); });
-                    auto j3 = std::async(std::launch::async, [&]() { permute_rows(lv[1].P); });
-                    rename_cols(lv[1].R);
-                    j1.get(); j2.get(); j3.get();
-                }
-                tile1_row_ptr = plan.row_ptr;
-            }
-            if (getenv("WAE_SETUP_DEBUG"))
-                fprintf(stderr, "[setup] level 1 tile plan + permutation %.3f s (%zu tiles, largest window %d)\n", now_s() - tq0,
-                        plan.row_ptr.empty() ? (size_t)0 : plan.row_ptr.size() - 1, plan.wmax);
+        if (l1_job.valid()) l1_job.get();                                   // (rethrows)
+        if (!l1.planes.empty()) lv[0].coarse_planes = std::move(l1.planes);
+        if (l1.built && !l1.perm.empty() && lv.size() >= 2) {              // the transfer to level 2 in the new numbering of level 1
+            auto j3 = std::async(std::launch::async, [&]() { permute_rows(lv[1].P, l1.perm); });
+            rename_cols(lv[1].R, l1.iperm);
+            j3.get();
         }
-        lap("level-1 plan + permutation");
+        const bool l1_dense = lv.size() < 2;                                // (a two-level hierarchy: level 1 is the dense one; its tiles are not used)
+        if (getenv("WAE_SETUP_DEBUG") && l1.built)
+            fprintf(stderr, "[setup] level 1 on the helper thread: plan + permutation + operator + tiles + transfer %.3f s (%zu tiles, largest window %d)\n",
+                    l1.seconds, l1.row_ptr.empty() ? (size_t)0 : l1.row_ptr.size() - 1, l1.wmax);
+        lap("wait for level 1 (helper thread)");
         {   // the penalty rows' own sub-block, plane by plane (compact numbering)
             std::vector<int> rows, loc(pen.size(), -1);
             for (size_t i = 0; i < pen.size(); ++i)
@@ -2199,42 +2303,16 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
         h->ops.resize(lv.size() + 1);
         h->slot_plane.resize(lv.size() + 1);
         h->xfer.resize(lv.size());
-        // the transfer operators of level 0 and the tile storage of the restriction: on a helper thread with a stream of its own,
-        // beside the level-1 operator (nothing shared but the device)
-        std::future<void> xfer0_job;
-        struct JoinX { std::future<void> &f; ~JoinX() { if (f.valid()) f.wait(); } } xfer0_join{xfer0_job};
-        auto upload_transfer = [](Transfer &X, const AmgLevel &L, hipStream_t s2) {
-            X.nf = L.P.n; X.nc = L.P.m;
-            X.p_ptr.upload(L.P.ptr.data(), L.P.ptr.size(), s2);
-            X.p_col.upload(L.P.col.data(), L.P.col.size(), s2);
-            X.p_val.upload(L.P.val.data(), L.P.val.size(), s2);
-            X.r_ptr.upload(L.R.ptr.data(), L.R.ptr.size(), s2);
-            X.r_col.upload(L.R.col.data(), L.R.col.size(), s2);
-            X.r_val.upload(L.R.val.data(), L.R.val.size(), s2);
-            HIP_CHECK(hipStreamSynchronize(s2));
-        };
-        if (!lv.empty()) {
-            const bool with_tiles = !tile1_row_ptr.empty();
-            xfer0_job = std::async(std::launch::async, [h, &lv, upload_transfer, with_tiles]() {
-                HIP_CHECK(hipSetDevice(h->device));
-                hipStream_t s2;
-                HIP_CHECK(hipStreamCreate(&s2));
-                struct Del { hipStream_t s; ~Del() { (void)hipStreamDestroy(s); } } del{s2};
-                upload_transfer(h->xfer[0], lv[0], s2);
-                if (with_tiles) {
-                    const int wcap = getenv("WAE_TILE_WCAP1") ? atoi(getenv("WAE_TILE_WCAP1")) : 608;
-                    const int tile_r = getenv("WAE_TILE_RESTRICT") ? atoi(getenv("WAE_TILE_RESTRICT")) : 1;
-                    if (tile_r) build_restriction_tiles(h->xfer[0], lv[0].R, wcap, s2);
-                }
-            });
-        }
         for (size_t l = 0; l < lv.size(); ++l) {
+            if (l == 0 && l1.built) {
+                h->slot_plane[1] = l1.slot_plane;
+                if (l1_dense) l1.op.tiles = TileStore();                   // (not reached in practice: a tiled fine level has a large level 1)
+                h->ops[1] = std::move(l1.op);
+                h->xfer[0] = std::move(l1.xfer0);
+                continue;
+            }
             h->slot_plane[l + 1] = build_levelop(h->ops[l + 1], lv[l].coarse_planes, st);
-            if (l == 0) lap("level-1 operator (groups, upload)");
-            if (l == 0 && !tile1_row_ptr.empty()) build_level_tiles(h->ops[1], lv[0].coarse_planes, h->slot_plane[1], tile1_row_ptr, st, 4);
-            if (l == 0) lap("level-1 tile storage");
-            if (l == 0) { xfer0_job.get(); lap("transfer + restriction tiles (helper thread): wait"); }
-            else upload_transfer(h->xfer[l], lv[l], st);
+            upload_transfer(h->xfer[l], lv[l], st);
         }
         lap("levels >= 2");
         // dense planes of the coarsest level (plane order, row-major)

@@ -9,6 +9,7 @@
 // The ordering needs no coordinates: three nested breadth-first stages on the pattern graph -- shells of a BFS from a
 // pseudo-peripheral node, strips inside a shell, bricks inside a strip -- each a few levels thick.
 #include "tiles.h"
+#include "hugemem.h"
 
 #include <algorithm>
 #include <atomic>
@@ -244,22 +245,45 @@ TilePlan plan_tiles(const Pattern &U, int tile_rows, int wcap, int thick) {
     return P;
 }
 
+// host threads of the set-up (as csrc/amg.cpp): contiguous ranges of rows / tiles, one per thread; every range writes its own part
+// of the output, so the result is the serial one
+static int tile_threads() {
+    static const int n = []() {
+        if (const char *e = getenv("WAE_SETUP_THREADS")) return std::max(1, atoi(e));
+        return (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    }();
+    return n;
+}
+template <class F> static void tile_ranges(int64_t n, int64_t grain, F &&body) {
+    const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(tile_threads(), n / std::max<int64_t>(grain, 1) + 1));
+    if (nparts == 1) { body((int64_t)0, n); return; }
+    std::vector<std::future<void>> jobs;
+    for (int t = 0; t < nparts; ++t) {
+        const int64_t lo = n * t / nparts, hi = n * (t + 1) / nparts;
+        jobs.push_back(std::async(std::launch::async, [&body, lo, hi]() { body(lo, hi); }));
+    }
+    for (auto &j : jobs) j.get();
+}
+
 CsrZ permute_symmetric(const CsrZ &A, const std::vector<int> &perm, const std::vector<int> &iperm) {
     CsrZ B;
     B.n = A.n; B.m = A.m;
     B.ptr.assign(A.n + 1, 0);
     for (int64_t i = 0; i < A.n; ++i) B.ptr[i + 1] = B.ptr[i] + (A.ptr[perm[i] + 1] - A.ptr[perm[i]]);
+    huge_reserve(B.col, A.col.size()); huge_reserve(B.val, A.val.size());
     B.col.resize(A.col.size());
     B.val.resize(A.val.size());
-    std::vector<std::pair<int, zc>> row;
-    for (int64_t i = 0; i < A.n; ++i) {
-        const int old = perm[i];
-        row.clear();
-        for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) row.emplace_back(iperm[A.col[p]], A.val[p]);
-        std::sort(row.begin(), row.end(), [](const std::pair<int, zc> &x, const std::pair<int, zc> &y) { return x.first < y.first; });
-        int q = B.ptr[i];
-        for (const auto &e : row) { B.col[q] = e.first; B.val[q] = e.second; ++q; }
-    }
+    tile_ranges(A.n, 8192, [&](int64_t lo, int64_t hi) {
+        std::vector<std::pair<int, zc>> row;
+        for (int64_t i = lo; i < hi; ++i) {
+            const int old = perm[i];
+            row.clear();
+            for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) row.emplace_back(iperm[A.col[p]], A.val[p]);
+            std::sort(row.begin(), row.end(), [](const std::pair<int, zc> &x, const std::pair<int, zc> &y) { return x.first < y.first; });
+            int q = B.ptr[i];
+            for (const auto &e : row) { B.col[q] = e.first; B.val[q] = e.second; ++q; }
+        }
+    });
     return B;
 }
 
@@ -267,14 +291,20 @@ TileWindows build_windows(const Pattern &U, const std::vector<int> &row_ptr) {
     TileWindows W;
     const size_t nt = row_ptr.size() - 1;
     W.win_ptr.assign(nt + 1, 0);
-    std::vector<int> buf;
-    for (size_t t = 0; t < nt; ++t) {
-        buf.assign(U.col.begin() + U.ptr[row_ptr[t]], U.col.begin() + U.ptr[row_ptr[t + 1]]);
-        std::sort(buf.begin(), buf.end());
-        buf.erase(std::unique(buf.begin(), buf.end()), buf.end());
-        W.win_cols.insert(W.win_cols.end(), buf.begin(), buf.end());
-        W.win_ptr[t + 1] = (int)W.win_cols.size();
-    }
+    std::vector<std::vector<int>> per(nt);                   // sorted distinct columns of every tile, then laid end to end
+    tile_ranges((int64_t)nt, 64, [&](int64_t lo, int64_t hi) {
+        for (int64_t t = lo; t < hi; ++t) {
+            std::vector<int> &buf = per[(size_t)t];
+            buf.assign(U.col.begin() + U.ptr[row_ptr[t]], U.col.begin() + U.ptr[row_ptr[t + 1]]);
+            std::sort(buf.begin(), buf.end());
+            buf.erase(std::unique(buf.begin(), buf.end()), buf.end());
+        }
+    });
+    for (size_t t = 0; t < nt; ++t) W.win_ptr[t + 1] = W.win_ptr[t] + (int)per[t].size();
+    W.win_cols.resize((size_t)W.win_ptr[nt]);
+    tile_ranges((int64_t)nt, 64, [&](int64_t lo, int64_t hi) {
+        for (int64_t t = lo; t < hi; ++t) std::copy(per[(size_t)t].begin(), per[(size_t)t].end(), W.win_cols.begin() + W.win_ptr[(size_t)t]);
+    });
     return W;
 }
 
@@ -296,12 +326,14 @@ TileGroupHost build_tile_group(const std::vector<const CsrZ *> &mats, bool is_re
             T.sptr[TILE_SLICES * t + w + 1] = T.sptr[TILE_SLICES * t + w] + 64 * ((len + lpr - 1) / lpr);
         }
     const size_t total = (size_t)T.sptr.back();
+    huge_reserve(T.sidx, total); huge_reserve(T.svals, total * wpe);
     T.sidx.assign(total, 0);
     T.svals.assign(total * wpe, 0.0);
     T.dslot.assign((size_t)row_ptr.back(), (unsigned short)0xFFFF);
     static const bool parity_sort = !(getenv("WAE_TILE_PARITY") && atoi(getenv("WAE_TILE_PARITY")) == 0);
+    tile_ranges((int64_t)nt, 16, [&](int64_t t_lo, int64_t t_hi) {
     std::vector<std::pair<int, int>> ent, ev, od;
-    for (size_t t = 0; t < nt; ++t) {
+    for (size_t t = (size_t)t_lo; t < (size_t)t_hi; ++t) {
         const int *wc = W.win_cols.data() + W.win_ptr[t];
         const int wn = W.win_ptr[t + 1] - W.win_ptr[t];
         for (int r = row_ptr[t]; r < row_ptr[t + 1]; ++r) {
@@ -344,5 +376,6 @@ TileGroupHost build_tile_group(const std::vector<const CsrZ *> &mats, bool is_re
             }
         }
     }
+    });
     return T;
 }
