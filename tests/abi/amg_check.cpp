@@ -1,7 +1,9 @@
 // Host-only check of csrc/amg.cpp (no GPU needed; built by tests/test_abi.py with hipcc, which provides the HIP vector types the
 // internal header uses): the fused triple product of two planes of one pattern (galerkin_pair: K and M of a Helmholtz family,
 // the largest item of the multigrid set-up) must equal two separate products bit for bit -- pattern and values -- for every
-// thread count, with short and with long rows (the row-wise and the two-step form of galerkin()).
+// thread count, with short and with long rows (the row-wise and the two-step form of galerkin()); and the one-pass shape matrix of
+// amg_setup against the two-step form (linear combination first): same hierarchy.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <random>
@@ -60,6 +62,47 @@ int main() {
             if (!same(C0, galerkin(R, A0, P, nt))) { std::printf("galerkin differs with %d threads\n", nt); return 1; }
             checks += 3;
         }
+    }
+    // The shape matrix of the set-up: the one-pass form (no linear combination as a matrix of its own) against the two-step form,
+    // which the optional shape coefficients select -- here with the same coefficients, so both must build the same hierarchy.
+    {
+        const int64_t n = 20000;
+        std::vector<CsrZ> planes;
+        planes.push_back(random_pattern(n, 13, g));
+        {   // make the first plane structurally symmetric with a dominant diagonal (an elliptic-like operator)
+            CsrZ &K = planes[0];
+            const CsrZ T = csr_transpose(K);
+            std::vector<zc> one(2, zc(1.0));
+            K = csr_lincomb({K, T}, one);
+            for (int64_t i = 0; i < n; ++i)
+                for (int p = K.ptr[i]; p < K.ptr[i + 1]; ++p) K.val[p] = K.col[p] == i ? zc(40.0) : zc(-0.5 - 0.4 * std::cos((double)(K.col[p] + i)));
+        }
+        planes.push_back(planes[0]);                         // a second plane on the same pattern
+        for (zc &v : planes[1].val) v *= 0.01;
+        CsrZ Q;                                              // a small one-sided term: rows 100..399 couple to columns 5, 6
+        Q.n = Q.m = n;
+        Q.ptr.assign(n + 1, 0);
+        for (int64_t i = 0; i < n; ++i) {
+            if (i >= 100 && i < 400) { Q.col.push_back(5); Q.val.push_back(zc(3.0, 1.0)); Q.col.push_back(6); Q.val.push_back(zc(-2.0, 0.5)); }
+            Q.ptr[i + 1] = (int)Q.col.size();
+        }
+        planes.push_back(Q);
+        const std::vector<zc> pc{zc(1.0), zc(-25.0, 3.0), zc(0.7, -0.2)};
+        AmgOptions opt;
+        std::vector<AmgLevel> la, lb;
+        std::vector<char> pa, pb;
+        amg_setup(planes, pc, opt, la, &pa, nullptr);
+        amg_setup(planes, pc, opt, lb, &pb, &pc);
+        if (la.size() != lb.size() || la.empty() || pa != pb) { std::printf("hierarchies differ in depth: %zu %zu\n", la.size(), lb.size()); return 1; }
+        for (size_t l = 0; l < la.size(); ++l) {
+            const bool ok = la[l].P.ptr == lb[l].P.ptr && la[l].P.col == lb[l].P.col && la[l].P.val == lb[l].P.val &&
+                            la[l].coarse_planes.size() == lb[l].coarse_planes.size();
+            if (!ok) { std::printf("level %zu: prolongators differ\n", l); return 1; }
+            for (size_t q = 0; q < la[l].coarse_planes.size(); ++q)
+                if (!same(la[l].coarse_planes[q], lb[l].coarse_planes[q])) { std::printf("level %zu plane %zu differs\n", l, q); return 1; }
+            ++checks;
+        }
+        std::printf("hierarchy: %zu levels, first coarse size %lld\n", la.size(), (long long)la[0].P.m);
     }
     std::printf("amg_check ok %d\n", checks);
     return 0;

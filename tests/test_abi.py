@@ -170,7 +170,8 @@ def test_julia_ccall_signatures_match_the_header():
 
 def test_fused_galerkin_product_is_bit_identical(tmp_path):
     """tests/abi/amg_check.cpp (host only): `galerkin_pair` -- the triple products R K P and R M P of the multigrid set-up formed in one
-    traversal of the shared pattern -- against two separate `galerkin` calls, bit for bit, for several thread counts."""
+    traversal of the shared pattern -- against two separate `galerkin` calls, bit for bit, for several thread counts; and the one-pass
+    shape matrix of `amg_setup` against its two-step form: the same hierarchy."""
     if shutil.which("hipcc") is None:
         pytest.skip("hipcc not on PATH")
     exe = str(tmp_path / "amg_check")
@@ -180,4 +181,4 @@ def test_fused_galerkin_product_is_bit_identical(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "amg_check ok 18" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and "amg_check ok 21" in r.stdout, r.stdout + r.stderr

@@ -331,7 +331,8 @@ CsrZ csr_lincomb(const std::vector<CsrZ> &planes, const std::vector<zc> &coef) {
         // a row's entries of all planes in one short list, ordered by column with the plane order kept among equal columns: the
         // sums are formed in the order of the dense-accumulator version (acc = 0; acc += c_k a_k, k ascending) -- same bits -- without
         // its two m-sized arrays per thread
-        std::vector<std::pair<int, zc>> row;
+        std::vector<std::pair<int64_t, zc>> row;             // key = column * planes + plane (unique: an in-place sort keeps the plane order)
+        const int64_t np = (int64_t)planes.size();
         {   // (an upper bound of this part's output: no regrowth -- every doubling of a 100-MB vector is a copy and a set of fresh pages)
             size_t bound = 0;
             for (const CsrZ &A : planes) bound += (size_t)(A.ptr[hi] - A.ptr[lo]);
@@ -341,15 +342,16 @@ CsrZ csr_lincomb(const std::vector<CsrZ> &planes, const std::vector<zc> &coef) {
             row.clear();
             for (size_t k = 0; k < planes.size(); ++k) {
                 const CsrZ &A = planes[k];
-                for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) row.emplace_back(A.col[p], coef[k] * A.val[p]);
+                for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) row.emplace_back((int64_t)A.col[p] * np + (int64_t)k, coef[k] * A.val[p]);
             }
-            std::stable_sort(row.begin(), row.end(), [](const std::pair<int, zc> &x, const std::pair<int, zc> &y) { return x.first < y.first; });
+            std::sort(row.begin(), row.end(), [](const std::pair<int64_t, zc> &x, const std::pair<int64_t, zc> &y) { return x.first < y.first; });
+            for (auto &e : row) e.first /= np;
             int cnt = 0;
             for (size_t e = 0; e < row.size();) {
                 zc acc = 0;
                 size_t f = e;
                 for (; f < row.size() && row[f].first == row[e].first; ++f) acc += row[f].second;
-                pcol[part].push_back(row[e].first); pval[part].push_back(acc);
+                pcol[part].push_back((int)row[e].first); pval[part].push_back(acc);
                 ++cnt;
                 e = f;
             }
@@ -615,55 +617,118 @@ void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, c
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tq = now();
     auto lap = [&](const char *what) { if (dbg) { const double t = now(); fprintf(stderr, "[amg] %-28s %.3f s\n", what, t - tq); tq = t; } };
-    const CsrZ Afull = csr_lincomb(planes, pc_ref);
-    lap("lincomb");
-    const CsrZ Ashape = pc_shape ? csr_lincomb(planes, *pc_shape) : CsrZ();
-    const CsrZ &Aref = pc_shape ? Ashape : Afull;          // the shape matrix comes from here, the penalty test from Afull
-    const int64_t n0 = Afull.n;
     // Real shape matrix S for strength-of-connection / aggregation / prolongator smoothing: the real part of the
     // STRUCTURALLY SYMMETRIC part of A_ref.  One-sided couplings (the flame term Q = s g^T couples every flame
     // node to the few reference nodes, Helmholtz.jl:464-487) are long-range and non-elliptic: letting them into
     // the strength graph doubles the GMRES iteration count on the 200k-DoF annulus (dev/gpu_solve_check.py).
+    const int64_t n0 = planes.empty() ? 0 : planes[0].n;
     CsrD S;
     S.n = S.m = n0;
     S.ptr.assign(n0 + 1, 0);
-    {
-        // (the mirror entry a_ji is looked up in row j -- columns are sorted -- instead of in a transposed copy: rows are
-        // independent, so the host threads divide them; same entries, same values as the transpose-based loop)
+    std::vector<double> dabs(n0);
+    if (!pc_shape) {
+        // One pass, without the linear combination A_ref = sum_k c_k A_k as a matrix of its own (290 MB written and read again at
+        // 1M unknowns): a row's entries of all planes are merged in a short list (columns ascending, plane order kept among equal
+        // columns: the sums have the bits of csr_lincomb), the mirror entry a_ji is summed from the planes' rows j (sorted columns:
+        // binary search), rows are independent.  Same S, same |diagonal| as the two-step form below.
         const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(setup_threads(), n0 / 4096 + 1));
         std::vector<std::vector<int>> pcol(nparts);
         std::vector<std::vector<double>> pval(nparts);
         parallel_ranges(n0, nparts, [&](int64_t lo, int64_t hi, int part) {
             std::vector<int> &oc = pcol[part];
             std::vector<double> &ov = pval[part];
-            huge_reserve(oc, (size_t)(Aref.ptr[hi] - Aref.ptr[lo])); huge_reserve(ov, (size_t)(Aref.ptr[hi] - Aref.ptr[lo]));
+            {
+                size_t bound = 0;
+                for (const CsrZ &A : planes) bound += (size_t)(A.ptr[hi] - A.ptr[lo]);
+                huge_reserve(oc, bound); huge_reserve(ov, bound);
+            }
+            // (key = column * planes + plane: unique, so an in-place sort keeps the plane order among equal columns; std::stable_sort
+            // allocates a buffer per call -- a million calls)
+            std::vector<std::pair<int64_t, zc>> row;
+            const int64_t np = (int64_t)planes.size();
             for (int64_t i = lo; i < hi; ++i) {
+                row.clear();
+                for (size_t k = 0; k < planes.size(); ++k) {
+                    const CsrZ &A = planes[k];
+                    for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) row.emplace_back((int64_t)A.col[p] * np + (int64_t)k, pc_ref[k] * A.val[p]);
+                }
+                std::sort(row.begin(), row.end(), [](const std::pair<int64_t, zc> &x, const std::pair<int64_t, zc> &y) { return x.first < y.first; });
+                for (auto &e : row) e.first /= np;
                 int cnt = 0;
-                for (int p = Aref.ptr[i]; p < Aref.ptr[i + 1]; ++p) {
-                    const int j = Aref.col[p];
+                zc dg = 0;
+                for (size_t e = 0; e < row.size();) {
+                    zc aij = 0;
+                    size_t f = e;
+                    for (; f < row.size() && row[f].first == row[e].first; ++f) aij += row[f].second;
+                    const int j = (int)row[e].first;
+                    e = f;
                     bool keep = j == i;
-                    if (!keep) {
-                        const int *b = Aref.col.data() + Aref.ptr[j], *e = Aref.col.data() + Aref.ptr[j + 1];
-                        const int *f = std::lower_bound(b, e, (int)i);
-                        if (f != e && *f == (int)i) {
-                            const double aij = std::abs(Aref.val[p]);
-                            const double aji = std::abs(Aref.val[(size_t)(f - Aref.col.data())]);
-                            keep = aji >= 0.25 * aij && aij >= 0.25 * aji;
+                    if (keep) dg = aij;
+                    else {
+                        zc aji = 0;
+                        bool found = false;
+                        for (size_t k = 0; k < planes.size(); ++k) {
+                            const CsrZ &A = planes[k];
+                            const int *b = A.col.data() + A.ptr[j], *en = A.col.data() + A.ptr[j + 1];
+                            if (b == en) continue;
+                            const int *q = std::lower_bound(b, en, (int)i);
+                            if (q != en && *q == (int)i) { aji += pc_ref[k] * A.val[(size_t)(q - A.col.data())]; found = true; }
+                        }
+                        if (found) {
+                            const double x = std::abs(aij), y = std::abs(aji);
+                            keep = y >= 0.25 * x && x >= 0.25 * y;
                         }
                     }
-                    if (keep) { oc.push_back(j); ov.push_back(Aref.val[p].real()); ++cnt; }
+                    if (keep) { oc.push_back(j); ov.push_back(aij.real()); ++cnt; }
                 }
                 S.ptr[i + 1] = cnt;
+                dabs[i] = std::abs(dg);
             }
         });
         stitch(n0, nparts, S.ptr, pcol, pval, S.col, S.val);
-    }
-    std::vector<double> dabs(n0);
-    for (int64_t i = 0; i < n0; ++i) {
-        zc dg = 0;
-        for (int p = Afull.ptr[i]; p < Afull.ptr[i + 1]; ++p)
-            if (Afull.col[p] == i) dg = Afull.val[p];
-        dabs[i] = std::abs(dg);
+        lap("shape matrix (fused)");
+    } else {
+        const CsrZ Afull = csr_lincomb(planes, pc_ref);
+        lap("lincomb");
+        const CsrZ Ashape = pc_shape ? csr_lincomb(planes, *pc_shape) : CsrZ();
+        const CsrZ &Aref = pc_shape ? Ashape : Afull;          // the shape matrix comes from here, the penalty test from Afull
+        {
+            // (the mirror entry a_ji is looked up in row j -- columns are sorted -- instead of in a transposed copy: rows are
+            // independent, so the host threads divide them; same entries, same values as the transpose-based loop)
+            const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(setup_threads(), n0 / 4096 + 1));
+            std::vector<std::vector<int>> pcol(nparts);
+            std::vector<std::vector<double>> pval(nparts);
+            parallel_ranges(n0, nparts, [&](int64_t lo, int64_t hi, int part) {
+                std::vector<int> &oc = pcol[part];
+                std::vector<double> &ov = pval[part];
+                huge_reserve(oc, (size_t)(Aref.ptr[hi] - Aref.ptr[lo])); huge_reserve(ov, (size_t)(Aref.ptr[hi] - Aref.ptr[lo]));
+                for (int64_t i = lo; i < hi; ++i) {
+                    int cnt = 0;
+                    for (int p = Aref.ptr[i]; p < Aref.ptr[i + 1]; ++p) {
+                        const int j = Aref.col[p];
+                        bool keep = j == i;
+                        if (!keep) {
+                            const int *b = Aref.col.data() + Aref.ptr[j], *e = Aref.col.data() + Aref.ptr[j + 1];
+                            const int *f = std::lower_bound(b, e, (int)i);
+                            if (f != e && *f == (int)i) {
+                                const double aij = std::abs(Aref.val[p]);
+                                const double aji = std::abs(Aref.val[(size_t)(f - Aref.col.data())]);
+                                keep = aji >= 0.25 * aij && aij >= 0.25 * aji;
+                            }
+                        }
+                        if (keep) { oc.push_back(j); ov.push_back(Aref.val[p].real()); ++cnt; }
+                    }
+                    S.ptr[i + 1] = cnt;
+                }
+            });
+            stitch(n0, nparts, S.ptr, pcol, pval, S.col, S.val);
+        }
+        for (int64_t i = 0; i < n0; ++i) {
+            zc dg = 0;
+            for (int p = Afull.ptr[i]; p < Afull.ptr[i + 1]; ++p)
+                if (Afull.col[p] == i) dg = Afull.val[p];
+            dabs[i] = std::abs(dg);
+        }
     }
     std::vector<char> skip(n0, 0);
     if (n0 > 0) {
