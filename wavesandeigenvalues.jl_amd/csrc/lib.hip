@@ -2110,8 +2110,14 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
                 basis_job = std::async(std::launch::async, [h, need, need_q, need_w]() {
                     HIP_CHECK(hipSetDevice(h->device));
                     if (h->V.n != need) h->V.alloc(need);
-                    if (h->rbQ.n < need_q) h->rbQ.alloc(need_q);
-                    if (h->rb.W.n < need_w) h->rb.W.alloc(need_w);
+                    // (the snapshot stores are written once here as well: the first kernels that touch freshly mapped device memory
+                    // ran slower -- 0.14 s over the first pass's snapshot phase on some boxes; behind the host work it costs nothing)
+                    const bool new_q = h->rbQ.n < need_q, new_w = h->rb.W.n < need_w;
+                    if (new_q) h->rbQ.alloc(need_q);
+                    if (new_w) h->rb.W.alloc(need_w);
+                    if (new_q && need_q) HIP_CHECK(hipMemset(h->rbQ.p, 0, need_q * sizeof(cplx)));
+                    if (new_w && need_w) HIP_CHECK(hipMemset(h->rb.W.p, 0, need_w * sizeof(cplx)));
+                    HIP_CHECK(hipDeviceSynchronize());
                 });
         }
         struct Join { std::future<void> &f; ~Join() { if (f.valid()) f.wait(); } } basis_join{basis_job};     // (also on an exception)
