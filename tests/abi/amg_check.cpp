@@ -103,6 +103,16 @@ int main() {
             ++checks;
         }
         std::printf("hierarchy: %zu levels, first coarse size %lld\n", la.size(), (long long)la[0].P.m);
+        // the prolongator smoothing in one pass over the filtered matrix against its two-step form (sparse product, then assembly)
+        g_amg_fused_prolongator = 0;
+        std::vector<AmgLevel> lc;
+        amg_setup(planes, pc, opt, lc, nullptr, nullptr);
+        g_amg_fused_prolongator = 1;
+        if (lc.size() != la.size()) { std::printf("two-step prolongator: depth differs\n"); return 1; }
+        for (size_t l = 0; l < la.size(); ++l) {
+            if (!(la[l].P.ptr == lc[l].P.ptr && la[l].P.col == lc[l].P.col && la[l].P.val == lc[l].P.val)) { std::printf("level %zu: fused prolongator differs\n", l); return 1; }
+            ++checks;
+        }
     }
     std::printf("amg_check ok %d\n", checks);
     return 0;

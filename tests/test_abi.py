@@ -181,4 +181,4 @@ def test_fused_galerkin_product_is_bit_identical(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "amg_check ok 21" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and "amg_check ok 24" in r.stdout, r.stdout + r.stderr

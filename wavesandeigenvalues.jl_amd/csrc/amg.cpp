@@ -6,6 +6,8 @@
 
 #include "amg.h"
 #include "hugemem.h"
+
+int g_amg_fused_prolongator = 1;     // (test hook, amg.h)
 #include <chrono>
 #include <cstdlib>
 #include <functional>
@@ -537,13 +539,16 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
         stitch(n, nparts, F.ptr, pcol, pval, F.col, F.val);
     }
     plap("filtered matrix");
-    // F * P_tentative does not need the spectral radius: it runs on half of the host threads beside the power iteration
+    // two-step form (test hook g_amg_fused_prolongator = 0): F * P_tentative as a sparse product of its own, beside the power iteration
     CsrD FP;
     FP.n = n; FP.m = na;
-    const int th_half = std::max(1, setup_threads() / 2);
-    auto fp_job = std::async(std::launch::async, [&]() {
-        spgemm<double, double, double>(n, na, F.ptr, F.col, F.val, Pt.ptr, Pt.col, Pt.val, FP.ptr, FP.col, FP.val, th_half);
-    });
+    const bool fused = g_amg_fused_prolongator != 0;
+    const int th_half = fused ? setup_threads() : std::max(1, setup_threads() / 2);
+    std::future<void> fp_job;
+    if (!fused)
+        fp_job = std::async(std::launch::async, [&]() {
+            spgemm<double, double, double>(n, na, F.ptr, F.col, F.val, Pt.ptr, Pt.col, Pt.val, FP.ptr, FP.col, FP.val, th_half);
+        });
     // spectral radius of D^-1 F by power iteration
     std::vector<double> x(n), y(n);
     uint64_t lcg = 88172645463325252ull;
@@ -568,12 +573,54 @@ CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double thet
     const double omega = (4.0 / 3.0) / rho;
     // P = Pt - omega * D^-1 F Pt
     plap("spectral radius");
-    fp_job.get();
-    plap("F * P_tentative (wait)");
     CsrD P;
     P.n = n; P.m = na;
     P.ptr.assign(n + 1, 0);
-    {
+    if (fused) {
+        // One pass over the rows of F: P_tentative has one unit entry per row, so row i of F * P_tentative is the row of F summed by
+        // aggregate -- in the column order of F, as the sparse product would sum it (same bits) --, and the row of P follows at once.
+        const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(setup_threads(), n / 4096 + 1));
+        std::vector<std::vector<int>> pcol(nparts);
+        std::vector<std::vector<double>> pval(nparts);
+        parallel_ranges(n, nparts, [&](int64_t lo, int64_t hi, int part) {
+            std::vector<int> &oc = pcol[part];
+            std::vector<double> &ov = pval[part];
+            huge_reserve(oc, (size_t)(F.ptr[hi] - F.ptr[lo]) + (size_t)(hi - lo)); huge_reserve(ov, (size_t)(F.ptr[hi] - F.ptr[lo]) + (size_t)(hi - lo));
+            std::vector<std::pair<int, double>> row;
+            for (int64_t i = lo; i < hi; ++i) {
+                const size_t row0 = oc.size();
+                if (!skip[i]) {
+                    row.clear();
+                    for (int p = F.ptr[i]; p < F.ptr[i + 1]; ++p) {
+                        const int c = agg[F.col[p]];
+                        if (c < 0) continue;                         // (an empty row of P_tentative)
+                        size_t k = 0;
+                        while (k < row.size() && row[k].first != c) ++k;
+                        if (k == row.size()) row.emplace_back(c, 0.0);
+                        row[k].second += F.val[p] * 1.0;
+                    }
+                    std::sort(row.begin(), row.end(), [](const std::pair<int, double> &x, const std::pair<int, double> &y) { return x.first < y.first; });
+                    const int a = agg[i];
+                    bool seen = false;
+                    for (const auto &e : row) {
+                        double v = -omega * e.second / Fd[i];
+                        if (e.first == a) { v += 1.0; seen = true; }
+                        oc.push_back(e.first);
+                        ov.push_back(v);
+                    }
+                    if (!seen && a >= 0) {   // keep sorted order
+                        oc.push_back(a);
+                        ov.push_back(1.0);
+                        size_t q = oc.size() - 1;
+                        while (q > row0 && oc[q - 1] > oc[q]) { std::swap(oc[q - 1], oc[q]); std::swap(ov[q - 1], ov[q]); --q; }
+                    }
+                }
+                P.ptr[i + 1] = (int)(oc.size() - row0);
+            }
+        });
+        stitch(n, nparts, P.ptr, pcol, pval, P.col, P.val);
+    } else {
+        fp_job.get();
         const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>(setup_threads(), n / 4096 + 1));
         std::vector<std::vector<int>> pcol(nparts);
         std::vector<std::vector<double>> pval(nparts);

@@ -19,6 +19,9 @@ CsrD galerkin_real(const CsrD &R, const CsrD &A, const CsrD &P);
 CsrZ galerkin(const CsrD &R, const CsrZ &A, const CsrD &P, int nthreads);
 // R A0 P and R A1 P for two matrices of one pattern in one traversal; bit-identical to two galerkin() calls (tests/abi/amg_check.cpp)
 void galerkin_pair(const CsrD &R, const CsrZ &A0, const CsrZ &A1, const CsrD &P, CsrZ &C0, CsrZ &C1, int nthreads);
+// test hook: 0 selects the two-step form of the prolongator smoothing (F * P_tentative as a sparse product, then the assembly); the
+// default forms the rows of P in one pass over F -- the same bits (tests/abi/amg_check.cpp)
+extern int g_amg_fused_prolongator;
 CsrD build_prolongator(const CsrD &S, const std::vector<char> &skip, double theta, bool smooth, const std::vector<int> *visit = nullptr);
 // penalty_rows (optional): receives the fine-level flags of the rows detected as penalty (Dirichlet-like) rows
 // pc_shape (optional): plane coefficients of the operator the strength graph / aggregates / prolongator smoothing are taken
