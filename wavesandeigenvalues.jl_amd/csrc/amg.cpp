@@ -2,6 +2,7 @@
 // (Set-up runs once per family on the host cores; everything it produces lives in HBM afterwards.)
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <numeric>
 
 #include "amg.h"
@@ -689,32 +690,28 @@ void amg_setup(const std::vector<CsrZ> &planes, const std::vector<zc> &pc_ref, c
                 for (const CsrZ &A : planes) bound += (size_t)(A.ptr[hi] - A.ptr[lo]);
                 huge_reserve(oc, bound); huge_reserve(ov, bound);
             }
-            // (key = column * planes + plane: unique, so an in-place sort keeps the plane order among equal columns; std::stable_sort
-            // allocates a buffer per call -- a million calls)
-            std::vector<std::pair<int64_t, zc>> row;
-            const int64_t np = (int64_t)planes.size();
+            // (the planes' rows are sorted: a k-way merge walks them together -- smallest head column first, the planes that have it
+            // summed in plane order, as csr_lincomb sums them)
+            const size_t np = planes.size();
+            std::vector<int> head(np), tail(np);
             for (int64_t i = lo; i < hi; ++i) {
-                row.clear();
-                for (size_t k = 0; k < planes.size(); ++k) {
-                    const CsrZ &A = planes[k];
-                    for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) row.emplace_back((int64_t)A.col[p] * np + (int64_t)k, pc_ref[k] * A.val[p]);
-                }
-                std::sort(row.begin(), row.end(), [](const std::pair<int64_t, zc> &x, const std::pair<int64_t, zc> &y) { return x.first < y.first; });
-                for (auto &e : row) e.first /= np;
+                for (size_t k = 0; k < np; ++k) { head[k] = planes[k].ptr[i]; tail[k] = planes[k].ptr[i + 1]; }
                 int cnt = 0;
                 zc dg = 0;
-                for (size_t e = 0; e < row.size();) {
+                for (;;) {
+                    int j = INT32_MAX;
+                    for (size_t k = 0; k < np; ++k)
+                        if (head[k] < tail[k]) j = std::min(j, planes[k].col[head[k]]);
+                    if (j == INT32_MAX) break;
                     zc aij = 0;
-                    size_t f = e;
-                    for (; f < row.size() && row[f].first == row[e].first; ++f) aij += row[f].second;
-                    const int j = (int)row[e].first;
-                    e = f;
+                    for (size_t k = 0; k < np; ++k)
+                        if (head[k] < tail[k] && planes[k].col[head[k]] == j) { aij += pc_ref[k] * planes[k].val[head[k]]; ++head[k]; }
                     bool keep = j == i;
                     if (keep) dg = aij;
                     else {
                         zc aji = 0;
                         bool found = false;
-                        for (size_t k = 0; k < planes.size(); ++k) {
+                        for (size_t k = 0; k < np; ++k) {
                             const CsrZ &A = planes[k];
                             const int *b = A.col.data() + A.ptr[j], *en = A.col.data() + A.ptr[j + 1];
                             if (b == en) continue;
