@@ -1925,6 +1925,55 @@ static void axpy_impl(const cplx *V, size_t stride, int nv, const cplx *c, cplx 
 void launch_axpy_neg(const cplx *V, size_t stride, int nv, const cplx *h, cplx *W, int64_t n, int nb, hipStream_t st, const unsigned char *cmask) {
     axpy_impl(V, stride, nv, h, W, n, nb, -1.0, W, st, cmask);
 }
+// W_j -= sum_i h[i][j] V_i for CNT vectors W_j (stride wstride) in ONE reading of V_0..nv-1: the block Gram-Schmidt update of the
+// snapshot basis (lib.hip rb_append_block), whose four new vectors used to read the basis once each.  h[(i*CNT + j)*nb + b], the
+// layout dots_multi writes.
+template <int CNT>
+__global__ __launch_bounds__(256) void axpy_neg_multi_kernel(const cplx *__restrict__ V, size_t stride, int nv, const cplx *__restrict__ h, cplx *W,
+                                                             size_t wstride, int64_t n, int nb) {
+    extern __shared__ cplx hs[];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < nv * CNT * nb; k += 256) {
+        const cplx c = h[k];
+        hs[k] = cplx{-c.x, -c.y};
+    }
+    __syncthreads();
+    const int R = 256 / nb;
+    const int b = tid % nb, rl = tid / nb;
+    if (rl >= R) return;
+    for (int64_t row = (int64_t)blockIdx.x * R + rl; row < n; row += (int64_t)gridDim.x * R) {
+        const size_t e = (size_t)row * nb + b;
+        cplx acc[CNT];
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) acc[j] = W[(size_t)j * wstride + e];
+        for (int i = 0; i < nv; ++i) {
+            const cplx v = stream_load(V + (size_t)i * stride + e);
+#pragma unroll
+            for (int j = 0; j < CNT; ++j) {
+                const cplx c = hs[(i * CNT + j) * nb + b];
+                acc[j].x += c.x * v.x - c.y * v.y;
+                acc[j].y += c.x * v.y + c.y * v.x;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) W[(size_t)j * wstride + e] = acc[j];
+    }
+}
+void launch_axpy_neg_multi(const cplx *V, size_t stride, int nv, const cplx *h, cplx *W, size_t wstride, int cnt, int64_t n, int nb, hipStream_t st) {
+    if (!n || nb < 1 || nv < 1 || cnt < 1) return;
+    const size_t shm = (size_t)nv * cnt * nb * sizeof(cplx);
+    if (nb > 256 || cnt > 4 || shm > 60 * 1024) throw WaeError(WAE_ERR_INVALID, "axpy_neg_multi: coefficients do not fit one launch");
+    const int R = 256 / nb;
+    const int64_t steps = (n + R - 1) / R;
+    const unsigned grid = (unsigned)std::min<int64_t>(steps, 2048);
+    switch (cnt) {
+    case 1: hipLaunchKernelGGL(axpy_neg_multi_kernel<1>, dim3(grid), dim3(256), shm, st, V, stride, nv, h, W, wstride, n, nb); break;
+    case 2: hipLaunchKernelGGL(axpy_neg_multi_kernel<2>, dim3(grid), dim3(256), shm, st, V, stride, nv, h, W, wstride, n, nb); break;
+    case 3: hipLaunchKernelGGL(axpy_neg_multi_kernel<3>, dim3(grid), dim3(256), shm, st, V, stride, nv, h, W, wstride, n, nb); break;
+    default: hipLaunchKernelGGL(axpy_neg_multi_kernel<4>, dim3(grid), dim3(256), shm, st, V, stride, nv, h, W, wstride, n, nb); break;
+    }
+    HIP_CHECK(hipGetLastError());
+}
 // w -= V h and norms[b] = ||w[:,b]|| in one pass over w (falls back to two kernels when the coefficients do not fit one launch)
 // base (optional): W = base - V h instead of the in-place update; inv_out (optional): 1/||W[:,b]||^2 beside the norms.  Both are
 // what a Krylov basis kept UNNORMALISED needs (lib.hip gmres): the new vector goes straight into its basis slot.

@@ -1655,8 +1655,16 @@ static void rb_append_block(wae_family *h, int cnt, const std::vector<std::vecto
     for (int j = 0; j < cnt; ++j) launch_norms(qn + (size_t)j * vecl, d, l, h->partial.p, R.hb.p + (size_t)j * l, st);
     rb_d2h(h, R.hb.p, n0.data(), (size_t)cnt * l);
     // (1) against the existing basis: block classical Gram-Schmidt, two passes
+    // (the update of all new vectors in one reading of the basis, with the coefficients where dots_multi left them: no round trip
+    // through the host; the basis used to be read once per new vector and pass -- 96 ms of a 1M-DoF pass)
+    static const bool multi_axpy = !(getenv("WAE_RB_MULTI_AXPY") && atoi(getenv("WAE_RB_MULTI_AXPY")) == 0);
+    const bool fits = (size_t)S * cnt * l * sizeof(cplx) <= 60 * 1024;
     for (int pass = 0; pass < 2 && S > 0; ++pass) {
         launch_dots_multi(R.Q, vecl, S, qn, vecl, cnt, d, l, h->partial.p, R.hb.p, st);       // hb[(i*cnt + j)*l + c]
+        if (multi_axpy && fits) {
+            launch_axpy_neg_multi(R.Q, vecl, S, R.hb.p, qn, vecl, cnt, d, l, st);
+            continue;
+        }
         rb_d2h(h, R.hb.p, hh.data(), (size_t)S * cnt * l);
         std::vector<cplx> cj((size_t)S * l);
         for (int j = 0; j < cnt; ++j) {
@@ -1706,7 +1714,27 @@ static void rb_append_block(wae_family *h, int cnt, const std::vector<std::vecto
                     const cplx v = hh[((size_t)i * cnt + j) * l + c];
                     H[((size_t)(S + j) * cap + i) * l + c] = zc(v.x, v.y);
                 }
-        if (S > 0) {
+        // new rows (old columns).  A term A_k = s B with B real and symmetric (K, M of a Helmholtz family) projects to s x (a Hermitian
+        // matrix): the new rows follow from the new columns, H[S+j, i] = (s / conj s) conj(H[i, S+j]), without reading A_k Q again.
+        zc herm_factor(0);
+        bool herm = false;
+        {
+            static const bool herm_on = !(getenv("WAE_RB_HERMITIAN") && atoi(getenv("WAE_RB_HERMITIAN")) == 0);
+            const int kterm = R.kact[ki], pl = h->term_plane[kterm];
+            const LevelOp &L0 = h->ops[0];
+            for (size_t g = 0; g < L0.groups.size() && herm_on && !herm; ++g)
+                for (int q = 0; q < L0.groups[g].nplanes; ++q)
+                    if (h->slot_plane[0][(size_t)L0.groups[g].plane0 + q] == pl && L0.groups[g].symmetric && L0.groups[g].is_real) {
+                        const zc sc = h->term_scale[kterm];
+                        if (sc != zc(0)) { herm = true; herm_factor = sc / std::conj(sc); }
+                    }
+        }
+        if (S > 0 && herm) {
+            for (int i = 0; i < S; ++i)
+                for (int j = 0; j < cnt; ++j)
+                    for (int c = 0; c < l; ++c)
+                        H[((size_t)i * cap + S + j) * l + c] = herm_factor * std::conj(H[((size_t)(S + j) * cap + i) * l + c]);
+        } else if (S > 0) {
             launch_dots_multi(Wk, vecl, S, qn, vecl, cnt, d, l, h->partial.p, R.hb.p, st);     // (A_k q_i)^H q_{S+j} = conj(row S+j), i < S
             rb_d2h(h, R.hb.p, hh.data(), (size_t)S * cnt * l);
             for (int i = 0; i < S; ++i)

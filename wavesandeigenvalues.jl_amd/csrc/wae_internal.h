@@ -241,6 +241,8 @@ void launch_copy(const cplx *X, cplx *Y, size_t count, hipStream_t s);
 void launch_dots(const cplx *V, size_t stride, int nv, const cplx *W, int64_t n, int nb, cplx *partial, cplx *out, hipStream_t s,
                  const unsigned char *cmask = nullptr);
 // W -= sum_i h[i][b] V_i
+// W_j -= sum_i h[(i*cnt + j)*nb + b] V_i, j < cnt <= 4, one reading of the nv vectors (snapshot basis: block Gram-Schmidt update)
+void launch_axpy_neg_multi(const cplx *V, size_t stride, int nv, const cplx *h, cplx *W, size_t wstride, int cnt, int64_t n, int nb, hipStream_t s);
 void launch_axpy_neg(const cplx *V, size_t stride, int nv, const cplx *h, cplx *W, int64_t n, int nb, hipStream_t s,
                      const unsigned char *cmask = nullptr);
 // Y = sum_i y[i][b] V_i
