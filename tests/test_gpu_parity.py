@@ -1079,3 +1079,38 @@ def test_pair_steps_of_the_narrow_recurrence():
         assert out[pair]["checks"] >= 20 and out[pair]["max_steps"] >= 20
     w1, w0 = complex(*out["1"]["eig"]), complex(*out["0"]["eig"])
     assert abs(w1 - w0) <= 1e-8 * abs(w0), (w1, w0)
+
+
+def test_snapshot_basis_shortcuts_change_nothing_but_the_bytes():
+    """The snapshot basis of the projected contour integral (wae_beyn_moments_rb) is extended with a block Gram-Schmidt update that
+    reads the basis once for all new vectors, and the projected real symmetric terms take their new rows from their new columns
+    (csrc/lib.hip rb_append_block).  Both off (WAE_RB_MULTI_AXPY=0, WAE_RB_HERMITIAN=0; read once per process, hence the child
+    processes) must give the same moments and -- the basis only provides initial guesses -- the same iteration counts to 1 %."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import json, numpy as np
+from wae_amd.helmholtz.family import annulus_family
+from wae_amd.nlevp import compute_moment_matrices
+L, pb = annulus_family("small", tau=2e-4)
+L.solver_tol = 1e-11; L.solver_ref = 2 * np.pi * 500.0
+fam = L.ensure_solver()
+G = np.array([150 - 150j, 1000 - 150j, 1000 + 150j, 150 + 150j]) * 2 * np.pi
+V = np.asfortranarray(np.random.default_rng(3).standard_normal((pb["d"], 8)) + 0j)
+A = compute_moment_matrices(L, G, V, K=1, N=16, rb=24)
+i = fam.last_info
+print(json.dumps({"its": i["iters_total"], "unconv": i["n_unconverged"], "snap": i.get("snapshots"),
+                  "sum": [float(np.abs(A[0]).sum()), float(np.abs(A[1][::5]).sum())]}))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for name, extra in (("default", {}), ("plain", {"WAE_RB_MULTI_AXPY": "0", "WAE_RB_HERMITIAN": "0"})):
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), **extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[name] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["default"]["unconv"] == 0 and out["plain"]["unconv"] == 0 and out["default"]["snap"] == 24
+    assert abs(out["default"]["its"] - out["plain"]["its"]) <= 0.01 * out["plain"]["its"] + 2
+    assert np.allclose(out["default"]["sum"], out["plain"]["sum"], rtol=1e-8)
