@@ -44,13 +44,15 @@ CsrD csr_transpose(const CsrD &A) {
 }
 bool csr_same_pattern(const CsrZ &A, const CsrZ &B) { return A.n == B.n && A.m == B.m && A.ptr == B.ptr && A.col == B.col; }
 
-// Host threads for the set-up (the set-up is part of the metric: one cold solver call = set-up + pass).  The row loops below are
+// Host threads for the set-up (the set-up is part of the metric: one cold solver call = set-up + pass).  32 by default: the phases
+// are bound by memory stalls and page faults, not by arithmetic, and on a 16-CPU share 24..64 threads all finish the 1M-DoF set-up
+// in 0.93-1.05 s where 16 take 1.22-1.31 and 8 take 1.5-1.9 (the kernel's CPU quota does the limiting).  The row loops below are
 // cut into contiguous chunks, one per thread, each with its own marker / accumulator and output vectors, stitched afterwards:
 // the result is the serial one bit for bit (per row the same operations in the same order).
 static int setup_threads() {
     static const int n = []() {
         if (const char *e = getenv("WAE_SETUP_THREADS")) return std::max(1, atoi(e));
-        return (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        return (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     }();
     return n;
 }

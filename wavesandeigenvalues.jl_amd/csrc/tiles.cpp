@@ -250,7 +250,7 @@ TilePlan plan_tiles(const Pattern &U, int tile_rows, int wcap, int thick) {
 static int tile_threads() {
     static const int n = []() {
         if (const char *e = getenv("WAE_SETUP_THREADS")) return std::max(1, atoi(e));
-        return (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        return (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     }();
     return n;
 }
