@@ -10,9 +10,9 @@ if [ "$WHAT" = spmv ]; then
     timeout -k 10 330 dev/collect_spmv_profile.sh C3 ${TAG}_C3 > $OUT/spmv_C3.log 2>&1
     timeout -k 10 170 dev/collect_spmv_profile.sh C2 ${TAG}_C2 > $OUT/spmv_C2.log 2>&1
 else
-    # (C2 first: the first process on a freshly restored box pays the host's page faults for every page of guest memory it is the
-    # first to touch -- a C3 bench run as the first process shows a 2.3-2.5-s set-up and a first pass 0.2 s slower than a steady one,
-    # every later process 0.95-1.05 s and +0.02 s; the first-process figures are kept in bench_first_process.json)
+    # (the first process on a freshly restored box pays the host's page faults for every page of guest memory it is the first to
+    # touch; bench.py prefaults 12 GB before the solver's clock for that reason.  The first-process figures are kept in
+    # bench_first_process.json, the C3 bench proper runs third)
     timeout -k 10 300 python bench.py --steps 1 --warmup 1 --no-newton --no-cpu-baseline > $OUT/bench_first.log 2> $OUT/bench_first.err
     grep "^{" $OUT/bench_first.log > $OUT/bench_first_process.json
     timeout -k 10 300 python bench.py --preset C2 --N 32 --l 16 > $OUT/bench_C2.log 2> $OUT/bench_C2.err
