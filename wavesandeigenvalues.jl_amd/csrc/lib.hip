@@ -974,6 +974,13 @@ static int gmres_wide(wae_family *h, const Batch &bt, const cplx *B, cplx *X, do
         for (int b = 0; b < nb; ++b) itot += iters[b];
         fprintf(stderr, "[gmres] nb=%d x0=%d lockstep_its=%d column_its=%d %.1f ms (device recurrence)\n", nb, (int)have_x0, total_it, itot,
                 (now_s() - t_dbg0) * 1e3);
+        if (atoi(getenv("WAE_GMRES_DEBUG")) > 2) {                 // per-column step counts, one system per line
+            for (int b0 = 0; b0 < nb; b0 += bt.cps) {
+                fprintf(stderr, "[gmres]   steps");
+                for (int b = b0; b < std::min(nb, b0 + bt.cps); ++b) fprintf(stderr, " %d", iters[b]);
+                fprintf(stderr, "\n");
+            }
+        }
     }
     if (info) {
         int imax = 0, itot = 0, nun = 0;
