@@ -87,6 +87,29 @@ def cpu_baseline(l, N, n_in, d_bench, tau, n_flame, budget_s=30.0):
                                    f"gives {rows[-1]['seconds_per_point'] * (measured['d'] / rows[-1]['d']) ** p:.0f} s there)." if measured else ".")}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run as a CHILD process
+    (this process never imports torch nor touches a GPU), pass its output through and return its exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["WAE_BENCH_SELF_LAUNCHED"] = "1"
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:                       # rank 0's JSON line (and anything else the ranks print), as it comes
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,10 +134,31 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-newton", action="store_true", help="skip the Newton-type refinement figures")
     ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of host time the CPU baseline may spend")
+    ap.add_argument("--mgpu", action="store_true",
+                    help="drive the N GPUs from ONE process through wae_beyn_moments_mgpu (the path a Julia host takes: one family handle "
+                         "per device, a host thread + stream per device inside the library, RCCL by dlopen) instead of one rank per GPU")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="rendezvous only (no GPU needed): every rank joins the process group, one all-reduce, rank 0 prints a JSON line "
+                         "with the rank count -- what tests/ uses to check on a CPU that --gpus N really starts N ranks")
     args = ap.parse_args()
     if args.rb < 0:
         npts = 4 * args.N
         args.rb = min(40, npts // 2)      # nlevp/beyn.py compute_moment_matrices, automatic rule
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    # --gpus N means N ranks.  Started plainly (no WORLD_SIZE in the environment) this process only LAUNCHES them -- as a child
+    # process, before torch is imported or the GPU touched -- relays rank 0's JSON line and leaves with the child's exit code.
+    # Started by torch.distributed.run (the driver's way) the environment must agree with --gpus.
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.mgpu:
+        if env_world not in (None, "1"):
+            sys.exit(f"bench.py --mgpu is a single-process mode; WORLD_SIZE={env_world} is set")
+    elif env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    elif int(env_world or "1") != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: start it as `python bench.py --gpus N` (it launches its "
+                 f"own ranks) or under torch.distributed.run with --nproc-per-node equal to --gpus")
 
     import torch
     import torch.distributed as dist
@@ -122,7 +166,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = args.gpus if args.mgpu else 1          # devices driven by THIS process (--mgpu: all of them, one rank)
+    if args.rehearse:
+        tot = torch.ones(1, dtype=torch.float64)
+        if world > 1:
+            dist.init_process_group(os.environ.get("WAE_BENCH_BACKEND", "gloo"))
+            dist.all_reduce(tot)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"rehearsal": True, "n_gpus": world, "ranks_counted": int(tot.item()), "gpus_requested": args.gpus,
+                              "launched_by": "bench.py" if os.environ.get("WAE_BENCH_SELF_LAUNCHED") else "external launcher"}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    if args.mgpu and ndev > torch.cuda.device_count() and os.environ.get("WAE_MGPU_EXCHANGE") != "copy":
+        sys.exit(f"bench.py --mgpu --gpus {ndev}: only {torch.cuda.device_count()} device(s) visible (several handles on one device "
+                 f"are a rehearsal that needs WAE_MGPU_EXCHANGE=copy)")
     backend = os.environ.get("WAE_BENCH_BACKEND", "nccl")      # "gloo" only to rehearse N>1 on a one-GPU box
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
@@ -146,13 +206,21 @@ def main():
     L.solver_tol = args.tol
     L.solver_maxit = 400
     L.solver_ref = 2 * np.pi * float(os.environ.get("WAE_REF_HZ", "500"))
+    nshare = ndev if args.mgpu else world          # how many devices share the contour
     L.solver_opts = {"batch": args.batch, "restart": args.restart, "sweeps": args.sweeps, "jacobi_weight": args.jacw,
                      # workspace hints: the snapshot store of the passes to come is mapped during the set-up
-                     "probe_columns": args.l // world if (world > 1 and args.l % world == 0) else args.l, "snapshots": args.rb}
+                     "probe_columns": args.l // nshare if (nshare > 1 and args.l % nshare == 0) else args.l, "snapshots": args.rb}
+    Ls = [L]                                       # --mgpu: one replica of the family per device, all driven from here
+    for g in range(1, ndev):
+        Lg = L.copy()
+        Lg.device_id = g % torch.cuda.device_count()
+        Ls.append(Lg)
+    from concurrent.futures import ThreadPoolExecutor
     from wae_amd.nlevp.distributed import warm_up_dense_linalg
     warm_up_dense_linalg(torch.device("cuda", local), cols=args.l, K=args.K)     # (process-level library handles: not part of a solver call)
     t0 = time.time()
-    L.device()                                   # wae_family_create: conversion + upload of the term matrices
+    with ThreadPoolExecutor(ndev) as ex:           # wae_family_create: conversion + upload of the term matrices (the library
+        list(ex.map(lambda Lg: Lg.device(), Ls))   # releases the GIL: one host thread per device)
     torch.cuda.synchronize()
     t_upload = time.time() - t0
     # The benchmark boxes are restored micro-VMs: the first process to touch a page of guest memory pays the HOST's fault for it, and
@@ -167,7 +235,11 @@ def main():
         del blk
     t_prefault = time.time() - t0
     t0 = time.time()
-    fam = L.ensure_solver()                      # wae_solver_setup: multigrid hierarchy (part of the metric's "everything else")
+    with ThreadPoolExecutor(ndev) as ex:           # wae_solver_setup: multigrid hierarchy (part of the metric's "everything else")
+        fams = list(ex.map(lambda Lg: Lg.ensure_solver(), Ls))
+    fam = fams[0]
+    for g in range(torch.cuda.device_count() if args.mgpu else 0):
+        torch.cuda.synchronize(g)
     torch.cuda.synchronize()
     t_setup = time.time() - t0
 
@@ -186,7 +258,18 @@ def main():
     def step():
         nonlocal buf
         t = [time.time()]
-        if args.rb > 0:
+        if args.mgpu:
+            # ONE library call drives every device (wae_beyn_moments_mgpu): snapshot phase by probe column or by point, RCCL all-gather
+            # of the bases, projected phase round-robin, RCCL reduce to device 0, moments to the host array the ABI returns them in;
+            # the tail below wants them in HBM again (a Julia host would run its own dense tail on that array).
+            from wae_amd.nlevp.distributed import beyn_moments_mgpu
+            A, info = beyn_moments_mgpu(Ls, G, V, K=K, N=args.N, nsnap=args.rb, zmap=zmap)
+            t.append(time.time())
+            buf.copy_(torch.from_numpy(A.ravel(order="K").view(np.float64)))
+            torch.cuda.synchronize()
+            t.append(time.time())
+            info = dict(info)
+        elif args.rb > 0:
             # snapshot points -> all-gather of the snapshot store -> projected initial guesses -> all-reduce of the moments
             ph = {}
             buf, info = beyn_moments_distributed_rb(L, G, V, K, args.N, args.rb, timings=ph, zmap=zmap)
@@ -221,6 +304,8 @@ def main():
             res = (Om, r, S, Pd, mask)
             for name, a, b in (("moments", 0, 1), ("allreduce", 1, 2), ("d2h", 2, 3), ("svd_eig", 3, 4), ("residuals", 4, 5)):
                 tim[name] = t[b] - t[a]
+            if args.mgpu:
+                tim["moments_h2d_for_tail"] = tim.pop("allreduce")      # (the ABI returned them on the host)
         return info, res
 
     def sync():
@@ -304,13 +389,19 @@ def main():
             roof["level1"] = {"error": str(e)}
         out = {
             "metric": "eigenpairs/sec", "value": n_eig * args.steps / dt, "unit": "eigenpairs/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world * ndev, "rccl_ranks": (dist.get_world_size() if world > 1 else 1) if not args.mgpu else ndev,
+            "launch": ("one process, wae_beyn_moments_mgpu over %d device handle(s)" % ndev) if args.mgpu else
+                      ("%d rank(s), one process per GPU (torch.distributed, backend %s)" % (world, backend)),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"annular combustor Helmholtz NLEVP (P1), preset {args.preset}: d={d}, "
                                    f"L(w)=w^2 M+K+w Y C+n exp(-i w tau) Q, Beyn l={args.l} K={K} N={args.N}/edge "
                                    f"({4 * args.N} shifted systems x {args.l} columns), contour 150..1000 Hz x +-150 Hz, inner tol {args.tol:g}",
-                       "parallelism": ((f"{args.rb} snapshot points solved first, split by probe column over {world} GPU(s) "
+                       "parallelism": ("single host process: wae_beyn_moments_mgpu, a host thread + stream per device, %d device(s); "
+                                       "snapshot phase by probe column (by point when l is not divisible), bases all-gathered, projected "
+                                       "points round-robin, moments reduced to device 0 and returned in host memory" % ndev) if args.mgpu else
+                                      ((f"{args.rb} snapshot points solved first, split by probe column over {world} GPU(s) "
                                         f"({args.l // world} columns each), their solutions all-gathered; " if args.l % world == 0 else
                                         f"{args.rb} snapshot points solved first, round-robin over {world} GPU(s), their solutions all-gathered; ")
                                        + f"the other {4 * args.N - args.rb} points round-robin over the GPUs, starting from the projection on "

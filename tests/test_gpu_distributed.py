@@ -135,3 +135,38 @@ def test_single_process_mgpu_entry_with_several_virtual_ranks(monkeypatch, l, ns
         beyn_moments_mgpu([fams[0], fams[0]], GAMMA, V, K=1, N=16, nsnap=nsnap)
     for L in fams:
         L._drop_device()
+
+
+def _bench(args, **envkw):
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", WAE_BENCH_PREFAULT_GB="0", **envkw)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args + ["--preset", "small", "--N", "16", "--l", "4", "--K", "1", "--steps", "1",
+                        "--warmup", "1", "--tol", "1e-11", "--no-newton", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_launches_two_ranks_and_matches_one_rank():
+    """`python bench.py --gpus 2` (no launcher): two ranks over gloo on this box's one GPU -- the N > 1 path of the scaling bench,
+    entered the way a driver that only knows `--gpus N` enters it.  Same eigenvalues as the one-rank run."""
+    one = _bench(["--gpus", "1"])
+    two = _bench(["--gpus", "2"], WAE_BENCH_BACKEND="gloo")
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["rccl_ranks"] == 2
+    assert two["roofline"]["frac"] > 0 and two["solver"]["n_unconverged"] == 0
+    assert one["eigenpairs"] == two["eigenpairs"] > 0
+    a, b = np.array(one["eigenvalues_hz"]), np.array(two["eigenvalues_hz"])
+    assert np.max(np.abs(a - b)) <= 1e-6 * np.max(np.abs(a))
+
+
+def test_bench_mgpu_mode_drives_two_handles_from_one_process():
+    """`bench.py --mgpu --gpus 2`: the single-process entry a Julia host uses (wae_beyn_moments_mgpu), two handles on this one
+    device as virtual ranks (WAE_MGPU_EXCHANGE=copy)."""
+    one = _bench(["--gpus", "1"])
+    two = _bench(["--gpus", "2", "--mgpu"], WAE_MGPU_EXCHANGE="copy")
+    assert two["n_gpus"] == 2 and "wae_beyn_moments_mgpu" in two["launch"]
+    assert one["eigenpairs"] == two["eigenpairs"] > 0
+    a, b = np.array(one["eigenvalues_hz"]), np.array(two["eigenvalues_hz"])
+    assert np.max(np.abs(a - b)) <= 1e-6 * np.max(np.abs(a))

@@ -452,11 +452,12 @@ def bloch_sweep_distributed(L, bs, starts, method=None, b_symbol="b", **kw):
     return sweep_distributed(list(bs), unit, 3 * nstart)
 
 
-def beyn_moments_mgpu(families, G, V, K=1, N=16, nsnap=None, points=None):
+def beyn_moments_mgpu(families, G, V, K=1, N=16, nsnap=None, points=None, zmap=None):
     """The single-process multi-GPU entry of the C ABI (``wae_beyn_moments_mgpu``; what a Julia host calls): ``families`` is a
     list of LinearOperatorFamily replicas, one per GPU (``device=g``), all with the same terms and parameters.  Returns the
     moment tensor d x l x 2K (numpy) and the merged solve statistics.  nsnap=None: the automatic rule of
-    compute_moment_matrices (40 snapshot points for contours of >= 64 points, d >= 1000)."""
+    compute_moment_matrices (40 snapshot points for contours of >= 64 points, d >= 1000).  zmap = (c, rho): moments in the
+    variable (z - c)/rho, as in beyn_moments_distributed_rb (the systems are those of the true z)."""
     import ctypes as C
 
     from .. import _lib
@@ -468,6 +469,8 @@ def beyn_moments_mgpu(families, G, V, K=1, N=16, nsnap=None, points=None):
     fams = [L.ensure_solver() for L in families]
     d = L0.size()
     ct = np.ascontiguousarray(coefficient_table(L0, zs), dtype=np.complex128) if len(zs) else np.zeros((0, len(L0.terms)), dtype=np.complex128)
+    if zmap is not None:
+        zs = np.ascontiguousarray((zs - complex(zmap[0])) / complex(zmap[1]))
     Vf = np.asfortranarray(np.asarray(V, dtype=np.complex128))
     l = Vf.shape[1]
     if nsnap is None:
