@@ -73,7 +73,8 @@ int64_t wae_family_spmv_bytes(const wae_family *h, const uint8_t *mask, int32_t 
  * mat-vec (iterative_solvers.jl:307,399,571-572,581; perturbation.jl:339,352,413; Householder.jl:189-190).
  *   coeffs  T complex scalars c_k = prod_j f_kj(params; derivs) evaluated on the host (LinOpFam.jl:466-477);
  *           a term skipped by the functor (LinOpFam.jl:502-516) is passed as 0.
- *   X, Y    d x r column-major complex, host memory.
+ *   X, Y    d x r column-major complex, host memory.  r = 0 is a no-op (`L(z)*zeros(d,0)`), and so are wae_solve /
+ *           wae_solve_guess with r = 0 and wae_eig_residuals with n = 0: WAE_OK, nothing is read or written.
  */
 int wae_spmv_sum(wae_family *h, const double *coeffs, const double *X, double *Y, int32_t r, int32_t op);
 /* one coefficient set per column (ncoef = r): Y[:,j] = sum_k c_jk op(A_k) X[:,j] -- e.g. the residuals L(w_j) v_j of

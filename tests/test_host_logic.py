@@ -171,3 +171,13 @@ def test_conjugate_span_start_of_the_left_processes():
     # numerically dependent start vectors: falls back to the plain conjugates
     Vd = np.stack([spin_p, spin_p * (1 + 1e-13)], axis=1)
     assert np.allclose(_conjugate_span_start(Vd), np.conj(Vd))
+
+
+def test_householder_many_of_an_empty_start_list_is_an_empty_list():
+    """the batched refinement with nothing to refine (a Beyn pass that found no eigenvalue inside): no device, no library call"""
+    from wae_amd.nlevp import householder_many
+    L = helmholtz_family(F.rijke_terms(), n=0.5)
+    stats = {}
+    assert householder_many(L, [], stats=stats) == []
+    assert stats["newton_rounds"] == 0 and stats["inner_column_iterations"] == 0
+    assert L._fam is None                                    # the family was not even uploaded

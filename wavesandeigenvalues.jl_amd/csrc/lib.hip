@@ -1946,9 +1946,10 @@ static void ensure(DevBuf<cplx> &b, size_t n) { if (b.n < n) b.alloc(n); }
 
 int wae_spmv_sum_cols(wae_family *h, const double *coeffs, int32_t ncoef, const double *X, double *Y, int32_t r, int32_t op) {
     return guarded([&]() {
-        WAE_REQUIRE(h && coeffs && X && Y && r > 0, "bad argument");
-        WAE_REQUIRE(ncoef == 1 || ncoef == r, "ncoef must be 1 or r");
+        WAE_REQUIRE(h && r >= 0 && (r == 0 || (coeffs && X && Y)), "bad argument");
         WAE_REQUIRE(op >= 0 && op <= 2, "bad op");
+        if (r == 0) return WAE_OK;                                // L(z) * zeros(d, 0): nothing to do (LinOpFam.jl:482-529 returns d x 0)
+        WAE_REQUIRE(ncoef == 1 || ncoef == r, "ncoef must be 1 or r");
         HIP_CHECK(hipSetDevice(h->device));
         hipStream_t st = h->stream;
         const size_t cnt = (size_t)h->d * r;
@@ -1991,7 +1992,8 @@ int wae_eig_residuals(wae_family *h, int32_t n, const double *coeff_table, const
         return WAE_OK;
     }
     return guarded([&]() {
-        WAE_REQUIRE(h && n > 0 && coeff_table && (P || P_dev) && res_out, "bad argument");
+        WAE_REQUIRE(h && n >= 0 && (n == 0 || (coeff_table && (P || P_dev) && res_out)), "bad argument");
+        if (n == 0) return WAE_OK;                                // no pairs: nothing to test
         HIP_CHECK(hipSetDevice(h->device));
         hipStream_t st = h->stream;
         const int T = h->T;
@@ -2424,9 +2426,13 @@ static int solve_chunk(wae_family *h, const Batch &bt, const std::vector<std::ve
 int wae_solve_guess(wae_family *h, const double *coeffs, int32_t ncoef, const double *B, const double *Gd, double *X, int32_t r, int32_t op,
                     double tol, int32_t maxit, wae_solve_info *info) {
     return guarded([&]() {
-        WAE_REQUIRE(h && coeffs && B && X && r > 0, "bad argument");
-        WAE_REQUIRE(ncoef == 1 || ncoef == r, "ncoef must be 1 or r");
+        WAE_REQUIRE(h && r >= 0 && (r == 0 || (coeffs && B && X)), "bad argument");
         WAE_REQUIRE(op >= 0 && op <= 2, "bad op");
+        if (r == 0) {                                             // L(z) \ zeros(d, 0)
+            if (info) std::memset(info, 0, sizeof(*info));
+            return WAE_OK;
+        }
+        WAE_REQUIRE(ncoef == 1 || ncoef == r, "ncoef must be 1 or r");
         require_solver(h);
         HIP_CHECK(hipSetDevice(h->device));
         hipStream_t st = h->stream;

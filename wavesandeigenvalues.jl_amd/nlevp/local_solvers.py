@@ -542,6 +542,10 @@ def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, orde
            "inner_column_iterations": 0}
     zs = [complex(z) for z in zs]
     ns = len(zs)
+    if ns == 0:                                           # an empty batch of start values: nothing to refine
+        if stats is not None:
+            stats.update(st_)
+        return []
     d = L.size()
     fam = L.ensure_solver()
     active, mode = L.active, L.mode
