@@ -100,8 +100,15 @@ def launch_ranks(n):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["WAE_BENCH_SELF_LAUNCHED"] = "1"
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    # (torch.distributed.run's argparse resolves abbreviations over the WHOLE command line: a script option that is a prefix of one of
+    # its own -- --l of --log-dir, --n of --nnodes -- is refused as ambiguous even behind the script name: pass the long spellings)
+    long_names = {"--l": "--probe-columns", "--n": "--flame-n"}
+    argv = []
+    for a in sys.argv[1:]:
+        head, eq, tail = a.partition("=")
+        argv.append(long_names.get(head, head) + eq + tail)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
     print(f"bench.py: launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     for line in proc.stdout:                       # rank 0's JSON line (and anything else the ranks print), as it comes
@@ -116,7 +123,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--preset", default="C3")
-    ap.add_argument("--l", type=int, default=8)
+    ap.add_argument("--l", "--probe-columns", dest="l", type=int, default=8)
     ap.add_argument("--N", type=int, default=64)
     ap.add_argument("--K", type=int, default=2,
                     help="moments 0..2K-1 (beyn.jl:50-52).  K = 2 makes the Hankel matrix l*K = 16 columns wide from the same 2 048 solves: "
@@ -126,7 +133,7 @@ def main():
     ap.add_argument("--restart", type=int, default=40)
     ap.add_argument("--sweeps", type=int, default=1)
     ap.add_argument("--jacw", type=float, default=0.8, help="Jacobi weight of the V-cycle's smoother")
-    ap.add_argument("--n", type=float, default=1.0)
+    ap.add_argument("--n", "--flame-n", dest="n", type=float, default=1.0)
     ap.add_argument("--tau", type=float, default=2e-4)
     ap.add_argument("--rb", type=int, default=-1,
                     help="snapshot points for projected initial guesses (wae_beyn_moments_rb); -1 = the package's automatic "

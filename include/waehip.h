@@ -62,6 +62,19 @@ const char *wae_version(void);
 int wae_family_create(wae_family **out, int64_t d, int32_t T, int32_t index_bytes, int32_t base,
                       int32_t orientation, const void *const *ptr, const void *const *idx,
                       const double *const *val, int32_t device);
+/* wae_family_create with options (opts may be NULL / nopts 0 = wae_family_create):
+ *   opts[0]  symmetry tolerance of the TRANSPOSED products, default 0.  A term matrix whose transpose equals itself is stored
+ *            once and applied as it is for op = T / C (`A'*y`, `A'\\b`: Householder.jl:101, iterative_solvers.jl:398,572); with 0
+ *            that requires mirror entries that are equal bit for bit, so `A'` is exactly `A'`.  A finite-element matrix
+ *            (`discretize`: M, K, C of src/Helmholtz.jl:405-463) is symmetric by construction but, assembled in floating point,
+ *            only up to the order of its element sums; opts[0] = t > 0 accepts  |a_ij - a_ji| <= t * min(s_i, s_j),
+ *            s_i = largest off-diagonal magnitude of row i (a penalty or Dirichlet diagonal entry does not widen the test),
+ *            and the adjoint products of such a family then run on the same fast path as the forward ones -- differing from the
+ *            exact transposed product by that assembly rounding (<= t per entry, relative to the row scale).  The Helmholtz
+ *            wrappers pass 1e-14; must lie in [0, 1e-8]. */
+int wae_family_create_opts(wae_family **out, int64_t d, int32_t T, int32_t index_bytes, int32_t base,
+                           int32_t orientation, const void *const *ptr, const void *const *idx,
+                           const double *const *val, int32_t device, const double *opts, int32_t nopts);
 int wae_family_destroy(wae_family *h);
 /* d, T, total nnz, and the algorithmic byte count of one spmv_sum with r right-hand sides over the terms
  * whose coefficient is non-zero in `mask` (NULL = all):  sum_k[nnz_k*(16+4)+(d+1)*4] + 2*r*d*16 */

@@ -60,7 +60,10 @@ mutable struct DeviceFamily
     solver_ready::Bool
     tol::Float64
     maxit::Int32
-    function DeviceFamily(L::LinearOperatorFamily; device::Integer=0, tol=1e-12, maxit=400)
+    # symmetry_tol: opts[0] of wae_family_create_opts.  0 (default): `A'` is exactly `A'` -- a term is applied un-transposed for
+    # A'*y / A'\\b only if it is bitwise symmetric.  Families from `discretize` (M, K, C symmetric by construction, assembled in floating
+    # point) should pass 1e-14: their adjoint products then take the forward path (include/waehip.h).
+    function DeviceFamily(L::LinearOperatorFamily; device::Integer=0, tol=1e-12, maxit=400, symmetry_tol::Float64=0.0)
         T = length(L.terms)
         d = size(L.terms[1].coeff, 1)
         # Helmholtz terms are SparseMatrixCSC{ComplexF64,UInt32} (Helmholtz.jl:407-408,515): pass colptr/rowval/nzval as they are
@@ -68,9 +71,16 @@ mutable struct DeviceFamily
         ptrs = [pointer(m.colptr) for m in mats]; idxs = [pointer(m.rowval) for m in mats]; vals = [pointer(m.nzval) for m in mats]
         h = Ref{Ptr{Cvoid}}(C_NULL)
         GC.@preserve mats ptrs idxs vals begin
-            check(ccall((:wae_family_create, libwaehip), Cint,
-                        (Ref{Ptr{Cvoid}}, Int64, Int32, Int32, Int32, Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Int32),
-                        h, d, T, 4, 1, 0 #=WAE_CSC=#, ptrs, idxs, vals, device))
+            if symmetry_tol == 0.0
+                check(ccall((:wae_family_create, libwaehip), Cint,
+                            (Ref{Ptr{Cvoid}}, Int64, Int32, Int32, Int32, Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Int32),
+                            h, d, T, 4, 1, 0 #=WAE_CSC=#, ptrs, idxs, vals, device))
+            else
+                opts = Float64[symmetry_tol]
+                check(ccall((:wae_family_create_opts, libwaehip), Cint,
+                            (Ref{Ptr{Cvoid}}, Int64, Int32, Int32, Int32, Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Int32, Ptr{Float64}, Int32),
+                            h, d, T, 4, 1, 0 #=WAE_CSC=#, ptrs, idxs, vals, device, opts, length(opts)))
+            end
         end
         fam = new(L, h[], false, tol, maxit)
         finalizer(f -> (f.handle != C_NULL && ccall((:wae_family_destroy, libwaehip), Cint, (Ptr{Cvoid},), f.handle); f.handle = C_NULL), fam)
@@ -116,6 +126,46 @@ function Base.:*(A::Operator, X::StridedVecOrMat{ComplexF64})
     check(ccall((:wae_spmv_sum, libwaehip), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Int32, Int32),
                 A.fam.handle, A.c, X, Y, size(X, 2), A.op))
     return Y
+end
+
+"number of HIP devices the library sees (wae_device_count) and its build string (wae_version)"
+function device_count()
+    n = Ref{Cint}(0)
+    check(ccall((:wae_device_count, libwaehip), Cint, (Ref{Cint},), n))
+    return Int(n[])
+end
+version() = unsafe_string(ccall((:wae_version, libwaehip), Cstring, ()))
+
+"(d, T, nnz) of the resident family (wae_family_info)"
+function family_info(fam::DeviceFamily)
+    d = Ref{Int64}(0); T = Ref{Int32}(0); nz = Ref{Int64}(0)
+    check(ccall((:wae_family_info, libwaehip), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int32}, Ref{Int64}), fam.handle, d, T, nz))
+    return Int(d[]), Int(T[]), Int(nz[])
+end
+
+"algorithmic bytes of one `L(z)*X` with r columns over the terms flagged in `mask` (wae_family_spmv_bytes; SURVEY 8d formula)"
+function spmv_bytes(fam::DeviceFamily; r::Integer=1, mask=nothing)
+    m = mask === nothing ? C_NULL : UInt8.(mask .!= 0)
+    return ccall((:wae_family_spmv_bytes, libwaehip), Int64, (Ptr{Cvoid}, Ptr{UInt8}, Int32), fam.handle, m, r)
+end
+
+"Y[:,j] = Σ_k C[k,j] op(A_k) X[:,j]: one coefficient column per column of X (wae_spmv_sum_cols) -- e.g. `L(ω_j)*v_j` or
+`L(ω_j,1)*v_j` for all start values of `householder_many` in one launch.  C is T x r (column j = `coefficients(L, ω_j)`)."
+function spmv_cols(fam::DeviceFamily, C::Matrix{ComplexF64}, X::Matrix{ComplexF64}; op::Int32=OP_N)
+    size(C, 2) == size(X, 2) || error("spmv_cols: one coefficient column per column of X")
+    Y = similar(X)
+    check(ccall((:wae_spmv_sum_cols, libwaehip), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}, Int32, Ptr{ComplexF64}, Ptr{ComplexF64}, Int32, Int32),
+                fam.handle, C, size(C, 2), X, Y, size(X, 2), op))
+    return Y
+end
+
+"y = Σ_k c[k] A_k X[:,k]: one input column per term (wae_spmv_sum_multi) -- the regrouped sum over (m,n) of `L(m,n)*w` in
+perturbation.jl:394-415"
+function spmv_multi(fam::DeviceFamily, c::Vector{ComplexF64}, X::Matrix{ComplexF64})
+    size(X, 2) == length(fam.L.terms) == length(c) || error("spmv_multi: one column and one coefficient per term")
+    y = Vector{ComplexF64}(undef, size(X, 1))
+    check(ccall((:wae_spmv_sum_multi, libwaehip), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}, Ptr{ComplexF64}, Ptr{ComplexF64}), fam.handle, c, X, y))
+    return y
 end
 
 # probe_columns / snapshots: workspace hints (opts[8], opts[9] of wae_solver_setup) for the contour integrals that will follow --
@@ -551,6 +601,346 @@ function solve(fam::DeviceFamily, Γ; Δl=1, N=16, tol=1e-8, eigvals=Dict(), max
         (!found_new && sum(keep) < l) && break                     # rank gap reached and nothing new: done (solver.jl:172)
     end
     return eigvals
+end
+
+# ---------------------------------------------------------------------------------------------------------------
+# householder for SEVERAL start values in lock-step (the refinement `solve` wants after `beyn`, solver.jl:96-140): the two
+# shift-invert Arnoldi processes of every Newton step are batched over the start values on the device.  A single-column solve is
+# latency-bound: refining the 8 estimates of the 1M-DoF benchmark this way costs about what refining one does.
+# ---------------------------------------------------------------------------------------------------------------
+"per-system (lam, X, gap) of `eigs` for nsys operator pairs (A_s - σ_s M, M) in lock-step: cA T x nsys, v0 d x nsys.
+An entry is an EigsError when that system's inner solves stalled."
+function eigs_many(fam::DeviceFamily, cA::Matrix{ComplexF64}, cM::Vector{ComplexF64}, V0::Matrix{ComplexF64}, op::Int32, sigmas::Vector{Float64};
+                   nev::Int=1, tol::Float64=1e-12, maxiter::Int=300)
+    d, nsys = size(V0)
+    step = min(d, max(20, 2nev + 1), max(6, 2nev + 2))
+    cAs = cA .- reshape(ComplexF64.(sigmas), 1, :) .* cM
+    sig_out = op == OP_C ? conj.(ComplexF64.(sigmas)) : ComplexF64.(sigmas)
+    V0 = copy(V0)
+    out = Vector{Any}(undef, nsys)
+    pending = collect(1:nsys); total = 0
+    while !isempty(pending) && total < maxiter
+        H, V, info = arnoldi_batch(fam, cAs[:, pending], repeat(cM, 1, length(pending)), step, V0[:, pending], op; ritz_tol=(nev == 1 ? tol : 0.0))
+        total += step
+        failed = info.n_unconverged > 0 && info.relres_max > 1e-4
+        still = Int[]
+        for (q, s) in enumerate(pending)
+            Hs = H[:, :, q]; Vs = V[:, :, q]
+            m = step
+            while m > 1 && all(Hs[:, m] .== 0); m -= 1; end            # steps not taken (early exit on the device)
+            taken = m
+            for j in 1:m
+                if Hs[j+1, j] == 0; m = j; break; end                  # invariant subspace
+            end
+            F = eigen(Hs[1:m, 1:m])
+            ord = sortperm(abs.(F.values); rev=true)
+            theta, Y = F.values[ord], F.vectors[:, ord]
+            k = min(nev, m)
+            res = abs(Hs[m+1, m]) .* abs.(Y[m, 1:k])
+            X = Vs[:, 1:m] * Y[:, 1:k]
+            for j in 1:k; X[:, j] ./= norm(X[:, j]); end
+            gap = m > k ? abs(1.0 / theta[k+1]) : Inf
+            out[s] = (sig_out[s] .+ 1.0 ./ theta[1:k], X, gap)
+            if !(all(res .<= tol .* abs.(theta[1:k])) || m < taken || m >= d)
+                if failed
+                    out[s] = EigsError("inner solves stalled")
+                else
+                    V0[:, s] = X * ones(ComplexF64, k); push!(still, s)
+                end
+            end
+        end
+        pending = still
+    end
+    return out
+end
+
+"start vectors of the left (adjoint) processes when the caller gives none: conj(v) for an isolated mode (Householder.jl:84-86); for
+several start vectors their conjugate span, bi-orthogonal in the bilinear form, W = conj(V G^-1), G = transpose(V) V -- a spinning
+mode of an annulus has vᵀv = 0 and conj(v) is its PARTNER, orthogonal to the left vector wanted."
+function conjugate_span_start(V::Matrix{ComplexF64})
+    ns = size(V, 2)
+    ns < 2 && return conj.(V)
+    nrm = [norm(V[:, j]) for j in 1:ns]; nrm[nrm .== 0] .= 1.0
+    Vn = V ./ reshape(nrm, 1, :)
+    G = transpose(Vn) * Vn
+    (all(isfinite, G) && minimum(svdvals(G)) >= 1e-6) || return conj.(V)
+    return conj.(Vn * inv(G))
+end
+
+"[(sol, n, flag), ...] = householder_many(Ld, zs; maxiter, tol, relax, lam_tol, order, v0s, v0s_adj): `householder`
+(Householder.jl:70-192, nev = 1) for every start value in zs, the device work batched over the start values.  An empty zs returns
+an empty list."
+function householder_many(fam::DeviceFamily, zs; maxiter=10, tol=0., relax=1., lam_tol=Inf, order=1, v0s=nothing, v0s_adj=nothing, output=false)
+    L = fam.L
+    z = ComplexF64.(collect(zs)); ns = length(z)
+    ns == 0 && return Tuple{Solution,Int,Int}[]
+    ensure_solver!(fam)
+    d = size(L.terms[1].coeff, 1); T = length(L.terms)
+    active, mode = L.active, L.mode
+    V = v0s === nothing ? ones(ComplexF64, d, ns) : Matrix{ComplexF64}(reshape(v0s, d, ns))
+    W = v0s_adj === nothing ? conjugate_span_start(V) : Matrix{ComplexF64}(reshape(v0s_adj, d, ns))
+    z0 = fill(complex(Inf), ns); lam = fill(complex(Inf), ns); n = zeros(Int, ns); flag = ones(Int, ns)
+    gaps = fill(Inf, ns); lams = fill(Inf, ns)
+    cM = zeros(ComplexF64, T); cM[end] = -1                             # M = -L.terms[end].coeff  (Householder.jl:92)
+    upd(c) = householder_update([factorial(i - 1) * c[i] for i in 1:length(c)])
+    while true
+        act = [s for s in 1:ns if flag[s] == 1 && abs(z[s] - z0[s]) > tol && n[s] < maxiter]
+        isempty(act) && break
+        cA = Matrix{ComplexF64}(undef, T, length(act)); sig = Float64[]
+        L.active = [L.eigval]; L.mode = :all
+        for (q, s) in enumerate(act)
+            z0[s] = z[s]
+            L.params[L.eigval] = z[s]; L.params[L.auxval] = 0
+            cA[:, q] = coefficients(L, z[s])
+            push!(sig, (isfinite(gaps[s]) && lams[s] < 1e-4 * gaps[s]) ? 1e-5 * gaps[s] : 0.0)
+        end
+        local right, left
+        try
+            right = eigs_many(fam, cA, cM, V[:, act], OP_N, sig)
+            left = eigs_many(fam, cA, cM, W[:, act], OP_C, sig)
+        catch excp
+            for s in act; flag[s] = excp isa LinearAlgebra.SingularException ? -6 : -2; end
+            break
+        end
+        for (q, s) in enumerate(act)
+            if right[q] isa EigsError || left[q] isa EigsError; flag[s] = -4; continue; end
+            lam_r, v_r, gap = right[q]; _, v_l, _ = left[q]
+            isfinite(gap) && (gaps[s] = gap)
+            lams[s] = minimum(abs.(lam_r))
+            L.params[L.eigval] = z[s]; L.params[L.auxval] = lam_r[1]
+            local dz
+            try
+                sol = Solution(L.params, v_r[:, 1], v_l[:, 1], L.auxval)
+                perturb!(sol, fam, L.eigval, order; mode=:householder)
+                dz = upd(sol.eigval_pert[Symbol("$(string(L.eigval))/Taylor")])
+            catch excp
+                flag[s] = excp isa LinearAlgebra.SingularException ? -6 : -2
+                continue
+            end
+            lam[s] = lam_r[1]
+            output && println(s, " ", n[s], "\t", abs(lam[s]), "\t", abs(dz), "\t", z[s])
+            z[s] += relax * dz
+            V[:, s] = (1 - relax) .* V[:, s] .+ relax .* v_r[:, 1]
+            W[:, s] = (1 - relax) .* W[:, s] .+ relax .* v_l[:, 1]
+            n[s] += 1
+        end
+    end
+    # Householder.jl:189-190 for all start values at once: two batched operator products
+    MV = Operator(fam, cM, OP_N) * V
+    for s in 1:ns; V[:, s] ./= sqrt(dot(V[:, s], MV[:, s])); end
+    cD = Matrix{ComplexF64}(undef, T, ns)
+    saved = copy(L.params); L.active = [L.eigval]; L.mode = :all
+    for s in 1:ns
+        L.params[L.eigval] = z[s]; L.params[L.auxval] = isfinite(lam[s]) ? lam[s] : 0
+        cD[:, s] = coefficients(L, z[s], 1)
+    end
+    merge!(L.params, saved); L.active, L.mode = active, mode
+    DV = spmv_cols(fam, cD, V)
+    for s in 1:ns; W[:, s] ./= conj(dot(W[:, s], DV[:, s])); end
+    out = Tuple{Solution,Int,Int}[]
+    for s in 1:ns
+        f = flag[s]
+        L.params[L.eigval] = z[s]; L.params[L.auxval] = isfinite(lam[s]) ? lam[s] : 0
+        if f == 1
+            f = n[s] >= maxiter ? -1 : (abs(lam[s]) <= lam_tol ? 1 : (abs(z[s] - z0[s]) <= tol ? 0 : (isnan(z[s]) ? -5 : -3)))
+        end
+        push!(out, (Solution(L.params, V[:, s], W[:, s], L.eigval), n[s], f))
+    end
+    L.active, L.mode = active, mode
+    return out
+end
+
+"`solve` (solver.jl:36-184) with the local refinement of ALL new Beyn estimates of a cycle in one lock-step batch
+(`householder_many`, which also delivers the adjoint vectors the deflation of the moments needs, solver.jl:131-137)"
+function solve_batched(fam::DeviceFamily, Γ; Δl=1, N=16, tol=1e-8, eigvals=Dict(), max_outer_cycles=1, atol_σ=1e-12, rtol_σ=1e-8, order=1, loglevel=0)
+    L = fam.L
+    d = size(L.terms[1].coeff, 1)
+    eigvals = Dict{ComplexF64,Any}(eigvals)
+    A = Array{Array{ComplexF64,3},1}()
+    l = 0
+    for cycle in 1:max_outer_cycles * max(1, div(d, Δl))
+        l >= d && break
+        V = zeros(ComplexF64, d, Δl); for i in 1:Δl; l + i <= d && (V[l+i, i] = 1); end
+        mom = compute_moment_matrices(fam, Γ, V; K=1, N=N)
+        for (ω, val) in eigvals                                        # deflation of known eigenpairs (solver.jl:57-64,131-137)
+            sol = val[1]; val[2] || continue
+            for p in 0:size(mom, 3)-1
+                mom[:, :, p+1] .-= (-2π * im * ω^p) .* (sol.v * (sol.v_adj[l+1:l+Δl])')
+            end
+        end
+        push!(A, mom); l += Δl
+        B0 = hcat((a[:, :, 1] for a in A)...); B1 = hcat((a[:, :, 2] for a in A)...)
+        F = svd(B0)
+        σmax = isempty(F.S) ? 0.0 : F.S[1]
+        keep = (F.S .> atol_σ) .& (F.S .> rtol_σ * σmax)
+        any(keep) || break
+        U, S, W = F.U[:, keep], F.S[keep], F.V[:, keep]
+        Ω, P = eigen(U' * B1 * W * Diagonal(1 ./ S)); P = U * P
+        inside = [j for j in 1:length(Ω) if inpoly(Ω[j], Γ)]
+        found_new = false
+        for (sol, n, flag) in householder_many(fam, Ω[inside]; maxiter=10, tol=tol, order=order, v0s=P[:, inside])
+            flag >= 0 || continue
+            ω = sol.params[L.eigval]
+            any(abs(ω - w) <= 10tol * max(1, abs(w)) for w in keys(eigvals)) && continue
+            eigvals[ω] = Any[sol, inpoly(ω, Γ)]
+            found_new = true
+            loglevel > 0 && println("solve_batched: new eigenvalue ", ω, " after ", n, " Newton steps")
+        end
+        (!found_new && sum(keep) < l) && break                         # rank gap reached and nothing new: done (solver.jl:172)
+    end
+    return eigvals
+end
+
+# ---------------------------------------------------------------------------------------------------------------
+# the snapshot basis of a handle on the host (exchange between GPUs when the caller runs its own process group instead of
+# compute_moment_matrices(::Vector{DeviceFamily}, ...) below)
+# ---------------------------------------------------------------------------------------------------------------
+"(S, l, kact, Hk, g) = rb_export(fam): the projected terms of the handle's snapshot basis (wae_rb_export): Hk[c, i, s, ki] =
+q_iᴴ A_k q_s of column c's basis for the terms kact (0-based term indices), g[c, i] = q_iᴴ v_c"
+function rb_export(fam::DeviceFamily)
+    S = Ref{Int32}(0); l = Ref{Int32}(0); nk = Ref{Int32}(0)
+    check(ccall((:wae_rb_export, libwaehip), Cint, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}, Ref{Int32}, Ptr{Int32}, Ptr{ComplexF64}, Ptr{ComplexF64}),
+                fam.handle, S, l, nk, C_NULL, C_NULL, C_NULL))
+    kact = zeros(Int32, nk[]); Hk = zeros(ComplexF64, l[], S[], S[], nk[]); g = zeros(ComplexF64, l[], S[])
+    check(ccall((:wae_rb_export, libwaehip), Cint, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}, Ref{Int32}, Ptr{Int32}, Ptr{ComplexF64}, Ptr{ComplexF64}),
+                fam.handle, S, l, nk, kact, Hk, g))
+    return Int(S[]), Int(l[]), kact, Hk, g
+end
+
+"install a basis whose vectors lie at the device address Q_dev (S x d x l, interleaved [row][column]) for mode 2 (wae_rb_import)"
+function rb_import(fam::DeviceFamily, Q_dev::UInt64, kact::Vector{Int32}, Hk::Array{ComplexF64,4}, g::Matrix{ComplexF64})
+    l, S = size(g)
+    check(ccall((:wae_rb_import, libwaehip), Cint, (Ptr{Cvoid}, Int32, Int32, UInt64, Int32, Ptr{Int32}, Ptr{ComplexF64}, Ptr{ComplexF64}),
+                fam.handle, S, l, Q_dev, length(kact), kact, Hk, g))
+    return
+end
+
+# ---------------------------------------------------------------------------------------------------------------
+# P1 assembly and shape sensitivity on the device (SURVEY 8f-2, 8f-4): the element loops of `discretize` for P1 meshes
+# (Helmholtz.jl:405-487) and the local re-discretisations of `discrete_adjoint_shape_sensitivity` (shape_sensitivity.jl:16-141).
+# points: 3 x N Float64 (`mesh.points`); tets / tris: 4 x ntet / 3 x ntri matrices of 1-BASED point indices
+# (`hcat(mesh.tetrahedra...)`); the wrappers hand 0-based Int32 copies to the library.
+# ---------------------------------------------------------------------------------------------------------------
+_zero_based(a) = Matrix{Int32}(a) .- Int32(1)
+
+function _take_p1(h::Ptr{Cvoid}, both::Bool)
+    try
+        n = Ref{Int64}(0); nz = Ref{Int64}(0)
+        check(ccall((:wae_p1_info, libwaehip), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), h, n, nz))
+        rowptr = zeros(Int32, n[] + 1); col = zeros(Int32, nz[]); m = zeros(Float64, nz[]); k = both ? zeros(Float64, nz[]) : Float64[]
+        check(ccall((:wae_p1_get, libwaehip), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}), h, rowptr, col, m, both ? k : C_NULL))
+        # the arrays are CSR: as (colptr, rowval) they describe the TRANSPOSE; transpose back (M, K, C are symmetric, Q is not)
+        csr(v) = SparseMatrixCSC{ComplexF64,UInt32}(sparse(transpose(SparseMatrixCSC(Int(n[]), Int(n[]), UInt32.(rowptr .+ 1), UInt32.(col .+ 1), ComplexF64.(v)))))
+        return both ? (csr(m), csr(k)) : csr(m)
+    finally
+        ccall((:wae_p1_free, libwaehip), Cint, (Ptr{Cvoid},), h)
+    end
+end
+
+"M, K = assemble_p1(points, tets; c_tet, device): mass and stiffness (K = -c² ∫∇φ_a·∇φ_b, Helmholtz.jl:120-124,405-441) on the device"
+function assemble_p1(points::Matrix{Float64}, tets::AbstractMatrix{<:Integer}; c_tet=nothing, device::Integer=0)
+    t0 = _zero_based(tets); h = Ref{Ptr{Cvoid}}(C_NULL)
+    cc = c_tet === nothing ? C_NULL : Vector{Float64}(c_tet)
+    check(ccall((:wae_p1_assemble, libwaehip), Cint, (Int32, Int64, Ptr{Float64}, Int64, Ptr{Int32}, Ptr{Float64}, Ref{Ptr{Cvoid}}),
+                device, size(points, 2), points, size(t0, 2), t0, cc, h))
+    return _take_p1(h[], true)
+end
+
+"C = assemble_p1_boundary(points, tris; c_tri, device): admittance-boundary operator -i c |e1×e2| (1+δ_ab)/24 (Helmholtz.jl:443-463)"
+function assemble_p1_boundary(points::Matrix{Float64}, tris::AbstractMatrix{<:Integer}; c_tri=nothing, device::Integer=0)
+    t0 = _zero_based(tris); h = Ref{Ptr{Cvoid}}(C_NULL)
+    cc = c_tri === nothing ? C_NULL : Vector{Float64}(c_tri)
+    check(ccall((:wae_p1_assemble_boundary, libwaehip), Cint, (Int32, Int64, Ptr{Float64}, Int64, Ptr{Int32}, Ptr{Float64}, Ref{Ptr{Cvoid}}),
+                device, size(points, 2), points, size(t0, 2), t0, cc, h))
+    return -1im .* _take_p1(h[], false)
+end
+
+"Q, V_flame = assemble_p1_flame(points, tets, flame_tets, ref_tet, n_ref, nglobal_scaled; device): Q = Σ_flame S ⊗ g
+(Helmholtz.jl:292-344,464-487); flame_tets / ref_tet are 1-based indices into tets; nglobal_scaled = (γ-1)/ρ·Q02U0"
+function assemble_p1_flame(points::Matrix{Float64}, tets::AbstractMatrix{<:Integer}, flame_tets::AbstractVector{<:Integer}, ref_tet::Integer,
+                           n_ref::Vector{Float64}, nglobal_scaled::Real; device::Integer=0)
+    t0 = _zero_based(tets); fl = Vector{Int32}(flame_tets) .- Int32(1); h = Ref{Ptr{Cvoid}}(C_NULL); vol = Ref{Float64}(0.0)
+    check(ccall((:wae_p1_assemble_flame, libwaehip), Cint,
+                (Int32, Int64, Ptr{Float64}, Int64, Ptr{Int32}, Int64, Ptr{Int32}, Int32, Ptr{Float64}, Float64, Ref{Ptr{Cvoid}}, Ref{Float64}),
+                device, size(points, 2), points, size(t0, 2), t0, length(fl), fl, ref_tet - 1, n_ref, Float64(nglobal_scaled), h, vol))
+    return _take_p1(h[], false), vol[]
+end
+
+"sens (3 x length(surface_points)) = discrete_adjoint_shape_sensitivity_p1(points, tets, c_tet, surface_points, ω, v, v_adj; ...):
+-v_adjᴴ (dL/dx) v of shape_sensitivity.jl:16-141 for the interior operators and, if bnd_tris is given, the admittance boundary ω·Y·C;
+v, v_adj normalised as there (vᴴv = 1, v_adjᴴ L'(ω) v = 1).  One device thread per (point, adjacent simplex, coordinate); the pairs of a
+point are summed here in order."
+function discrete_adjoint_shape_sensitivity_p1(points::Matrix{Float64}, tets::AbstractMatrix{<:Integer}, c_tet, surface_points::AbstractVector{<:Integer},
+                                               ω::ComplexF64, v::Vector{ComplexF64}, v_adj::Vector{ComplexF64};
+                                               bnd_tris=nothing, bnd_c=nothing, Y=0.0, h::Float64=1e-9, device::Integer=0)
+    t0 = _zero_based(tets)
+    lut = zeros(Int, size(points, 2)); for (i, p) in enumerate(surface_points); lut[p] = i; end
+    pair_pt_t = Int32[]; pair_tet = Int32[]; own_t = Int[]
+    for e in 1:size(t0, 2), a in 1:4
+        p = t0[a, e] + 1
+        lut[p] > 0 && (push!(pair_pt_t, p - 1); push!(pair_tet, e - 1); push!(own_t, lut[p]))
+    end
+    s0 = bnd_tris === nothing ? zeros(Int32, 3, 0) : _zero_based(bnd_tris)
+    pair_pt_s = Int32[]; pair_tri = Int32[]; own_s = Int[]
+    for e in 1:size(s0, 2), a in 1:3
+        p = s0[a, e] + 1
+        lut[p] > 0 && (push!(pair_pt_s, p - 1); push!(pair_tri, e - 1); push!(own_s, lut[p]))
+    end
+    out_t = zeros(ComplexF64, 3, length(pair_tet)); out_s = zeros(ComplexF64, 3, length(pair_tri))
+    cc = c_tet === nothing ? C_NULL : Vector{Float64}(c_tet)
+    bc = (bnd_c === nothing || isempty(pair_tri)) ? C_NULL : Vector{Float64}(bnd_c)
+    om = Float64[real(ω), imag(ω)]; omy = Float64[real(ω * Y), imag(ω * Y)]
+    check(ccall((:wae_p1_shape_sensitivity, libwaehip), Cint,
+                (Int32, Int64, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Int64, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Int64, Ptr{Int32}, Ptr{Int32},
+                 Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Float64, Ptr{ComplexF64}, Ptr{ComplexF64}),
+                device, size(points, 2), points, t0, cc, length(pair_tet), pair_pt_t, pair_tet, isempty(pair_tri) ? C_NULL : s0, bc, length(pair_tri),
+                isempty(pair_tri) ? C_NULL : pair_pt_s, isempty(pair_tri) ? C_NULL : pair_tri, size(t0, 2), size(s0, 2), om, omy, v, v_adj, h,
+                isempty(pair_tet) ? C_NULL : out_t, isempty(pair_tri) ? C_NULL : out_s))
+    sens = zeros(ComplexF64, 3, length(surface_points))
+    for (q, i) in enumerate(own_t); sens[:, i] .+= out_t[:, q]; end
+    for (q, i) in enumerate(own_s); sens[:, i] .+= out_s[:, q]; end
+    return sens
+end
+
+"flame part of the same sensitivity (a :flame entry in dscrp; shape_sensitivity.jl:62-141): -v_adjᴴ coeff (Q₊ - Q₋)/(2h) v per surface
+point and coordinate, Q re-discretised on the flame domain REDUCED to the tetrahedra at the point (its volume included, Helmholtz.jl:325);
+coeff = the flame term's scalar n·exp(-iωτ) at ω.  flame_tets / ref_tet 1-based."
+function discrete_adjoint_shape_sensitivity_p1_flame(points::Matrix{Float64}, tets::AbstractMatrix{<:Integer}, surface_points::AbstractVector{<:Integer},
+                                                     flame_tets::AbstractVector{<:Integer}, ref_tet::Integer, n_ref::Vector{Float64}, nglobal_scaled::Real,
+                                                     coeff::ComplexF64, v::Vector{ComplexF64}, v_adj::Vector{ComplexF64}; h::Float64=1e-9, device::Integer=0)
+    t0 = _zero_based(tets)
+    ns = length(surface_points)
+    lut = zeros(Int, size(points, 2)); for (i, p) in enumerate(surface_points); lut[p] = i; end
+    pair_pt = Int32[]; pair_tet = Int32[]; own = Int[]
+    for e in flame_tets, a in 1:4
+        p = t0[a, e] + 1
+        lut[p] > 0 && (push!(pair_pt, p - 1); push!(pair_tet, e - 1); push!(own, lut[p]))
+    end
+    pair_pt_r = Int32[]; own_r = Int[]
+    for a in 1:4
+        p = t0[a, ref_tet] + 1
+        lut[p] > 0 && (push!(pair_pt_r, p - 1); push!(own_r, lut[p]))
+    end
+    np, nr = length(pair_tet), length(pair_pt_r)
+    det_pm = zeros(Float64, 2, 3, np); ssum = zeros(ComplexF64, np); g_pm = zeros(ComplexF64, 2, 3, nr); g0 = zeros(ComplexF64, 1)
+    check(ccall((:wae_p1_shape_sensitivity_flame, libwaehip), Cint,
+                (Int32, Int64, Ptr{Float64}, Int64, Ptr{Int32}, Int64, Ptr{Int32}, Ptr{Int32}, Int32, Int64, Ptr{Int32}, Ptr{Float64},
+                 Ptr{ComplexF64}, Ptr{ComplexF64}, Float64, Ptr{Float64}, Ptr{ComplexF64}, Ptr{ComplexF64}, Ptr{ComplexF64}),
+                device, size(points, 2), points, size(t0, 2), t0, np, np == 0 ? C_NULL : pair_pt, np == 0 ? C_NULL : pair_tet, ref_tet - 1, nr,
+                nr == 0 ? C_NULL : pair_pt_r, n_ref, v, v_adj, h, np == 0 ? C_NULL : det_pm, np == 0 ? C_NULL : ssum, nr == 0 ? C_NULL : g_pm, g0))
+    a_pm = zeros(ComplexF64, 2, 3, ns); V_pm = zeros(Float64, 2, 3, ns)      # v_adjᴴ S± and the volume of the point's flame tetrahedra
+    for (q, i) in enumerate(own)
+        a_pm[:, :, i] .+= det_pm[:, :, q] ./ 24 .* ssum[q]; V_pm[:, :, i] .+= det_pm[:, :, q] ./ 6
+    end
+    b_pm = fill(g0[1], 2, 3, ns)                                             # Σ_b ∇φ_b·n_ref v_b on the reference tetrahedron
+    for (q, i) in enumerate(own_r); b_pm[:, :, i] = g_pm[:, :, q]; end
+    out = zeros(ComplexF64, 3, ns)
+    for i in 1:ns
+        V_pm[1, 1, i] > 0 || continue                                        # no flame tetrahedron at the point: empty domain, no term
+        q = a_pm[:, :, i] .* (-(Float64(nglobal_scaled) ./ V_pm[:, :, i]) .* b_pm[:, :, i])      # v_adjᴴ Q± v  (g = -nlocal ∇φ·n_ref)
+        out[:, i] = -coeff .* (q[1, :] .- q[2, :]) ./ (2h)
+    end
+    return out
 end
 
 # ---------------------------------------------------------------------------------------------------------------

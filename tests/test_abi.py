@@ -137,7 +137,7 @@ def test_julia_ccall_signatures_match_the_header():
     width where it has a scalar."""
     protos = _header_prototypes()
     calls = _julia_ccalls()
-    assert len(calls) >= 14
+    assert len(calls) >= 30
     seen = set()
     for name, types in calls:
         assert name in protos, name
@@ -166,6 +166,25 @@ def test_julia_ccall_signatures_match_the_header():
     code = "\n".join(ln.split("#")[0] for ln in code.split("\n"))
     for a, b in ("()", "[]", "{}"):
         assert code.count(a) == code.count(b), (a, code.count(a), code.count(b))
+
+
+def test_every_product_export_is_bound_from_julia():
+    """The host the north star names is Julia: every entry of include/waehip.h that is not a measurement helper (wae_bench_*) or the
+    test hook (wae_debug_*) must have a `ccall` in julia/WAEHip.jl -- a feature that exists only in the Python mirror is not a
+    drop-in."""
+    protos = _header_prototypes()
+    bound = {name for name, _ in _julia_ccalls()}
+    need = {n for n in protos if not n.startswith(("wae_bench_", "wae_debug_"))}
+    assert len(need) >= 30
+    assert not sorted(need - bound), sorted(need - bound)
+    assert set(protos) == set(_lib.EXPORTS)
+    # ... and the batched refinement + the solve driver that uses it exist on the Julia side
+    jl = open(os.path.join(ROOT, "julia", "WAEHip.jl"), encoding="utf-8").read()
+    for fn in ("function householder_many(", "function solve_batched(", "function eigs_many(", "function conjugate_span_start(",
+               "function assemble_p1(", "function assemble_p1_boundary(", "function assemble_p1_flame(",
+               "function discrete_adjoint_shape_sensitivity_p1(", "function discrete_adjoint_shape_sensitivity_p1_flame(",
+               "function spmv_cols(", "function spmv_multi(", "function rb_export(", "function rb_import("):
+        assert fn in jl, fn
 
 
 def test_fused_galerkin_product_is_bit_identical(tmp_path):

