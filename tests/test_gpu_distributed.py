@@ -141,7 +141,7 @@ def _bench(args, **envkw):
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", WAE_BENCH_PREFAULT_GB="0", **envkw)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args + ["--preset", "small", "--N", "16", "--l", "4", "--K", "1", "--steps", "1",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args + ["--preset", "small", "--N", "32", "--l", "8", "--K", "2", "--steps", "1",
                         "--warmup", "1", "--tol", "1e-11", "--no-newton", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
