@@ -808,7 +808,11 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 4) void spmv_tile_kernel(O
             for (int j = 0; j < NOUT; ++j) {
                 const int c = ocol(j);
                 const int b = col0 + c < nb ? col0 + c : nb - 1;
+#ifdef WAE_TILE_FAKE_COALESCE      /* timing probe only (wrong operands): the access pattern of a row-contiguous epilogue */
+                const size_t e = (size_t)(r0 + min(wv * RPW + 8 * j + (lane >> 3), nrows - 1)) * nb + min(col0 + (lane & 7), nb - 1);
+#else
                 const size_t e = (size_t)row * nb + b;
+#endif
                 bv[j] = need_b ? B[e] : cplx{0.0, 0.0};
                 xv[j] = (mode == MODE_JAC && dslot == 0xFFFFu) ? X[e] : cplx{0.0, 0.0};       // (normally taken from the window, below)
             }
@@ -1125,7 +1129,11 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 4) void spmv_tile_kernel(O
             for (int j = 0; j < NOUT; ++j) {
                 const int b = col0 + ocol(j);
                 if (b >= nb) continue;
+#ifdef WAE_TILE_FAKE_COALESCE
+                const size_t e = (size_t)(r0 + min(wv * RPW + 8 * j + (lane >> 3), nrows - 1)) * nb + min(col0 + (lane & 7), nb - 1);
+#else
                 const size_t e = (size_t)row * nb + b;
+#endif
                 Y[e] = out[j];
                 if (mode == MODE_AX_J0) const_cast<cplx *>(B)[e] = b2[j];
             }

@@ -84,6 +84,7 @@ struct RbState {                     // snapshot basis of wae_beyn_moments_rb (o
 };
 
 struct wae_family {
+    bool vc_light = false;               // the current solve belongs to the projected phase of a contour integral (1-5 steps from a good guess): vcycle() runs its light form
     int device = 0;
     hipStream_t stream = nullptr;
     int64_t d = 0;
@@ -731,14 +732,26 @@ static cplx *vcycle(wae_family *h, const Batch &bt, int l, const cplx *b, const 
         launch_spmv(A, pc, bt.cps, x, t, b, h->jac_w, bt.nb, MODE_JAC, st, cm);
         std::swap(x, t);
     }
+    // (experiment) WAE_VC_LIGHT_ADD=1: the light cycle additive -- the coarse correction is computed from b itself, not from the residual
+    // after the first sweep: no second fine-level product per cycle
+    static const int light_add = getenv("WAE_VC_LIGHT_ADD") ? atoi(getenv("WAE_VC_LIGHT_ADD")) : 0;
     // residual -> t, restrict -> lb[l+1]
-    launch_spmv(A, pc, bt.cps, x, t, b, 0.0, bt.nb, MODE_RES, st, cm);
+    const bool additive = h->vc_light && light_add && l == 0 && h->nsweeps == 1;
+    if (!additive) launch_spmv(A, pc, bt.cps, x, t, b, 0.0, bt.nb, MODE_RES, st, cm);
     // for op = T/C the transfer operators are unchanged (real): (R A P)^H = R A^H P
-    launch_spmv(h->xfer[l].devR(), h->one_dev.p, 1 << 30, t, h->lb[l + 1].p, nullptr, 0.0, bt.nb, MODE_AX, st, cm);
+    launch_spmv(h->xfer[l].devR(), h->one_dev.p, 1 << 30, additive ? b : t, h->lb[l + 1].p, nullptr, 0.0, bt.nb, MODE_AX, st, cm);
     const cplx *xc = vcycle(h, bt, l + 1, h->lb[l + 1].p, cm);
     launch_prolong_add(h->xfer[l].p_ptr.p, h->xfer[l].p_col.p, h->xfer[l].p_val.p, h->xfer[l].nf, xc, x, bt.nb, st, cm);
-    static const int post_coarse = getenv("WAE_VC_POST_COARSE") ? atoi(getenv("WAE_VC_POST_COARSE")) : 1;
-    const int npost = (l >= 1 && !post_coarse) ? 0 : h->nsweeps;
+    // Post-smoothing on the coarse levels (WAE_VC_POST_COARSE): 1 always, 0 never, 2 (default) everywhere but in the projected phase of
+    // a contour integral.  A solve that starts from a projected guess (216 of the 256 points of the benchmark contour) takes 1-5 steps:
+    // there a cheaper cycle beats a better one (measured at 1M unknowns: projected phase 1.17 -> 0.99 s without the coarse
+    // post-smoothing, while the from-zero solves of the snapshot phase lose 1.26 -> 1.63 s).
+    static const int post_coarse = getenv("WAE_VC_POST_COARSE") ? atoi(getenv("WAE_VC_POST_COARSE")) : 2;
+    // ... and the fine level's too (WAE_VC_LIGHT_POST0=1 keeps it): the light cycle is V(1,0) on every level -- projected phase 1.02 -> 0.89 s,
+    // same eigenpairs (residuals 5.6e-9 -> 6.4e-9, rank gap 1.2e9), 9 325 -> 9 139 column-iterations per pass.
+    static const int light_post0 = getenv("WAE_VC_LIGHT_POST0") ? atoi(getenv("WAE_VC_LIGHT_POST0")) : 0;
+    const bool no_post = l >= 1 ? (post_coarse == 0 || (post_coarse == 2 && h->vc_light)) : (h->vc_light && !light_post0);
+    const int npost = no_post ? 0 : h->nsweeps;
     // (WAE_JAC_POST: a post-smoothing weight of its own -- two sweeps with different weights form a degree-2 polynomial smoother)
     static const double w_post_env = getenv("WAE_JAC_POST") ? atof(getenv("WAE_JAC_POST")) : 0.0;
     const double w_post = w_post_env > 0.0 ? w_post_env : h->jac_w;
@@ -2685,7 +2698,10 @@ int wae_beyn_moments_rb(wae_family *h, int32_t npts, const double *z, const doub
                 rb_apply_guess(h, Y, ns, h->Xs.p);
             }
             const double tb = now_s();
+            struct LightGuard { wae_family *h; ~LightGuard() { h->vc_light = false; } } light_guard{h};
+            h->vc_light = guess && (mode == 1 || mode == 2);       // (vcycle: the cheaper cycle for the solves of the projected phase)
             const int its = solve_chunk(h, bt, pcs, h->Bs.p, h->Xs.p, tol, maxit, &li, nullptr, guess);
+            h->vc_light = false;
             launch_beyn_accum(h->Xs.p, bt.nb, d, l, ns, h->zw_dev.p, h->zw_dev.p + ns, npow, Ad, st, l_total, col0, h->perm());
             if (rbdbg) HIP_CHECK(hipStreamSynchronize(st));
             const double tc = now_s();
