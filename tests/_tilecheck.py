@@ -44,6 +44,40 @@ class TermProducts:
         return Y, bound, dg
 
 
+class FamilyProducts:
+    """The same for ANY family: A_k X and |A_k| |X| for every term of ``L`` (host matrices ``t.coeff``), coefficient rows as
+    ``L.coefficients(z)`` gives them (one per term, 0 where the functor skips a term) -- e.g. the 11 terms of a Bloch unit cell
+    (base / seam parts times exp(+-i b 2 pi / DOS), src/Helmholtz.jl:508-513)."""
+
+    def __init__(self, L, X, op="N"):
+        self.op = op
+        mats = [t.coeff.tocsr() for t in L.terms]
+        if op == "C":
+            mats = [A.conj().T.tocsr() for A in mats]
+        self.AX = [A @ X for A in mats]
+        aX = np.abs(X)
+        self.absAX = [abs(A) @ aX for A in mats]
+        self.diag = [A.diagonal() for A in mats]
+
+    def apply(self, ct):
+        r = self.AX[0].shape[1]
+        ct = np.asarray(ct)
+        if self.op == "C":
+            ct = ct.conj()
+        cj = ct if ct.shape[0] == r else np.repeat(ct[:1], r, axis=0)
+        nz = [k for k in range(ct.shape[1]) if np.any(cj[:, k] != 0)]
+        Y = sum(self.AX[k] * cj[None, :, k] for k in nz)
+        bound = sum(self.absAX[k] * np.abs(cj[None, :, k]) for k in nz)
+        dg = sum(self.diag[k][:, None] * cj[None, :, k] for k in nz)
+        return Y, bound, dg
+
+
+def scipy_operator_product(L, coeffs, V):
+    """sum_k c_k A_k V with scipy on the host matrices of the family: the product the residual checks of the full-size tests form
+    WITHOUT the kernels under test"""
+    return sum(c * (t.coeff @ V) for c, t in zip(coeffs, L.terms) if c != 0)
+
+
 def assert_close(got, want, bound, what, cols=None, tol=TOL):
     cols = range(want.shape[1]) if cols is None else cols
     for j in cols:

@@ -580,7 +580,9 @@ def test_projected_guesses_column_split_exchange(l, nranks):
         fam.beyn_moments_rb(zs[rest], ws[rest], ct[rest], None, 2, S, Q_dev=store.data_ptr(), accumulate=True, l_total=l, **kw)
     fam.beyn_moments_rb(zs[rest], ws[rest], ct[rest], V, 2, S, Q_dev=store.data_ptr(), accumulate=True, **kw)
     assert fam.last_info["n_unconverged"] == 0
-    assert fam.last_info["iters_total"] < 0.5 * its0 * len(rest) / len(zs)      # the imported basis does its job
+    # the imported basis does its job (round 4: the projected phase runs the light V(1,0) cycle -- cheaper steps, a few more of them:
+    # 0.41 of the from-zero count with the full cycle, 0.50 with the light one on this 8 736-DoF problem)
+    assert fam.last_info["iters_total"] < 0.6 * its0 * len(rest) / len(zs)
     A2 = buf.cpu().numpy().view(np.complex128).reshape((d, l, 2), order="F")
     assert relerr(A2, A0) < 1e-8
     Lp._drop_device()

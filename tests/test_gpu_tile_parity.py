@@ -17,7 +17,7 @@ import sys
 import numpy as np
 import pytest
 
-from _tilecheck import TermProducts, assert_close, check_modes
+from _tilecheck import FamilyProducts, TermProducts, assert_close, check_modes
 from wae_amd.helmholtz.family import annulus_family
 
 pytestmark = pytest.mark.gpu
@@ -88,6 +88,43 @@ def test_tile_kernel_at_benchmark_size_against_scipy(preset, d_expect):
     R = B - AXs
     for j in range(64):                                             # error-like (diagonal-scaled) measure, as the solver's own
         assert np.linalg.norm(R[:, j] / dg[:, j]) <= 1e-8 * np.linalg.norm(B[:, j] / dg[:, j]), j
+    L._drop_device()
+
+
+def test_tile_kernel_on_the_bloch_unit_cell_at_benchmark_size_against_scipy():
+    """BASELINE configs[3] (C4): the Bloch unit cell at d = 200 000 (DOS = 32) -- 10 terms + aux in 8 sparsity patterns, the seam parts
+    of M, K, C and the flame term as side rows with COMPLEX per-plane coefficients exp(+-i b 2 pi / DOS) (src/Bloch.jl:4-112,
+    src/Helmholtz.jl:508-513) -- in the persistent work-list regime of the tile kernel (782 fine tiles), against scipy products of
+    the cell's own term matrices: wave numbers b = 0 (no phase), 5 and 16 (phase -1), one system per launch and one per column, op N
+    and C, the fused forms 0 / 1 / 2 / 6, r = 64 and r = 8.  (Until round 4 this family met scipy at 728 DoF only.)"""
+    from wae_amd.helmholtz import annulus
+    from wae_amd.helmholtz.bloch import bloch_family
+    rng = np.random.default_rng(33)
+    cell = annulus.build_unit_cell(grid=annulus.PRESETS["C4"], DOS=32, tau=2e-4)
+    d = cell["nsector"]
+    assert abs(d - 200_000) <= 2_000
+    L = bloch_family(cell)
+    assert len(L.terms) >= 11
+    fam = L.device()
+    zs = 2 * np.pi * (np.linspace(155, 995, 64) + 1j * np.linspace(-145, 145, 64))
+    X = rng.standard_normal((d, 64)) + 1j * rng.standard_normal((d, 64))
+    X8 = np.ascontiguousarray(X[:, 8:16])
+    tpN, tpC = FamilyProducts(L, X, "N"), FamilyProducts(L, X, "C")
+    tp8 = FamilyProducts(L, X8, "N")
+    for b in (0, 5, 16):
+        L.params["b"] = b
+        ct1 = np.array([L.coefficients(zs[40])])
+        ct64 = np.array([L.coefficients(z) for z in zs])
+        assert b == 0 or np.any(np.abs(ct1.imag) > 0)               # (the seam parts carry their phase factors)
+        check_modes(fam, tpN, ct1, X, rng, f"C4 b={b} r=64 one system", modes=(0, 1, 2, 6))
+        check_modes(fam, tpN, ct64, X, rng, f"C4 b={b} r=64 one system per column", modes=(0, 1, 2, 6))
+        check_modes(fam, tp8, ct1, X8, rng, f"C4 b={b} r=8 one system", modes=(0, 1, 2, 6))
+        check_modes(fam, tp8, ct64[:8], X8, rng, f"C4 b={b} r=8 one system per column", modes=(0, 2))
+        for ct in (ct1, ct64):                                       # the public entries, both orientations
+            want, bound, _ = tpN.apply(ct)
+            assert_close(fam.spmv(ct if len(ct) > 1 else ct[0], X), want, bound, f"C4 b={b} wae_spmv_sum r=64")
+            want, bound, _ = tpC.apply(ct)
+            assert_close(fam.spmv(ct if len(ct) > 1 else ct[0], X, op=2), want, bound, f"C4 b={b} wae_spmv_sum r=64 op C")
     L._drop_device()
 
 

@@ -500,6 +500,13 @@ template <int CTRL> __device__ __forceinline__ double lane_quad(double v) {     
     const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
+// DPP move of a double under a bank mask (a bank = four lanes of a 16-lane row): enabled lanes take `src` from the lane CTRL names,
+// the others keep `old`
+template <int CTRL, int BANKS> __device__ __forceinline__ double lane_dpp_masked(double old, double src) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xF, BANKS, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xF, BANKS, false);
+    return __hiloint2double(hi, lo);
+}
 // LPR = lanes per row: 2 (rows of up to 16 register-resident entries, 256-row tiles: the fine level) or 4 (up to 48, 128-row
 // tiles: the first coarse level, whose windows allow ~64 rows per tile anyway).
 // NWV = wavefronts per workgroup: 8, or 16 ("QUAD", round 3; fine level, one system per chunk): the tile keeps its 256 rows, its
@@ -603,7 +610,36 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 4) void spmv_tile_kernel(O
     static_assert(!QUAD || (LPR == 4 && UNI && NBUF == 2 && KRT == 8), "QUAD: LPR = 4, one system per chunk, two buffers, 8 entries per lane");
     const int qh = lane & 1, qc = (lane >> 1) & 1, qrot = (lane >> 2) & 3;     // (QUAD) this lane's halves, and the rotation of its row
     // column of result j of this lane: QUAD keeps positions 2 h + j of its column half (position s <-> column 4 c + (s + qrot) mod 4)
-    auto ocol = [&](int j) { return QUAD ? 4 * qc + ((2 * qh + j + qrot) & 3) : (rot_out + j) & 7; };
+    // COAL (round 4; one system per chunk, two lanes per row, two buffers -- the form of every wide solve): the epilogue touches memory
+    // ROW-CONTIGUOUSLY.  In the older form each lane wrote its four results of ONE row, 16 bytes at a time: a wave instruction was 64
+    // separate 16-byte requests (counters: 63.7 M of the 84.5 M L2 requests of a product at 1M unknowns were such partial writes), and the
+    // right-hand sides of the fused forms were read the same way.  Here the two lanes of a row keep the even / the odd COLUMNS (not
+    // the lower / upper positions), the four rows of an 8-lane group are transposed through DPP (quad permute for the neighbouring pair,
+    // masked row shifts by four lanes for the other), and instruction k of the group moves row k as ONE 128-byte request; what is
+    // loaded that way (B) is transposed back before the arithmetic.  Same sums, same results, bit for bit.
+    constexpr bool COAL = UNI && LPR == 2 && NBUF == 2 && !QUAD;
+    const bool he = ((sub ^ rot) & 1) != 0;                  // (COAL) this lane keeps accumulator positions 2 m + he: columns of parity `sub`
+    auto ocol = [&](int j) { return QUAD ? 4 * qc + ((2 * qh + j + qrot) & 3) : COAL ? (2 * j + (he ? 1 : 0) + rot) & 7 : (rot_out + j) & 7; };
+    // (COAL) transposed layout: register k of lane (g = lane >> 3, a = (lane >> 1) & 3, h = lane & 1) belongs to row 4 g + k of the
+    // wavefront's 32 and to the column that lane (4 g + k, h) kept at position a
+    auto tcol = [&](int k) { return (2 * ((lane >> 1) & 3) + ((lane ^ k) & 1) + ((4 * (lane >> 3) + k) & 7)) & 7; };
+    auto transpose4 = [&](cplx (&R)[4]) {                    // 4 x 4 transpose (register index <-> row of the group); its own inverse
+        const bool odd = ((lane >> 1) & 1) != 0;
+#pragma unroll
+        for (int m0 = 0; m0 < 4; m0 += 2) {                  // rows a and a ^ 1: two lanes further on in the quad
+            // (component by component: a select between two array ELEMENTS becomes a select of addresses and sends the arrays to scratch)
+            const double sx = odd ? R[m0].x : R[m0 + 1].x, sy = odd ? R[m0].y : R[m0 + 1].y;
+            const double rx = lane_quad<0x4E>(sx), ry = lane_quad<0x4E>(sy);
+            R[m0].x = odd ? rx : R[m0].x;          R[m0].y = odd ? ry : R[m0].y;
+            R[m0 + 1].x = odd ? R[m0 + 1].x : rx;  R[m0 + 1].y = odd ? R[m0 + 1].y : ry;
+        }
+#pragma unroll
+        for (int m0 = 0; m0 < 2; ++m0) {                     // rows a and a ^ 2: four lanes further on (row_shl:4 into banks 0, 2; row_shr:4 into banks 1, 3)
+            const cplx tmp = R[m0 + 2];
+            R[m0 + 2] = cplx{lane_dpp_masked<0x104, 0x5>(R[m0 + 2].x, R[m0].x), lane_dpp_masked<0x104, 0x5>(R[m0 + 2].y, R[m0].y)};
+            R[m0] = cplx{lane_dpp_masked<0x114, 0xA>(R[m0].x, tmp.x), lane_dpp_masked<0x114, 0xA>(R[m0].y, tmp.y)};
+        }
+    };
     const GroupDev G0 = op.g[0];
     const TileGroupDev T0 = td.g0;
     // ---- per-tile state
@@ -803,17 +839,23 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 4) void spmv_tile_kernel(O
         const double dsg = op.conj_diag ? -1.0 : 1.0;
         cplx bv[NOUT], xv[NOUT];
         cplx dgu = {1.0, 0.0};
+        auto trow = [&](int k) { return wv * RPW + 4 * (lane >> 3) + k; };       // (COAL) row of register k in the transposed layout
         auto epilogue_loads = [&]() {                        // right-hand sides of the fused modes: requested together
+            if constexpr (COAL) {                            // B row by row, 128 bytes per 8-lane group and instruction
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int lr = trow(k) < nrows ? trow(k) : (nrows > 0 ? nrows - 1 : 0);
+                    const int c = tcol(k);
+                    const int b = col0 + c < nb ? col0 + c : nb - 1;
+                    bv[k] = need_b ? B[(size_t)(r0 + lr) * nb + b] : cplx{0.0, 0.0};
+                }
+            }
 #pragma unroll
             for (int j = 0; j < NOUT; ++j) {
                 const int c = ocol(j);
                 const int b = col0 + c < nb ? col0 + c : nb - 1;
-#ifdef WAE_TILE_FAKE_COALESCE      /* timing probe only (wrong operands): the access pattern of a row-contiguous epilogue */
-                const size_t e = (size_t)(r0 + min(wv * RPW + 8 * j + (lane >> 3), nrows - 1)) * nb + min(col0 + (lane & 7), nb - 1);
-#else
                 const size_t e = (size_t)row * nb + b;
-#endif
-                bv[j] = need_b ? B[e] : cplx{0.0, 0.0};
+                if constexpr (!COAL) bv[j] = need_b ? B[e] : cplx{0.0, 0.0};
                 xv[j] = (mode == MODE_JAC && dslot == 0xFFFFu) ? X[e] : cplx{0.0, 0.0};       // (normally taken from the window, below)
             }
             if (UNI && need_d) {                             // one diagonal per row and chunk
@@ -1037,7 +1079,14 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 4) void spmv_tile_kernel(O
                                 a[j].y + lane_quad<0x93>(a[j + 2].y) + lane_quad<0x4E>(a[j + 4].y) + lane_quad<0x39>(a[j + 6].y)};
             }
         };
-        if (!HALVES) meet(acc, res);
+        if constexpr (COAL) {                                // the two lanes of a row meet; lane `sub` keeps the columns of its parity
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const double sx = he ? acc[2 * m].x : acc[2 * m + 1].x, sy = he ? acc[2 * m].y : acc[2 * m + 1].y;
+                const double mx = he ? acc[2 * m + 1].x : acc[2 * m].x, my = he ? acc[2 * m + 1].y : acc[2 * m].y;
+                res[m] = cplx{mx + lane_quad<0xB1>(sx), my + lane_quad<0xB1>(sy)};
+            }
+        } else if (!HALVES) meet(acc, res);
         if (SPLIT && !HALVES) {                              // res = c0 (M x) + c1 (K x), the coefficients of each column's system
             cplx res2[NOUT];
             meet(acc2, res2);
@@ -1055,6 +1104,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 4) void spmv_tile_kernel(O
         // Epilogue.  (Two buffers: loads first, then the wait for this wavefront's pieces of the next window, which sits before the
         // stores: those drain under the next chunk.)
         if (NBUF == 2) epilogue_loads();
+        if constexpr (COAL) { if (need_b) transpose4(bv); }  // (back to this lane's own row: position m <-> column ocol(m))
         if (mode == MODE_JAC && dslot != 0xFFFFu) {          // the row's own X: it is in the window (1 GB per sweep not read again)
 #pragma unroll
             for (int j = 0; j < NOUT; ++j) xv[j] = win[dslot * 8 + ocol(j)];
@@ -1124,16 +1174,24 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 1 : 4) void spmv_tile_kernel(O
             for (int c = next_active(c1o + 1, ch_end); c < ch_end && left < NBUF; c = next_active(c + 1, ch_end)) ++left;
             if (left < NBUF - 1) { load_list(gr, w0_n, W_n); pre_ready = true; }
         }
+        if constexpr (COAL) {                                // row by row: instruction k of an 8-lane group writes the 128 bytes of row k
+            transpose4(out);
+            if (mode == MODE_AX_J0) transpose4(b2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int b = col0 + tcol(k);
+                if (trow(k) >= nrows || b >= nb) continue;
+                const size_t e = (size_t)(r0 + trow(k)) * nb + b;
+                Y[e] = out[k];
+                if (mode == MODE_AX_J0) const_cast<cplx *>(B)[e] = b2[k];
+            }
+        } else
         if (live) {
 #pragma unroll
             for (int j = 0; j < NOUT; ++j) {
                 const int b = col0 + ocol(j);
                 if (b >= nb) continue;
-#ifdef WAE_TILE_FAKE_COALESCE
-                const size_t e = (size_t)(r0 + min(wv * RPW + 8 * j + (lane >> 3), nrows - 1)) * nb + min(col0 + (lane & 7), nb - 1);
-#else
                 const size_t e = (size_t)row * nb + b;
-#endif
                 Y[e] = out[j];
                 if (mode == MODE_AX_J0) const_cast<cplx *>(B)[e] = b2[j];
             }
