@@ -316,7 +316,8 @@ int wae_p1_shape_sensitivity_flame(int32_t device, int64_t npoints, const double
  * Time `reps` launches of the fused multi-term SpMV on device-resident data with HIP events on the
  * library's own stream; r right-hand sides.  ms_out = average milliseconds per launch. */
 int wae_bench_spmv(wae_family *h, const double *coeffs, int32_t r, int32_t reps, double *ms_out);
-/* the same for an operator of the multigrid hierarchy (which = 0: level operator `level`, 1: restriction from `level`), with its
+/* the same for an operator of the multigrid hierarchy (which = 0: level operator `level`, 1: restriction from `level`, 2: prolongation
+ * to `level`, an in-place update of the fine vector), with its
  * algorithmic bytes per launch (SURVEY 8d layout: 16 + 4 bytes per nonzero and plane with a non-zero coefficient -- 8 + 4 for the
  * real restriction -- row pointers, input and output vectors touched once): the roofline line of the level-1 kernels. */
 int wae_bench_spmv_level(wae_family *h, const double *coeffs, int32_t which, int32_t level, int32_t r, int32_t reps, double *ms_out,
@@ -329,7 +330,8 @@ int wae_bench_triad(int32_t device, int64_t n, int32_t reps, double *gbs_out);
  * damped-Jacobi sweep, product + first sweep, converged-chunk masks -- and on the coarse levels of its hierarchy.  This entry
  * runs ONE such launch so that the parity tests can compare every form with the CPU oracle:
  *   which = 0: the operator of multigrid level `level` (0 = the family itself; >= 1 needs wae_solver_setup);
- *   which = 1: the restriction from `level` to `level + 1` (coefficients ignored).
+ *   which = 1: the restriction from `level` to `level + 1` (coefficients ignored; mode 0);
+ *   which = 2: the prolongation from `level + 1` to `level`, Y = B + P X (coefficients ignored; mode 3).
  *   mode: 0 Y = A X | 1 Y = B - A X | 2 Y = X + w/diag (B - A X) | 3 Y = B + A X | 4 Y = (A X)/diag | 5 Y = (B - A X)/diag
  *         | 6 Y = A X and B2 = w/diag (A X)  (diag = the diagonal of sum_k c_k A_k, w = jac_w)
  *   coeffs: ncoef x T (ncoef = 1: one system; ncoef = r: one coefficient row per column);

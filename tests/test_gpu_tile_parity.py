@@ -80,6 +80,22 @@ def test_tile_kernel_at_benchmark_size_against_scipy(preset, d_expect):
             b = fam.debug_spmv(ct1, Xl, mode=mode, B=None if mode in (0, 6) else Bl, level=lv, which=which, no_tiles=True)
             for u, v in zip(a if mode == 6 else (a,), b if mode == 6 else (b,)):
                 assert np.max(np.abs(u - v)) <= 1e-12 * np.max(np.abs(v)), (which, lv, mode)
+    # the transfers by fine tile (round 4: restriction in two phases, prolongation with the coarse rows of a tile staged in LDS)
+    # against the CSR kernels: which = 1 above; the prolongation Y = B + P X here, also with a converged-chunk mask
+    nf, nc = sizes[(1, 0)]
+    Xc = rng.standard_normal((nc, 64)) + 1j * rng.standard_normal((nc, 64))
+    Bf = rng.standard_normal((nf, 64)) + 1j * rng.standard_normal((nf, 64))
+    for cm in (None, mask):
+        a = fam.debug_spmv(ct1, Xc, mode=3, B=Bf, Y0=Bf, level=0, which=2, cmask=cm)
+        b = fam.debug_spmv(ct1, Xc, mode=3, B=Bf, Y0=Bf, level=0, which=2, cmask=cm, no_tiles=True)
+        assert np.max(np.abs(a - b)) <= 1e-13 * np.max(np.abs(b)) and np.max(np.abs(a - Bf)) > 0.1
+        if cm is not None:
+            off = np.nonzero(~np.repeat(cm, 8))[0]
+            assert np.array_equal(a[:, off], Bf[:, off])
+    Xr = rng.standard_normal((nf, 64)) + 1j * rng.standard_normal((nf, 64))
+    a = fam.debug_spmv(ct1, Xr, mode=0, level=0, which=1, cmask=mask, Y0=np.full((nc, 64), 3 + 7j))
+    b = fam.debug_spmv(ct1, Xr, mode=0, level=0, which=1, cmask=mask, Y0=np.full((nc, 64), 3 + 7j), no_tiles=True)
+    assert np.max(np.abs(a - b)) <= 1e-12 * np.max(np.abs(b))
     # a lock-step solve of 64 shifted systems; the residual is formed with scipy, not with the kernel under test
     B = rng.standard_normal((d, 64)) + 1j * rng.standard_normal((d, 64))
     Xs = fam.solve(ct64, B, tol=1e-10, maxit=300)

@@ -1439,6 +1439,81 @@ __global__ __launch_bounds__(256) void prolong_add_kernel(const int *__restrict_
         X[e] = acc;
     }
 }
+// ---- transfer operators by fine tile (wae_internal.h XferTilesDev) ------------------------------------------------------------
+// One workgroup per (fine tile, 8-column chunk); thread (tid >> 3, tid & 7) = (row or slot, column): the 8 lanes of a row move one
+// 128-byte segment.
+__global__ __launch_bounds__(256) void prolong_tiles_kernel(XferTilesDev T, const cplx *__restrict__ Xc, cplx *__restrict__ X, int nb,
+                                                            const unsigned char *__restrict__ cmask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xt_smem[];
+    cplx *const sl = (cplx *)xt_smem;                        // [slot][8]
+    const int t = blockIdx.x, ch = blockIdx.y;
+    if (cmask && !cmask[ch]) return;
+    const int col = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int b = ch * 8 + col;
+    const bool colok = b < nb;
+    const int s0 = T.tptr[t], ns = T.tptr[t + 1] - s0;
+    for (int s = rl; s < ns; s += 32) sl[s * 8 + col] = colok ? Xc[(size_t)T.clist[s0 + s] * nb + b] : cplx{0.0, 0.0};
+    __syncthreads();
+    const int r0 = T.row_ptr[t], nr = T.row_ptr[t + 1] - r0;
+    for (int r = rl; r < nr; r += 32) {
+        if (!colok) continue;
+        const size_t e = (size_t)(r0 + r) * nb + b;
+        cplx acc = X[e];
+        for (int p = T.pptr[r0 + r]; p < T.pptr[r0 + r + 1]; ++p) {
+            const double a = T.pval[p];
+            const cplx v = sl[(int)T.ploc[p] * 8 + col];
+            acc.x += a * v.x; acc.y += a * v.y;
+        }
+        X[e] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void restrict_tiles_kernel(XferTilesDev T, const cplx *__restrict__ X, cplx *__restrict__ partial, int nb,
+                                                             const unsigned char *__restrict__ cmask) {
+    __shared__ cplx fr[256 * 8];                             // [fine row of the tile][8]
+    const int t = blockIdx.x, ch = blockIdx.y;
+    if (cmask && !cmask[ch]) return;
+    const int col = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int b = ch * 8 + col;
+    const bool colok = b < nb;
+    const int r0 = T.row_ptr[t], nr = T.row_ptr[t + 1] - r0;
+    for (int r = rl; r < nr; r += 32) fr[r * 8 + col] = colok ? X[(size_t)(r0 + r) * nb + b] : cplx{0.0, 0.0};
+    __syncthreads();
+    if (!colok) return;
+    const int s0 = T.tptr[t], ns = T.tptr[t + 1] - s0;
+    for (int s = rl; s < ns; s += 32) {
+        cplx acc = {0.0, 0.0};
+        for (int p = T.rptr[s0 + s]; p < T.rptr[s0 + s + 1]; ++p) {
+            const double a = T.rval[p];
+            const cplx v = fr[(int)T.rloc[p] * 8 + col];
+            acc.x += a * v.x; acc.y += a * v.y;
+        }
+        partial[(size_t)(s0 + s) * nb + b] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void restrict_sum_kernel(XferTilesDev T, const cplx *__restrict__ partial, cplx *__restrict__ Yc, size_t total, int nb,
+                                                           const unsigned char *__restrict__ cmask) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t I = e / nb;
+        const int b = (int)(e - I * nb);
+        if (cmask && !cmask[b >> 3]) continue;
+        cplx acc = {0.0, 0.0};
+        for (int q = T.qptr[I]; q < T.qptr[I + 1]; ++q) { const cplx v = partial[(size_t)T.qidx[q] * nb + b]; acc.x += v.x; acc.y += v.y; }
+        Yc[e] = acc;
+    }
+}
+void launch_prolong_tiles(const XferTilesDev &T, const cplx *Xc, cplx *X, int nb, hipStream_t st, const unsigned char *cmask) {
+    if (!T.ntiles || nb <= 0) return;
+    hipLaunchKernelGGL(prolong_tiles_kernel, dim3(T.ntiles, (nb + 7) / 8), dim3(256), (size_t)T.maxslots * 8 * sizeof(cplx), st, T, Xc, X, nb, cmask);
+    HIP_CHECK(hipGetLastError());
+}
+void launch_restrict_tiles(const XferTilesDev &T, const cplx *X, cplx *partial, cplx *Yc, int nb, hipStream_t st, const unsigned char *cmask) {
+    if (!T.ntiles || nb <= 0) return;
+    hipLaunchKernelGGL(restrict_tiles_kernel, dim3(T.ntiles, (nb + 7) / 8), dim3(256), 0, st, T, X, partial, nb, cmask);
+    const size_t total = (size_t)T.nc * nb;
+    hipLaunchKernelGGL(restrict_sum_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, st, T, partial, Yc, total, nb, cmask);
+    HIP_CHECK(hipGetLastError());
+}
+
 // compact <-> full row sets (penalty-block polish, lib.hip): out[i][b] = X[rows[i]][b];  X[rows[i]][b] += D[i][b]
 __global__ __launch_bounds__(256) void gather_rows_kernel(const cplx *__restrict__ X, const int *__restrict__ rows, size_t total, int nb,
                                                           cplx *__restrict__ out) {

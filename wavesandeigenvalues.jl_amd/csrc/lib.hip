@@ -660,6 +660,77 @@ static void build_restriction_tiles(Transfer &X, const CsrD &R, int wcap, hipStr
     X.r_tiles.ready = true;
 }
 
+// Both transfers by fine tile (wae_internal.h XferTiles): P (fine x coarse, rows in the fine level's tile order), row_ptr = the fine tiles.
+static void build_transfer_tiles(Transfer &X, const CsrD &P, const std::vector<int> &row_ptr, int nbmax, hipStream_t st) {
+    XferTiles &F = X.ft;
+    F.ready = false;
+    const int nt = (int)row_ptr.size() - 1;
+    if (nt <= 0 || row_ptr.back() != P.n) return;
+    std::vector<int> tptr(nt + 1, 0), clist, rptr(1, 0), stamp((size_t)P.m, -1), slot((size_t)P.m, 0);
+    std::vector<unsigned short> ploc(P.col.size()), rloc;
+    std::vector<double> rval;
+    rloc.reserve(P.col.size()); rval.reserve(P.col.size());
+    int maxslots = 0;
+    std::vector<int> cols, cnt, pos;
+    for (int t = 0; t < nt; ++t) {
+        const int a = row_ptr[t], b = row_ptr[t + 1];
+        if (b - a > 256) return;                             // (the kernels stage at most 256 fine rows)
+        cols.clear();
+        for (int p = P.ptr[a]; p < P.ptr[b]; ++p)
+            if (stamp[(size_t)P.col[p]] != t) { stamp[(size_t)P.col[p]] = t; cols.push_back(P.col[p]); }
+        std::sort(cols.begin(), cols.end());
+        const int ns = (int)cols.size();
+        if (ns > 2048) return;
+        maxslots = std::max(maxslots, ns);
+        for (int k = 0; k < ns; ++k) slot[(size_t)cols[k]] = k;
+        const int s0 = (int)clist.size();
+        clist.insert(clist.end(), cols.begin(), cols.end());
+        tptr[t + 1] = s0 + ns;
+        cnt.assign(ns, 0);
+        for (int p = P.ptr[a]; p < P.ptr[b]; ++p) { ploc[p] = (unsigned short)slot[(size_t)P.col[p]]; cnt[slot[(size_t)P.col[p]]]++; }
+        const int e0 = (int)rloc.size();
+        pos.assign(ns + 1, 0);
+        for (int k = 0; k < ns; ++k) pos[k + 1] = pos[k] + cnt[k];
+        rloc.resize((size_t)e0 + pos[ns]); rval.resize((size_t)e0 + pos[ns]);
+        for (int k = 0; k < ns; ++k) rptr.push_back(e0 + pos[k + 1]);
+        for (int i = a; i < b; ++i)                           // ascending fine row inside every slot: a fixed summation order
+            for (int p = P.ptr[i]; p < P.ptr[i + 1]; ++p) {
+                const int k = ploc[p];
+                rloc[(size_t)e0 + pos[k]] = (unsigned short)(i - a);
+                rval[(size_t)e0 + pos[k]] = P.val[p];
+                pos[k]++;
+            }
+    }
+    const int64_t nslots = (int64_t)clist.size();
+    std::vector<int> qptr((size_t)P.m + 1, 0), qidx((size_t)nslots);
+    for (int64_t s = 0; s < nslots; ++s) qptr[(size_t)clist[s] + 1]++;
+    for (int64_t I = 0; I < P.m; ++I) qptr[I + 1] += qptr[I];
+    {
+        std::vector<int> at(qptr.begin(), qptr.end() - 1);
+        for (int64_t s = 0; s < nslots; ++s) qidx[(size_t)at[(size_t)clist[s]]++] = (int)s;     // ascending slot = ascending tile
+    }
+    F.row_ptr.upload(row_ptr.data(), row_ptr.size(), st);
+    F.tptr.upload(tptr.data(), tptr.size(), st);
+    F.clist.upload(clist.data(), clist.size(), st);
+    F.pptr.upload(P.ptr.data(), P.ptr.size(), st);
+    F.ploc.upload(ploc.data(), ploc.size(), st);
+    F.pval.upload(P.val.data(), P.val.size(), st);
+    F.rptr.upload(rptr.data(), rptr.size(), st);
+    F.rloc.upload(rloc.data(), rloc.size(), st);
+    F.rval.upload(rval.data(), rval.size(), st);
+    F.qptr.upload(qptr.data(), qptr.size(), st);
+    F.qidx.upload(qidx.data(), qidx.size(), st);
+    F.partial.alloc((size_t)nslots * (size_t)std::max(nbmax, 8));
+    HIP_CHECK(hipStreamSynchronize(st));                     // (the host vectors die at scope end)
+    XferTilesDev &D = F.dev;
+    D.ntiles = nt; D.maxslots = maxslots; D.nslots = nslots; D.nf = P.n; D.nc = P.m;
+    D.row_ptr = F.row_ptr.p; D.tptr = F.tptr.p; D.clist = F.clist.p; D.pptr = F.pptr.p; D.ploc = F.ploc.p; D.pval = F.pval.p;
+    D.rptr = F.rptr.p; D.rloc = F.rloc.p; D.rval = F.rval.p; D.qptr = F.qptr.p; D.qidx = F.qidx.p;
+    F.ready = true;
+}
+// WAE_XFER_TILES=0: the older transfer kernels (A/B measurements, tests)
+static bool xfer_tiles_on() { const char *e = getenv("WAE_XFER_TILES"); return !(e && atoi(e) == 0); }
+
 // ----------------------------------------------------------------------------------------------------
 // coefficient tables
 // ----------------------------------------------------------------------------------------------------
@@ -739,9 +810,12 @@ static cplx *vcycle(wae_family *h, const Batch &bt, int l, const cplx *b, const 
     const bool additive = h->vc_light && light_add && l == 0 && h->nsweeps == 1;
     if (!additive) launch_spmv(A, pc, bt.cps, x, t, b, 0.0, bt.nb, MODE_RES, st, cm);
     // for op = T/C the transfer operators are unchanged (real): (R A P)^H = R A^H P
-    launch_spmv(h->xfer[l].devR(), h->one_dev.p, 1 << 30, additive ? b : t, h->lb[l + 1].p, nullptr, 0.0, bt.nb, MODE_AX, st, cm);
+    const bool by_tile = h->xfer[l].ft.ready && bt.nb >= 8 && xfer_tiles_on();      // (wae_internal.h XferTiles: level 0, wide batches)
+    if (by_tile) launch_restrict_tiles(h->xfer[l].ft.dev, additive ? b : t, h->xfer[l].ft.partial.p, h->lb[l + 1].p, bt.nb, st, cm);
+    else launch_spmv(h->xfer[l].devR(), h->one_dev.p, 1 << 30, additive ? b : t, h->lb[l + 1].p, nullptr, 0.0, bt.nb, MODE_AX, st, cm);
     const cplx *xc = vcycle(h, bt, l + 1, h->lb[l + 1].p, cm);
-    launch_prolong_add(h->xfer[l].p_ptr.p, h->xfer[l].p_col.p, h->xfer[l].p_val.p, h->xfer[l].nf, xc, x, bt.nb, st, cm);
+    if (by_tile) launch_prolong_tiles(h->xfer[l].ft.dev, xc, x, bt.nb, st, cm);
+    else launch_prolong_add(h->xfer[l].p_ptr.p, h->xfer[l].p_col.p, h->xfer[l].p_val.p, h->xfer[l].nf, xc, x, bt.nb, st, cm);
     // Post-smoothing on the coarse levels (WAE_VC_POST_COARSE): 1 always, 0 never, 2 (default) everywhere but in the projected phase of
     // a contour integral.  A solve that starts from a projected guess (216 of the 256 points of the benchmark contour) takes 1-5 steps:
     // there a cheaper cycle beats a better one (measured at 1M unknowns: projected phase 1.17 -> 0.99 s without the coarse
@@ -2301,6 +2375,7 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
                               upload_transfer(l1.xfer0, L0, s2);
                               const int tile_r = getenv("WAE_TILE_RESTRICT") ? atoi(getenv("WAE_TILE_RESTRICT")) : 1;
                               if (with_tiles && tile_r) build_restriction_tiles(l1.xfer0, L0.R, wcap, s2);
+                              if (!h->tile_row_ptr.empty() && xfer_tiles_on()) build_transfer_tiles(l1.xfer0, L0.P, h->tile_row_ptr, h->NB, s2);
                           });
                           const std::vector<CsrZ> &pl1 = l1.planes.empty() ? L0.coarse_planes : l1.planes;
                           l1.slot_plane = build_levelop(l1.op, pl1, s3, WAE_LEVEL_SYM_TOL);
@@ -2400,6 +2475,7 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
             }
             h->slot_plane[l + 1] = build_levelop(h->ops[l + 1], lv[l].coarse_planes, st, WAE_LEVEL_SYM_TOL);
             upload_transfer(h->xfer[l], lv[l], st);
+            if (l == 0 && !h->tile_row_ptr.empty() && xfer_tiles_on()) build_transfer_tiles(h->xfer[0], lv[0].P, h->tile_row_ptr, h->NB, st);
         }
         lap("levels >= 2");
         // dense planes of the coarsest level (plane order, row-major)
@@ -3157,24 +3233,24 @@ int wae_debug_spmv(wae_family *h, int32_t which, int32_t level, int32_t mode, co
                    const double *B, double *Y, double *B2, int32_t r, int32_t op, double jac_w, const uint8_t *cmask, int32_t flags,
                    int64_t *n_in_q, int64_t *n_out_q) {
     return guarded([&]() {
-        WAE_REQUIRE(h && (which == 0 || which == 1) && level >= 0 && op >= 0 && op <= 2, "bad argument");
+        WAE_REQUIRE(h && which >= 0 && which <= 2 && level >= 0 && op >= 0 && op <= 2, "bad argument");
         WAE_REQUIRE(level == 0 || h->solver_ready, "levels >= 1 need wae_solver_setup");
         // (the last level of a hierarchy is dense: it has no sparse operator to launch)
         WAE_REQUIRE(which == 0 ? (level == 0 || level < (int)h->ops.size() - 1) : level < (int)h->xfer.size(), "no such level");
-        const int64_t n_in = which == 0 ? h->ops[level].n : h->xfer[level].nf;
-        const int64_t n_out = which == 0 ? h->ops[level].n : h->xfer[level].nc;
+        const int64_t n_in = which == 0 ? h->ops[level].n : (which == 1 ? h->xfer[level].nf : h->xfer[level].nc);
+        const int64_t n_out = which == 0 ? h->ops[level].n : (which == 1 ? h->xfer[level].nc : h->xfer[level].nf);
         if (n_in_q) *n_in_q = n_in;
         if (n_out_q) *n_out_q = n_out;
         if (!X && !Y) return WAE_OK;                               // size query
         WAE_REQUIRE(X && Y && r > 0 && r <= 256, "bad argument (1 <= r <= 256)");
-        WAE_REQUIRE(which == 1 || (coeffs && (ncoef == 1 || ncoef == r)), "ncoef must be 1 or r");
-        WAE_REQUIRE(mode >= MODE_AX && mode <= MODE_AX_J0 && (which == 0 || mode == MODE_AX), "bad mode");
+        WAE_REQUIRE(which != 0 || (coeffs && (ncoef == 1 || ncoef == r)), "ncoef must be 1 or r");
+        WAE_REQUIRE(mode >= MODE_AX && mode <= MODE_AX_J0 && (which == 0 || mode == (which == 1 ? MODE_AX : MODE_ADD)), "bad mode");
         WAE_REQUIRE(B || mode == MODE_AX || mode == MODE_AX_DS || mode == MODE_AX_J0, "this mode reads B");
         WAE_REQUIRE(mode != MODE_AX_J0 || B2, "mode 6 writes B2");
         HIP_CHECK(hipSetDevice(h->device));
         hipStream_t st = h->stream;
-        const int *perm = level == 0 && which == 0 ? h->perm() : nullptr;
-        const int *perm_in = which == 1 && level == 0 ? h->perm() : perm;
+        const int *perm = level == 0 && which != 1 ? h->perm() : nullptr;                 // (numbering of the OUTPUT rows: level 0 is the caller's)
+        const int *perm_in = level == 0 && which != 2 ? h->perm() : nullptr;
         DevBuf<cplx> xc, yc, xi, yi, bi, pcd;
         DevBuf<unsigned char> cm;
         const size_t cin = (size_t)n_in * r, cout = (size_t)n_out * r;
@@ -3208,6 +3284,15 @@ int wae_debug_spmv(wae_family *h, int32_t which, int32_t level, int32_t mode, co
             A = h->xfer[level].devR();
         }
         if (flags & 1) A.tiles = nullptr;
+        const Transfer *xf = which == 0 ? nullptr : &h->xfer[level];
+        const bool by_tile = xf && xf->ft.ready && !(flags & 1) && r >= 8 && (size_t)r <= xf->ft.partial.n / (size_t)std::max<int64_t>(xf->ft.dev.nslots, 1);
+        if (which == 2) {                                           // Y = B + P X, in place on the staged B
+            launch_copy(bi.p, yi.p, cout, st);                      // (masked chunks: Y and B agree there only if the caller passed them equal)
+            if (by_tile) launch_prolong_tiles(xf->ft.dev, xi.p, yi.p, r, st, cmask ? cm.p : nullptr);
+            else launch_prolong_add(xf->p_ptr.p, xf->p_col.p, xf->p_val.p, xf->nf, xi.p, yi.p, r, st, cmask ? cm.p : nullptr);
+        } else if (which == 1 && by_tile) {
+            launch_restrict_tiles(xf->ft.dev, xi.p, xf->ft.partial.p, yi.p, r, st, cmask ? cm.p : nullptr);
+        } else
         launch_spmv(A, which == 0 ? pcd.p : h->one_dev.p, cps, xi.p, yi.p, (mode == MODE_AX || mode == MODE_AX_DS) ? nullptr : bi.p, jac_w, r, mode, st,
                     cmask ? cm.p : nullptr);
         launch_inter_to_colmajor(yi.p, r, n_out, r, yc.p, st, perm);
@@ -3225,12 +3310,13 @@ int wae_debug_spmv(wae_family *h, int32_t which, int32_t level, int32_t mode, co
 int wae_bench_spmv_level(wae_family *h, const double *coeffs, int32_t which, int32_t level, int32_t r, int32_t reps, double *ms_out,
                          int64_t *bytes_out) {
     return guarded([&]() {
-        WAE_REQUIRE(h && coeffs && (which == 0 || which == 1) && level >= 0 && r > 0 && r <= 256 && reps > 0 && ms_out, "bad argument");
+        WAE_REQUIRE(h && coeffs && which >= 0 && which <= 2 && level >= 0 && r > 0 && r <= 256 && reps > 0 && ms_out, "bad argument");
         require_solver(h);
         WAE_REQUIRE(which == 0 ? (level == 0 || level < (int)h->ops.size() - 1) : level < (int)h->xfer.size(), "no such level");
         HIP_CHECK(hipSetDevice(h->device));
         hipStream_t st = h->stream;
-        const int64_t n_in = which == 0 ? h->ops[level].n : h->xfer[level].nf, n_out = which == 0 ? h->ops[level].n : h->xfer[level].nc;
+        const int64_t n_in = which == 0 ? h->ops[level].n : (which == 1 ? h->xfer[level].nf : h->xfer[level].nc);
+        const int64_t n_out = which == 0 ? h->ops[level].n : (which == 1 ? h->xfer[level].nc : h->xfer[level].nf);
         DevBuf<cplx> x, y, pcd;
         x.alloc((size_t)n_in * r); y.alloc((size_t)n_out * r);
         std::vector<cplx> hx((size_t)n_in * r);
@@ -3263,13 +3349,25 @@ int wae_bench_spmv_level(wae_family *h, const double *coeffs, int32_t which, int
             bytes = (int64_t)h->xfer[level].r_col.n * 12 + (n_out + 1) * 4;       // real values: 8 + 4 bytes per entry
         }
         bytes += (int64_t)r * (n_in + n_out) * 16;
+        if (which == 2) bytes += (int64_t)r * n_out * 16;          // (the prolongation updates the fine vector in place: read + write)
         if (bytes_out) *bytes_out = bytes;
-        for (int i = 0; i < 3; ++i) launch_spmv(A, pcp, 1 << 30, x.p, y.p, nullptr, 0.0, r, MODE_AX, st);
+        const Transfer *xf = which == 0 ? nullptr : &h->xfer[level];
+        const bool by_tile = xf && xf->ft.ready && r >= 8 && xfer_tiles_on() &&
+                             (size_t)r <= xf->ft.partial.n / (size_t)std::max<int64_t>(xf->ft.dev.nslots, 1);
+        auto one = [&]() {
+            if (which == 2) {
+                if (by_tile) launch_prolong_tiles(xf->ft.dev, x.p, y.p, r, st);
+                else launch_prolong_add(xf->p_ptr.p, xf->p_col.p, xf->p_val.p, xf->nf, x.p, y.p, r, st, nullptr);
+            } else if (which == 1 && by_tile) launch_restrict_tiles(xf->ft.dev, x.p, xf->ft.partial.p, y.p, r, st);
+            else launch_spmv(A, pcp, 1 << 30, x.p, y.p, nullptr, 0.0, r, MODE_AX, st);
+        };
+        if (which == 2) HIP_CHECK(hipMemsetAsync(y.p, 0, (size_t)n_out * r * sizeof(cplx), st));
+        for (int i = 0; i < 3; ++i) one();
         hipEvent_t e0, e1;
         HIP_CHECK(hipEventCreate(&e0));
         HIP_CHECK(hipEventCreate(&e1));
         HIP_CHECK(hipEventRecord(e0, st));
-        for (int i = 0; i < reps; ++i) launch_spmv(A, pcp, 1 << 30, x.p, y.p, nullptr, 0.0, r, MODE_AX, st);
+        for (int i = 0; i < reps; ++i) one();
         HIP_CHECK(hipEventRecord(e1, st));
         HIP_CHECK(hipEventSynchronize(e1));
         float ms = 0.f;
