@@ -80,8 +80,8 @@ def test_tile_kernel_at_benchmark_size_against_scipy(preset, d_expect):
             b = fam.debug_spmv(ct1, Xl, mode=mode, B=None if mode in (0, 6) else Bl, level=lv, which=which, no_tiles=True)
             for u, v in zip(a if mode == 6 else (a,), b if mode == 6 else (b,)):
                 assert np.max(np.abs(u - v)) <= 1e-12 * np.max(np.abs(v)), (which, lv, mode)
-    # the transfers by fine tile (round 4: restriction in two phases, prolongation with the coarse rows of a tile staged in LDS)
-    # against the CSR kernels: which = 1 above; the prolongation Y = B + P X here, also with a converged-chunk mask
+    # the prolongation by fine tile (round 4: the coarse rows a tile talks to staged in LDS) against the gather kernel it replaces:
+    # Y = B + P X, also with a converged-chunk mask; and the restriction once more under a mask
     nf, nc = sizes[(1, 0)]
     Xc = rng.standard_normal((nc, 64)) + 1j * rng.standard_normal((nc, 64))
     Bf = rng.standard_normal((nf, 64)) + 1j * rng.standard_normal((nf, 64))

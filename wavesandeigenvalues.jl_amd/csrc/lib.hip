@@ -660,75 +660,46 @@ static void build_restriction_tiles(Transfer &X, const CsrD &R, int wcap, hipStr
     X.r_tiles.ready = true;
 }
 
-// Both transfers by fine tile (wae_internal.h XferTiles): P (fine x coarse, rows in the fine level's tile order), row_ptr = the fine tiles.
-static void build_transfer_tiles(Transfer &X, const CsrD &P, const std::vector<int> &row_ptr, int nbmax, hipStream_t st) {
+// The prolongation by fine tile (wae_internal.h XferTiles): P (fine x coarse, rows in the fine level's tile order), row_ptr = the fine tiles.
+static void build_transfer_tiles(Transfer &X, const CsrD &P, const std::vector<int> &row_ptr, hipStream_t st) {
     XferTiles &F = X.ft;
     F.ready = false;
     const int nt = (int)row_ptr.size() - 1;
     if (nt <= 0 || row_ptr.back() != P.n) return;
-    std::vector<int> tptr(nt + 1, 0), clist, rptr(1, 0), stamp((size_t)P.m, -1), slot((size_t)P.m, 0);
-    std::vector<unsigned short> ploc(P.col.size()), rloc;
-    std::vector<double> rval;
-    rloc.reserve(P.col.size()); rval.reserve(P.col.size());
-    int maxslots = 0;
-    std::vector<int> cols, cnt, pos;
+    std::vector<int> tptr(nt + 1, 0), clist, stamp((size_t)P.m, -1), slot((size_t)P.m, 0);
+    std::vector<unsigned short> ploc(P.col.size());
+    int maxslots = 0, maxent = 0;
+    std::vector<int> cols;
     for (int t = 0; t < nt; ++t) {
         const int a = row_ptr[t], b = row_ptr[t + 1];
-        if (b - a > 256) return;                             // (the kernels stage at most 256 fine rows)
+        if (b - a > 256) return;                             // (the kernel walks at most 256 fine rows per workgroup)
         cols.clear();
         for (int p = P.ptr[a]; p < P.ptr[b]; ++p)
             if (stamp[(size_t)P.col[p]] != t) { stamp[(size_t)P.col[p]] = t; cols.push_back(P.col[p]); }
         std::sort(cols.begin(), cols.end());
         const int ns = (int)cols.size();
-        if (ns > 2048) return;
         maxslots = std::max(maxslots, ns);
+        maxent = std::max(maxent, P.ptr[b] - P.ptr[a]);
         for (int k = 0; k < ns; ++k) slot[(size_t)cols[k]] = k;
-        const int s0 = (int)clist.size();
         clist.insert(clist.end(), cols.begin(), cols.end());
-        tptr[t + 1] = s0 + ns;
-        cnt.assign(ns, 0);
-        for (int p = P.ptr[a]; p < P.ptr[b]; ++p) { ploc[p] = (unsigned short)slot[(size_t)P.col[p]]; cnt[slot[(size_t)P.col[p]]]++; }
-        const int e0 = (int)rloc.size();
-        pos.assign(ns + 1, 0);
-        for (int k = 0; k < ns; ++k) pos[k + 1] = pos[k] + cnt[k];
-        rloc.resize((size_t)e0 + pos[ns]); rval.resize((size_t)e0 + pos[ns]);
-        for (int k = 0; k < ns; ++k) rptr.push_back(e0 + pos[k + 1]);
-        for (int i = a; i < b; ++i)                           // ascending fine row inside every slot: a fixed summation order
-            for (int p = P.ptr[i]; p < P.ptr[i + 1]; ++p) {
-                const int k = ploc[p];
-                rloc[(size_t)e0 + pos[k]] = (unsigned short)(i - a);
-                rval[(size_t)e0 + pos[k]] = P.val[p];
-                pos[k]++;
-            }
+        tptr[t + 1] = (int)clist.size();
+        for (int p = P.ptr[a]; p < P.ptr[b]; ++p) ploc[p] = (unsigned short)slot[(size_t)P.col[p]];
     }
-    const int64_t nslots = (int64_t)clist.size();
-    std::vector<int> qptr((size_t)P.m + 1, 0), qidx((size_t)nslots);
-    for (int64_t s = 0; s < nslots; ++s) qptr[(size_t)clist[s] + 1]++;
-    for (int64_t I = 0; I < P.m; ++I) qptr[I + 1] += qptr[I];
-    {
-        std::vector<int> at(qptr.begin(), qptr.end() - 1);
-        for (int64_t s = 0; s < nslots; ++s) qidx[(size_t)at[(size_t)clist[s]]++] = (int)s;     // ascending slot = ascending tile
-    }
+    maxent = (maxent + 3) & ~3;
+    if ((size_t)maxslots * 128 + (size_t)maxent * 10 + 1100 > 60 * 1024) return;       // (LDS of the kernel)
     F.row_ptr.upload(row_ptr.data(), row_ptr.size(), st);
     F.tptr.upload(tptr.data(), tptr.size(), st);
     F.clist.upload(clist.data(), clist.size(), st);
     F.pptr.upload(P.ptr.data(), P.ptr.size(), st);
     F.ploc.upload(ploc.data(), ploc.size(), st);
     F.pval.upload(P.val.data(), P.val.size(), st);
-    F.rptr.upload(rptr.data(), rptr.size(), st);
-    F.rloc.upload(rloc.data(), rloc.size(), st);
-    F.rval.upload(rval.data(), rval.size(), st);
-    F.qptr.upload(qptr.data(), qptr.size(), st);
-    F.qidx.upload(qidx.data(), qidx.size(), st);
-    F.partial.alloc((size_t)nslots * (size_t)std::max(nbmax, 8));
     HIP_CHECK(hipStreamSynchronize(st));                     // (the host vectors die at scope end)
     XferTilesDev &D = F.dev;
-    D.ntiles = nt; D.maxslots = maxslots; D.nslots = nslots; D.nf = P.n; D.nc = P.m;
+    D.ntiles = nt; D.maxslots = maxslots; D.maxent = maxent; D.nslots = (int64_t)clist.size(); D.nf = P.n; D.nc = P.m;
     D.row_ptr = F.row_ptr.p; D.tptr = F.tptr.p; D.clist = F.clist.p; D.pptr = F.pptr.p; D.ploc = F.ploc.p; D.pval = F.pval.p;
-    D.rptr = F.rptr.p; D.rloc = F.rloc.p; D.rval = F.rval.p; D.qptr = F.qptr.p; D.qidx = F.qidx.p;
     F.ready = true;
 }
-// WAE_XFER_TILES=0: the older transfer kernels (A/B measurements, tests)
+// WAE_XFER_TILES=0: the older prolongation kernel (A/B measurements, tests)
 static bool xfer_tiles_on() { const char *e = getenv("WAE_XFER_TILES"); return !(e && atoi(e) == 0); }
 
 // ----------------------------------------------------------------------------------------------------
@@ -811,8 +782,7 @@ static cplx *vcycle(wae_family *h, const Batch &bt, int l, const cplx *b, const 
     if (!additive) launch_spmv(A, pc, bt.cps, x, t, b, 0.0, bt.nb, MODE_RES, st, cm);
     // for op = T/C the transfer operators are unchanged (real): (R A P)^H = R A^H P
     const bool by_tile = h->xfer[l].ft.ready && bt.nb >= 8 && xfer_tiles_on();      // (wae_internal.h XferTiles: level 0, wide batches)
-    if (by_tile) launch_restrict_tiles(h->xfer[l].ft.dev, additive ? b : t, h->xfer[l].ft.partial.p, h->lb[l + 1].p, bt.nb, st, cm);
-    else launch_spmv(h->xfer[l].devR(), h->one_dev.p, 1 << 30, additive ? b : t, h->lb[l + 1].p, nullptr, 0.0, bt.nb, MODE_AX, st, cm);
+    launch_spmv(h->xfer[l].devR(), h->one_dev.p, 1 << 30, additive ? b : t, h->lb[l + 1].p, nullptr, 0.0, bt.nb, MODE_AX, st, cm);
     const cplx *xc = vcycle(h, bt, l + 1, h->lb[l + 1].p, cm);
     if (by_tile) launch_prolong_tiles(h->xfer[l].ft.dev, xc, x, bt.nb, st, cm);
     else launch_prolong_add(h->xfer[l].p_ptr.p, h->xfer[l].p_col.p, h->xfer[l].p_val.p, h->xfer[l].nf, xc, x, bt.nb, st, cm);
@@ -2375,7 +2345,7 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
                               upload_transfer(l1.xfer0, L0, s2);
                               const int tile_r = getenv("WAE_TILE_RESTRICT") ? atoi(getenv("WAE_TILE_RESTRICT")) : 1;
                               if (with_tiles && tile_r) build_restriction_tiles(l1.xfer0, L0.R, wcap, s2);
-                              if (!h->tile_row_ptr.empty() && xfer_tiles_on()) build_transfer_tiles(l1.xfer0, L0.P, h->tile_row_ptr, h->NB, s2);
+                              if (!h->tile_row_ptr.empty() && xfer_tiles_on()) build_transfer_tiles(l1.xfer0, L0.P, h->tile_row_ptr, s2);
                           });
                           const std::vector<CsrZ> &pl1 = l1.planes.empty() ? L0.coarse_planes : l1.planes;
                           l1.slot_plane = build_levelop(l1.op, pl1, s3, WAE_LEVEL_SYM_TOL);
@@ -2475,7 +2445,7 @@ int wae_solver_setup(wae_family *h, const double *coeffs_ref, const double *opts
             }
             h->slot_plane[l + 1] = build_levelop(h->ops[l + 1], lv[l].coarse_planes, st, WAE_LEVEL_SYM_TOL);
             upload_transfer(h->xfer[l], lv[l], st);
-            if (l == 0 && !h->tile_row_ptr.empty() && xfer_tiles_on()) build_transfer_tiles(h->xfer[0], lv[0].P, h->tile_row_ptr, h->NB, st);
+            if (l == 0 && !h->tile_row_ptr.empty() && xfer_tiles_on()) build_transfer_tiles(h->xfer[0], lv[0].P, h->tile_row_ptr, st);
         }
         lap("levels >= 2");
         // dense planes of the coarsest level (plane order, row-major)
@@ -3285,13 +3255,11 @@ int wae_debug_spmv(wae_family *h, int32_t which, int32_t level, int32_t mode, co
         }
         if (flags & 1) A.tiles = nullptr;
         const Transfer *xf = which == 0 ? nullptr : &h->xfer[level];
-        const bool by_tile = xf && xf->ft.ready && !(flags & 1) && r >= 8 && (size_t)r <= xf->ft.partial.n / (size_t)std::max<int64_t>(xf->ft.dev.nslots, 1);
+        const bool by_tile = xf && xf->ft.ready && !(flags & 1) && r >= 8;
         if (which == 2) {                                           // Y = B + P X, in place on the staged B
             launch_copy(bi.p, yi.p, cout, st);                      // (masked chunks: Y and B agree there only if the caller passed them equal)
             if (by_tile) launch_prolong_tiles(xf->ft.dev, xi.p, yi.p, r, st, cmask ? cm.p : nullptr);
             else launch_prolong_add(xf->p_ptr.p, xf->p_col.p, xf->p_val.p, xf->nf, xi.p, yi.p, r, st, cmask ? cm.p : nullptr);
-        } else if (which == 1 && by_tile) {
-            launch_restrict_tiles(xf->ft.dev, xi.p, xf->ft.partial.p, yi.p, r, st, cmask ? cm.p : nullptr);
         } else
         launch_spmv(A, which == 0 ? pcd.p : h->one_dev.p, cps, xi.p, yi.p, (mode == MODE_AX || mode == MODE_AX_DS) ? nullptr : bi.p, jac_w, r, mode, st,
                     cmask ? cm.p : nullptr);
@@ -3352,14 +3320,12 @@ int wae_bench_spmv_level(wae_family *h, const double *coeffs, int32_t which, int
         if (which == 2) bytes += (int64_t)r * n_out * 16;          // (the prolongation updates the fine vector in place: read + write)
         if (bytes_out) *bytes_out = bytes;
         const Transfer *xf = which == 0 ? nullptr : &h->xfer[level];
-        const bool by_tile = xf && xf->ft.ready && r >= 8 && xfer_tiles_on() &&
-                             (size_t)r <= xf->ft.partial.n / (size_t)std::max<int64_t>(xf->ft.dev.nslots, 1);
+        const bool by_tile = xf && xf->ft.ready && r >= 8 && xfer_tiles_on();
         auto one = [&]() {
             if (which == 2) {
                 if (by_tile) launch_prolong_tiles(xf->ft.dev, x.p, y.p, r, st);
                 else launch_prolong_add(xf->p_ptr.p, xf->p_col.p, xf->p_val.p, xf->nf, x.p, y.p, r, st, nullptr);
-            } else if (which == 1 && by_tile) launch_restrict_tiles(xf->ft.dev, x.p, xf->ft.partial.p, y.p, r, st);
-            else launch_spmv(A, pcp, 1 << 30, x.p, y.p, nullptr, 0.0, r, MODE_AX, st);
+            } else launch_spmv(A, pcp, 1 << 30, x.p, y.p, nullptr, 0.0, r, MODE_AX, st);
         };
         if (which == 2) HIP_CHECK(hipMemsetAsync(y.p, 0, (size_t)n_out * r * sizeof(cplx), st));
         for (int i = 0; i < 3; ++i) one();

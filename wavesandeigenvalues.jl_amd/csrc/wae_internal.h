@@ -202,44 +202,34 @@ struct LevelOp {                    // sum_q pc[q] * plane_q  at one multigrid l
     std::vector<CsrZ> planes;
 };
 
-// Transfer operators by FINE tile (round 4).  The coarse rows a fine tile of 256 rows talks to (its "slots", ~70 with a smoothed
-// prolongator) fit LDS at any chunk width, so both transfers become streams over the fine multivector:
-//   prolongation  x += P e : a tile's slots of e are staged in LDS (9 KB per 8-column chunk), the fine rows stream through;
-//   restriction   r_c = R r: a tile's rows of r are staged in LDS (32 KB per chunk), every slot's partial sum over THIS tile's rows
-//                            goes to a partial buffer (phase A); a coarse row sums its <= ~8 partials in a fixed order (phase B).
-// Against the older forms -- prolong_add_kernel gathering ~3.4 coarse rows per fine row from L2 (3.5 GB of gathers per launch at 1M
-// unknowns and 64 columns), the restriction as a tile kernel over COARSE rows whose fine-level windows re-gather the fine vector 2.8
-// times -- the fine vector is read once, coalesced, and nothing else is large.  Deterministic (no atomics).
+// Prolongation by FINE tile (round 4).  The coarse rows a fine tile of 256 rows talks to (its "slots", ~130 with a smoothed
+// prolongator) fit LDS at any chunk width, so x += P e becomes a stream over the fine multivector: a tile's slots of e are staged in
+// LDS (16 KB per 8-column chunk), its fine rows stream through, and nothing else is large -- where prolong_add_kernel gathers ~5
+// coarse rows per fine row from L2.  Deterministic.
 struct XferTilesDev {
-    int ntiles = 0, maxslots = 0;
+    int ntiles = 0, maxslots = 0, maxent = 0;   // (maxent: most transfer entries of one tile)
     int64_t nslots = 0, nf = 0, nc = 0;
     const int *row_ptr = nullptr;           // fine tile t owns fine rows row_ptr[t] .. row_ptr[t+1]-1 (<= 256)
-    const int *tptr = nullptr;              // its slots: tptr[t] .. tptr[t+1]-1 (index into clist and into the partial rows)
+    const int *tptr = nullptr;              // its slots: tptr[t] .. tptr[t+1]-1 (index into clist)
     const int *clist = nullptr;             // coarse row of a slot
-    const int *pptr = nullptr;              // prolongation, per fine row: entries pptr[i] .. pptr[i+1]-1
+    const int *pptr = nullptr;              // per fine row: entries pptr[i] .. pptr[i+1]-1
     const unsigned short *ploc = nullptr;   //   slot of the entry, local to the row's tile
     const double *pval = nullptr;
-    const int *rptr = nullptr;              // restriction, per slot: entries rptr[s] .. rptr[s+1]-1
-    const unsigned short *rloc = nullptr;   //   fine row of the entry, local to the tile
-    const double *rval = nullptr;
-    const int *qptr = nullptr, *qidx = nullptr;   // phase B, per coarse row: its partial rows (slots), ascending
 };
 struct XferTiles {
-    DevBuf<int> row_ptr, tptr, clist, pptr, rptr, qptr, qidx;
-    DevBuf<unsigned short> ploc, rloc;
-    DevBuf<double> pval, rval;
-    DevBuf<cplx> partial;           // nslots x (batch width) partial sums of phase A
+    DevBuf<int> row_ptr, tptr, clist, pptr;
+    DevBuf<unsigned short> ploc;
+    DevBuf<double> pval;
     XferTilesDev dev;
     bool ready = false;
 };
 void launch_prolong_tiles(const XferTilesDev &T, const cplx *Xc, cplx *X, int nb, hipStream_t s, const unsigned char *cmask = nullptr);
-void launch_restrict_tiles(const XferTilesDev &T, const cplx *X, cplx *partial, cplx *Yc, int nb, hipStream_t s, const unsigned char *cmask = nullptr);
 
 struct Transfer {                   // P (n_fine x n_coarse) and R = P^T as single-plane real operators
     int64_t nf = 0, nc = 0;
     DevBuf<int> p_ptr, p_col, r_ptr, r_col;
     DevBuf<double> p_val, r_val;
-    XferTiles ft;                   // both transfers by fine tile (level 0 of a hierarchy whose fine level is renumbered into tiles)
+    XferTiles ft;                   // the prolongation by fine tile (level 0 of a hierarchy whose fine level is renumbered into tiles)
     TileStore r_tiles;              // R in tile-local storage (both levels renumbered into tiles): unit coefficient, no side rows
     OpDev devP() const;
     OpDev devR() const;
