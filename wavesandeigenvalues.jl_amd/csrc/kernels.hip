@@ -2419,39 +2419,53 @@ __global__ __launch_bounds__(256) void lincomb_rep8_kernel(const cplx *__restric
     const int R = 256 / l;
     const int c = tid % l, rl = tid / l;
     if (rl >= R) return;
-    for (int64_t row = (int64_t)blockIdx.x * R + rl; row < n; row += (int64_t)gridDim.x * R) {
-        const size_t eq = (size_t)row * l + c;
-        cplx acc[LRS];
+    // TWO rows per thread and step (round 4): every coefficient read from LDS serves both, and eight basis entries are in flight per
+    // thread instead of four (1 214 -> ~900 us for the 40 x 8 x 1M basis of the benchmark: the kernel was bound by its LDS reads, one
+    // 16-byte coefficient per basis entry and system)
+    for (int64_t row0 = ((int64_t)blockIdx.x * R + rl) * 2; row0 < n; row0 += (int64_t)gridDim.x * R * 2) {
+        const bool two = row0 + 1 < n;
+        const size_t eq0 = (size_t)row0 * l + c, eq1 = two ? eq0 + l : eq0;
+        cplx acc[2][LRS];
 #pragma unroll
-        for (int s = 0; s < LRS; ++s) acc[s] = (accumulate && s < nsys) ? X[(size_t)row * nb + s * l + c] : cplx{0.0, 0.0};
+        for (int s = 0; s < LRS; ++s) {
+            acc[0][s] = (accumulate && s < nsys) ? X[(size_t)row0 * nb + s * l + c] : cplx{0.0, 0.0};
+            acc[1][s] = (accumulate && s < nsys && two) ? X[(size_t)(row0 + 1) * nb + s * l + c] : cplx{0.0, 0.0};
+        }
         int i = 0;
         for (; i + 4 <= nv; i += 4) {
-            cplx v[4];
+            cplx v0[4], v1[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = Q[(size_t)(i + u) * stride + eq];
+            for (int u = 0; u < 4; ++u) { v0[u] = Q[(size_t)(i + u) * stride + eq0]; v1[u] = Q[(size_t)(i + u) * stride + eq1]; }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int s = 0; s < LRS; ++s)
                     if (s < nsys) {
                         const cplx cf = hs[(i + u) * nb + s * l + c];
-                        acc[s].x += cf.x * v[u].x - cf.y * v[u].y;
-                        acc[s].y += cf.x * v[u].y + cf.y * v[u].x;
+                        acc[0][s].x += cf.x * v0[u].x - cf.y * v0[u].y;
+                        acc[0][s].y += cf.x * v0[u].y + cf.y * v0[u].x;
+                        acc[1][s].x += cf.x * v1[u].x - cf.y * v1[u].y;
+                        acc[1][s].y += cf.x * v1[u].y + cf.y * v1[u].x;
                     }
         }
         for (; i < nv; ++i) {
-            const cplx v = Q[(size_t)i * stride + eq];
+            const cplx v0 = Q[(size_t)i * stride + eq0], v1 = Q[(size_t)i * stride + eq1];
 #pragma unroll
             for (int s = 0; s < LRS; ++s)
                 if (s < nsys) {
                     const cplx cf = hs[i * nb + s * l + c];
-                    acc[s].x += cf.x * v.x - cf.y * v.y;
-                    acc[s].y += cf.x * v.y + cf.y * v.x;
+                    acc[0][s].x += cf.x * v0.x - cf.y * v0.y;
+                    acc[0][s].y += cf.x * v0.y + cf.y * v0.x;
+                    acc[1][s].x += cf.x * v1.x - cf.y * v1.y;
+                    acc[1][s].y += cf.x * v1.y + cf.y * v1.x;
                 }
         }
 #pragma unroll
         for (int s = 0; s < LRS; ++s)
-            if (s < nsys) X[(size_t)row * nb + s * l + c] = acc[s];
+            if (s < nsys) {
+                X[(size_t)row0 * nb + s * l + c] = acc[0][s];
+                if (two) X[(size_t)(row0 + 1) * nb + s * l + c] = acc[1][s];
+            }
     }
 }
 void launch_lincomb_rep(const cplx *Q, size_t stride, int nv, const cplx *y, cplx *X, int64_t n, int nb, int l, hipStream_t st) {
@@ -2459,7 +2473,7 @@ void launch_lincomb_rep(const cplx *Q, size_t stride, int nv, const cplx *y, cpl
     if (nb > 256) throw WaeError(WAE_ERR_INVALID, "lincomb_rep: nb must be in 1..256");
     if (l >= 4 && l <= 256 && nb % l == 0 && nb / l <= LRS) {
         const int R = 256 / l, nsys = nb / l;
-        const unsigned grid = (unsigned)std::min<int64_t>((n + R - 1) / R, 4096);
+        const unsigned grid = (unsigned)std::min<int64_t>((n + 2 * R - 1) / (2 * R), 4096);
         const int maxv = std::max(1, AX_MAXC / nb);
         int done = 0;
         do {
