@@ -15,7 +15,7 @@ l, K, rb = 8, 2, int(os.environ.get('RB', 40))
 L, pb = annulus_family(preset, tau=2e-4)
 d = pb["d"]
 L.solver_tol, L.solver_maxit, L.solver_ref = 1e-10, 400, 2 * np.pi * 500.0
-L.solver_opts = {"batch": 64, "restart": 40, "sweeps": 1, "jacobi_weight": 0.8, "probe_columns": l, "snapshots": rb}
+L.solver_opts = {"batch": 64, "restart": 40, "sweeps": 1, "jacobi_weight": float(os.environ.get("JACW", 0.8)), "probe_columns": l, "snapshots": rb}
 warm_up_dense_linalg(torch.device("cuda", 0), cols=l, K=K)
 L.ensure_solver()
 G = np.array([150 - 150j, 1000 - 150j, 1000 + 150j, 150 + 150j]) * 2 * np.pi

@@ -109,6 +109,8 @@ int wae_spmv_sum_multi(wae_family *h, const double *coeffs, const double *X, dou
  *   [7] bit mask (as a double) of terms kept OUT of the shape matrix that the strength graph, the aggregates and the
  *       prolongator smoothing are built from (0).  Bloch families (src/Helmholtz.jl:508-513) pass the seam parts here:
  *       the solution jumps by exp(i b 2pi/N) across the seam, so no aggregate may span it.
+ *   [10] weight of the POST-smoothing sweeps (0.9), [11] weight of the one sweep of the light cycle (0.5) -- the V(1,0) cycle the
+ *       solves of wae_beyn_moments_rb's projected phase run, which start next to the answer and take 1-5 steps.
  *   [8], [9] workspace hints (0 = none): probe columns l and snapshot capacity of the contour integrals that will follow
  *       (wae_beyn_moments_rb): the snapshot store and the resident term products are then mapped during the set-up, behind
  *       its host work, instead of during the first integral.

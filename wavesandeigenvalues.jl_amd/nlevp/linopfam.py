@@ -167,16 +167,18 @@ class DeviceFamily:
 
     # -- solver --------------------------------------------------------------------------------------
     def setup_solver(self, coeffs_ref, theta=0.02, max_coarse=128, jacobi_weight=0.8, sweeps=1, restart=30,
-                     penalty_ratio=1e8, batch=64, shape_exclude=(), probe_columns=0, snapshots=0):
+                     penalty_ratio=1e8, batch=64, shape_exclude=(), probe_columns=0, snapshots=0, jacobi_weight_post=0.0,
+                     jacobi_weight_light=0.0):
         """shape_exclude: indices of terms kept out of the multigrid shape matrix (e.g. the seam parts of a Bloch family);
-        probe_columns, snapshots: workspace hints for the contour integrals to come (include/waehip.h opts[8], [9])"""
+        probe_columns, snapshots: workspace hints for the contour integrals to come (include/waehip.h opts[8], [9]);
+        jacobi_weight_post / _light: opts[10], [11] (0 = the library's defaults, 0.9 and 0.5)"""
         c = np.ascontiguousarray(coeffs_ref, dtype=np.complex128)
         mask = 0
         for k in shape_exclude:
             if k < 52:
                 mask |= 1 << int(k)
         opts = np.array([theta, max_coarse, jacobi_weight, sweeps, restart, penalty_ratio, batch, float(mask), float(probe_columns),
-                         float(snapshots)], dtype=np.float64)
+                         float(snapshots), float(jacobi_weight_post), float(jacobi_weight_light)], dtype=np.float64)
         check(_lib.lib().wae_solver_setup(self.handle, zptr(c), opts.ctypes.data_as(C.POINTER(C.c_double)), len(opts)))
         self.solver_ready = True
         self.batch = batch
