@@ -324,7 +324,8 @@ int wae_bench_spmv(wae_family *h, const double *coeffs, int32_t r, int32_t reps,
  * real restriction -- row pointers, input and output vectors touched once): the roofline line of the level-1 kernels. */
 int wae_bench_spmv_level(wae_family *h, const double *coeffs, int32_t which, int32_t level, int32_t r, int32_t reps, double *ms_out,
                          int64_t *bytes_out);
-/* device triad a = b + s*c over n doubles: measured streaming bandwidth in GB/s */
+/* device triad a = b + s*c over n doubles: measured streaming bandwidth in GB/s (the best of five grid sizes: the rate depends on the
+ * shape of the launch by up to 20 %) */
 int wae_bench_triad(int32_t device, int64_t n, int32_t reps, double *gbs_out);
 
 /* -- test hook (tests/ only) ----------------------------------------------------------------------------

@@ -2883,8 +2883,8 @@ __global__ __launch_bounds__(256) void triad_kernel(double2 *__restrict__ a, con
         a[e] = double2{x.x + s * y.x, x.y + s * y.y};
     }
 }
-void launch_triad(double *a, const double *b, const double *c, double s_, int64_t n, hipStream_t st) {
+void launch_triad(double *a, const double *b, const double *c, double s_, int64_t n, hipStream_t st, unsigned grid_cap) {
     size_t n2 = (size_t)n / 2;
-    hipLaunchKernelGGL(triad_kernel, dim3(grid_for(n2, 8192)), dim3(256), 0, st, (double2 *)a, (const double2 *)b, (const double2 *)c, s_, n2);
+    hipLaunchKernelGGL(triad_kernel, dim3(grid_for(n2, grid_cap)), dim3(256), 0, st, (double2 *)a, (const double2 *)b, (const double2 *)c, s_, n2);
     HIP_CHECK(hipGetLastError());
 }

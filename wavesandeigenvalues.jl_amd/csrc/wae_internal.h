@@ -336,4 +336,4 @@ void launch_axpy2_norm(const cplx *V, size_t stride, int nv, const cplx *c1, con
 void launch_gmres_pair_coef(const GmresDev &S, int j, const cplx *c1, const cplx *c2, const cplx *gram, cplx *alpha, cplx *c2m, cplx *hd2, hipStream_t s);
 void launch_gmres_solve_y(const GmresDev &S, int ju, cplx *out, hipStream_t s);
 // triad for bandwidth measurement
-void launch_triad(double *a, const double *b, const double *c, double s_, int64_t n, hipStream_t s);
+void launch_triad(double *a, const double *b, const double *c, double s, int64_t n, hipStream_t st, unsigned grid_cap = 8192);
