@@ -261,7 +261,9 @@ def discrete_adjoint_shape_sensitivity_unit_cell(cell, surface_points, sol, L, b
     if cQ is not None:
         f0 = m["flames"][0]
         touch = np.isin(m["tets"][f0["flame_tets"]], np.concatenate([np.arange(naxis, naxis + nxb), np.arange(ns, d_ext)])).any()
-        assert not touch, "flame tetrahedra on the Bloch boundary: the reduced flame domain of a point and its image would have to be merged"
+        if touch:       # (shape_sensitivity.jl:75-106 moves such a point together with its image for every domain of dscrp, the flame's included)
+            raise NotImplementedError("flame tetrahedra on the Bloch boundary: the reduced flame domain of a point and its image point would have "
+                                      "to be merged; keep the flame inside the sector (as discretize's unit-cell meshes do) or pass flame=False")
         fl = {**f0, "coeff": cQ}
     Y = complex(cell["params"]["Y"])
     cart = discrete_adjoint_shape_sensitivity(pts, m["tets"], m["c_tet"], allp, sol, L, bnd_tris=m["outlet_tris"], bnd_c=m["outlet_c"], Y=Y, h=h,
