@@ -27,3 +27,18 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def c3_family():
+    """ONE family of BASELINE configs[2] (995 328 DoF) for the whole GPU session: the numpy assembly of the annulus (8 s), the upload
+    (2 s) and the multigrid set-up (1 s) are paid once; tests/test_gpu_fullsize.py::test_c3_one_million_dof_pass and the C3 case of
+    tests/test_gpu_tile_parity.py share it (keep `pytest -m gpu` short).  Solver options as bench.py's."""
+    import numpy as np
+    from wae_amd.helmholtz.family import annulus_family
+    L, pb = annulus_family("C3", tau=2e-4)
+    L.solver_tol = 1e-10
+    L.solver_ref = 2 * np.pi * 500.0
+    L.solver_opts = {"batch": 64, "restart": 40, "sweeps": 1}
+    yield L, pb
+    L._drop_device()

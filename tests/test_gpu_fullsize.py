@@ -160,16 +160,14 @@ def test_projected_guesses_full_size(c2):
     assert np.allclose(S0[:8], S1[:8], rtol=1e-8) and S1[8] < 1e-8 * S1[0]
 
 
-def test_c3_one_million_dof_pass():
+def test_c3_one_million_dof_pass(c3_family):
     """BASELINE configs[2] = the bench default (995 328 DoF, 256 points x 8 columns, 40 snapshot points by the automatic
     rule) through size-independent properties: a lock-step solve of 64 systems verified by the independent SpMV path, the
     Beyn pass returning exactly the eight eigenpairs inside the contour with small backward errors, those eigenvalues within
     the mesh-convergence distance of the 200k-DoF ones (same geometry, 1.7x finer mesh), and Newton refinement from a Beyn
     estimate staying on it."""
-    L, pb = annulus_family("C3", tau=2e-4)
+    L, pb = c3_family                                                   # (tests/conftest.py: shared with the C3 tile-parity case)
     L.solver_tol = 1e-10
-    L.solver_ref = 2 * np.pi * 500.0
-    L.solver_opts = {"batch": 64, "restart": 40, "sweeps": 1}
     d = pb["d"]
     assert d == 995328
     fam = L.ensure_solver()
@@ -208,7 +206,6 @@ def test_c3_one_million_dof_pass():
     k = int(np.argmin(np.abs(Om - 2 * np.pi * 735)))
     sol, n, flag = householder(L, Om[k], maxiter=6, tol=1e-6, v0=P[:, k])
     assert abs(sol.params["ω"] - Om[k]) <= 1e-6 * abs(Om[k]) and n <= 3
-    L._drop_device()
 
 
 def test_c5_adjoint_perturbation_order_30_half_million_dof():
