@@ -12,6 +12,9 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o write --output-format
 if [ "$P" = C3 ]; then   # wave-level and LDS counters of the same launches (their own passes)
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace -d $OUT/sq -o sq --output-format csv -- python3 dev/spmv_only.py $P 64 > $OUT/sq.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $OUT/lds -o lds --output-format csv -- python3 dev/spmv_only.py $P 64 > $OUT/lds.log 2>&1
+# (round 4) L2 requests: how many, how many reads, how many hit
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $OUT/l2hit -o l2hit --output-format csv -- python3 dev/spmv_only.py $P 64 > $OUT/l2hit.log 2>&1
+rocprofv3 --pmc TCC_REQ_sum TCC_READ_sum --kernel-trace -d $OUT/l2req -o l2req --output-format csv -- python3 dev/spmv_only.py $P 64 > $OUT/l2req.log 2>&1
 fi
 python3 - "$OUT" "$P" <<'PY'
 import csv, glob, json, sys, collections

@@ -7,18 +7,14 @@ OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 if [ "$WHAT" = spmv ]; then
-    timeout -k 10 330 dev/collect_spmv_profile.sh C3 ${TAG}_C3 > $OUT/spmv_C3.log 2>&1
+    timeout -k 10 420 dev/collect_spmv_profile.sh C3 ${TAG}_C3 > $OUT/spmv_C3.log 2>&1
     timeout -k 10 170 dev/collect_spmv_profile.sh C2 ${TAG}_C2 > $OUT/spmv_C2.log 2>&1
 else
-    # (the first process on a freshly restored box pays the host's page faults for every page of guest memory it is the first to
-    # touch; bench.py prefaults 12 GB before the solver's clock for that reason.  The first-process figures are kept in
-    # bench_first_process.json, the C3 bench proper runs third)
-    timeout -k 10 300 python bench.py --steps 1 --warmup 1 --no-newton --no-cpu-baseline > $OUT/bench_first.log 2> $OUT/bench_first.err
-    grep "^{" $OUT/bench_first.log > $OUT/bench_first_process.json
-    timeout -k 10 300 python bench.py --preset C2 --N 32 --l 16 > $OUT/bench_C2.log 2> $OUT/bench_C2.err
-    grep "^{" $OUT/bench_C2.log > $OUT/bench_C2.json
+    # (the C3 bench runs FIRST: its value_cold is that of the first process on a freshly restored box, without any prefault -- round 4)
     timeout -k 10 500 python bench.py > $OUT/bench.log 2> $OUT/bench.err
     grep "^{" $OUT/bench.log > $OUT/bench.json
+    timeout -k 10 300 python bench.py --preset C2 --N 32 --l 16 > $OUT/bench_C2.log 2> $OUT/bench_C2.err
+    grep "^{" $OUT/bench_C2.log > $OUT/bench_C2.json
     timeout -k 10 300 dev/prof_bench.sh $OUT/prof_bench > $OUT/prof_bench.log 2>&1
 fi
 echo done

@@ -27,7 +27,8 @@ for preset in ("C3", "C2"):
     for name, dst in (("fetch/fetch_counter_collection.csv", f"{tag}_spmv_pmc_{preset}_FETCH_SIZE.csv"),
                       ("write/write_counter_collection.csv", f"{tag}_spmv_pmc_{preset}_WRITE_SIZE.csv"),
                       ("stats/stats_kernel_stats.csv", f"{tag}_spmv_only_{preset}_kernel_stats.csv"),
-                      ("sq/sq_counter_collection.csv", f"{tag}_spmv_pmc_{preset}_SQ.csv"), ("lds/lds_counter_collection.csv", f"{tag}_spmv_pmc_{preset}_LDS.csv")):
+                      ("sq/sq_counter_collection.csv", f"{tag}_spmv_pmc_{preset}_SQ.csv"), ("lds/lds_counter_collection.csv", f"{tag}_spmv_pmc_{preset}_LDS.csv"),
+                      ("l2hit/l2hit_counter_collection.csv", f"{tag}_spmv_pmc_{preset}_L2HIT.csv"), ("l2req/l2req_counter_collection.csv", f"{tag}_spmv_pmc_{preset}_L2REQ.csv")):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(ROOT, "profiles", dst))
     print(preset, json.dumps(out["kernels"], indent=1), "traffic GB", traffic / 1e9)
