@@ -1082,12 +1082,11 @@ def test_pair_steps_of_the_narrow_recurrence():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
-    procs = {pair: subprocess.Popen([sys.executable, os.path.join(root, "tests", "narrow_worker.py")], env=dict(os.environ, WAE_NARROW_PAIR=pair),
-                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for pair in ("1", "0")}      # (side by side: 2 x 50 s otherwise)
-    for pair, pr in procs.items():
-        so, se = pr.communicate(timeout=900)
-        assert pr.returncode == 0, so[-2000:] + se[-4000:]
-        out[pair] = json.loads(so.strip().split("\n")[-1])
+    for pair in ("1", "0"):          # (one after the other: two processes sharing the GPU took twice as long as the two in sequence)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "narrow_worker.py")], env=dict(os.environ, WAE_NARROW_PAIR=pair),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        out[pair] = json.loads(r.stdout.strip().split("\n")[-1])
         assert out[pair]["checks"] >= 20 and out[pair]["max_steps"] >= 20
     w1, w0 = complex(*out["1"]["eig"]), complex(*out["0"]["eig"])
     assert abs(w1 - w0) <= 1e-8 * abs(w0), (w1, w0)

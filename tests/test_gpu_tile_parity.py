@@ -153,20 +153,16 @@ def test_tile_kernel_on_the_bloch_unit_cell_at_benchmark_size_against_scipy():
 
 def test_persistent_work_list_forced_onto_a_small_problem():
     """tests/tile_worker.py under WAE_TILE_GRID=8: 35 fine tiles on "8 CUs" -- static + dynamic draw, stealing, tail parts -- in three
-    settings, each a child process (the switches are read once per process), started together:
+    settings, each a child process (the switches are read once per process):
     tail 1 / 4 (parts of the last tiles); waves = 16: the 16-wavefront form of the fine-level kernel (four lanes per row; an option,
     slower: DESIGN 4b); long_row = 12 (WAE_LONG_ROW): the rows of the TRANSPOSED flame term with more than 12 entries take the
     long-side-row path of the tile kernel's transposed orientation (op = C checks of the worker), as the reference nodes' rows do at
     the benchmark sizes."""
-    procs = []
-    for tail, waves, long_row in (("1", "8", ""), ("4", "8", "12"), ("4", "16", "")):
+    for tail, waves, long_row in (("1", "8", ""), ("4", "8", "12"), ("4", "16", "")):      # (in sequence: side by side they took longer)
         env = dict(os.environ, WAE_TILE_GRID="8", WAE_TILE_TAIL=tail, WAE_TILE_WAVES=waves)
         if long_row:
             env["WAE_LONG_ROW"] = long_row
-        procs.append((tail, subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tile_worker.py")], env=env, stdout=subprocess.PIPE,
-                                             stderr=subprocess.PIPE, text=True)))
-    for tail, p in procs:
-        so, se = p.communicate(timeout=900)
-        assert p.returncode == 0, so[-2000:] + se[-4000:]
-        res = json.loads(so.strip().split("\n")[-1])
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tile_worker.py")], env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+        res = json.loads(p.stdout.strip().split("\n")[-1])
         assert res["checks"] > 100 and res["grid"] == "8" and res["tail"] == tail
