@@ -588,6 +588,34 @@ def test_projected_guesses_column_split_exchange(l, nranks):
     Lp._drop_device()
 
 
+def test_cycle_weights_of_the_set_up_change_the_work_not_the_moments():
+    """wae_solver_setup opts[10] / opts[11] (round 4): the weights of the post-smoothing sweeps (default 0.9) and of the light cycle's one
+    sweep (default 0.5; the V(1,0) cycle of the projected phase of wae_beyn_moments_rb).  They are preconditioner parameters: whatever
+    their values, the moments agree with the plain path to the inner tolerance; only the iteration counts move.  (The light cycle is
+    what the 216 projected points of the benchmark contour run: DESIGN 4d.)"""
+    import json
+    import os
+    from wae_amd.helmholtz.family import annulus_family
+    gold = json.load(open(os.path.join(F.GOLDEN_DIR, "annulus_small_beyn.json")))
+    Gam = np.array([150 - 150j, 1000 - 150j, 1000 + 150j, 150 + 150j]) * 2 * np.pi
+    res = {}
+    for tag, opts in (("default", {}), ("r3", {"jacobi_weight_post": 0.8, "jacobi_weight_light": 0.8}), ("odd", {"jacobi_weight_post": 1.0, "jacobi_weight_light": 0.3})):
+        Lp, pb = annulus_family("small", n=gold["n"], tau=gold["tau"])
+        Lp.solver_tol = 1e-11
+        Lp.solver_ref = 2 * np.pi * 500.0
+        Lp.solver_opts = dict(opts)
+        d = pb["d"]
+        V = np.random.default_rng(gold["seed_V"]).standard_normal((d, gold["l"])) + 0j
+        if tag == "default":
+            A0 = compute_moment_matrices(Lp, Gam, V, K=1, N=gold["N"], rb=0)
+        A1 = compute_moment_matrices(Lp, Gam, V, K=1, N=gold["N"], rb=24)
+        info = dict(Lp.device().last_info)
+        assert info["n_unconverged"] == 0 and relerr(A1, A0) < 1e-8, (tag, relerr(A1, A0))
+        res[tag] = info["projected_iters"] if "projected_iters" in info else info["iters_total"]
+        Lp._drop_device()
+    assert len(set(res.values())) > 1, res                         # the options reached the solver: the work differs
+
+
 def test_householder_many_matches_single_runs():
     """Several start values refined in lock-step (wae_arnoldi_shiftinvert_batch) give what the single runs give; the
     batched Arnoldi factorisation satisfies its defining relation column by column."""
