@@ -465,12 +465,16 @@ def eigs_many(fam, cA, cM, v0s, op, sigmas, nev=1, tol=1e-12, maxiter=300, stol=
     step = int(min(d, max(6, 2 * nev + 2)))
     cAs = cA - np.asarray(sigmas, dtype=np.complex128)[:, None] * cM[None, :]
     sig_out = np.conj(sigmas) if op == OP_C else np.asarray(sigmas)
+    own_v0 = True
     if isinstance(v0s, (list, tuple)):                    # columns given one by one (views): one copy into column-major storage
         V0 = np.empty((d, nsys), dtype=np.complex128, order="F")
         for q, col in enumerate(v0s):
             V0[:, q] = col
-    else:
-        V0 = np.array(np.asarray(v0s, dtype=np.complex128).reshape(d, nsys), order="F")
+    else:                                                 # a column-major d x nsys array is handed to the library as it is (127 MB at 1M DoF
+        V0 = np.asarray(v0s, dtype=np.complex128).reshape(d, nsys)      # and 8 start values: no copy); copied only if a restart writes to it
+        own_v0 = not (V0 is v0s or V0.base is not None)
+        if not V0.flags.f_contiguous:
+            V0, own_v0 = np.asfortranarray(V0), True
     out = [None] * nsys
     pending = list(range(nsys))
     total = 0
@@ -498,13 +502,16 @@ def eigs_many(fam, cA, cM, v0s, op, sigmas, nev=1, tol=1e-12, maxiter=300, stol=
             k = min(nev, m)
             res = np.abs(Hs[m, m - 1]) * np.abs(Yr[m - 1, :k])
             X = Vs[:, :m] @ Yr[:, :k]
-            X = X / np.linalg.norm(X, axis=0)
+            for jj in range(k):                           # (BLAS dot + in-place scaling: np.linalg.norm and a division cost three passes
+                X[:, jj] *= 1.0 / np.sqrt(np.vdot(X[:, jj], X[:, jj]).real)      # with temporaries over 16 MB per vector)
             gap = abs(1.0 / theta[k]) if m > k else np.inf
             out[s] = (sig_out[s] + 1.0 / theta[:k], X, gap)
             if not (np.all(res <= tol * np.abs(theta[:k])) or m < taken or m >= d):
                 if failed:
                     out[s] = EigsError("inner solves stalled")
                 else:
+                    if not own_v0:
+                        V0, own_v0 = V0.copy(order="F"), True
                     V0[:, s] = X @ np.ones(k)
                     still.append(s)
         pending = still
@@ -580,10 +587,11 @@ def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, orde
         try:
             st_["newton_rounds"] += 1
             t_ = _time.perf_counter()
-            right = eigs_many(fam, cA, cM, [V[:, s] for s in act], OP_N, sig, stol=L.solver_tol, smax=L.solver_maxit, stats=st_)
+            allact = len(act) == ns
+            right = eigs_many(fam, cA, cM, V if allact else [V[:, s] for s in act], OP_N, sig, stol=L.solver_tol, smax=L.solver_maxit, stats=st_)
             st_["right_arnoldi_seconds"] += _time.perf_counter() - t_
             t_ = _time.perf_counter()
-            left = eigs_many(fam, cA, cM, [W[:, s] for s in act], OP_C, sig, stol=L.solver_tol, smax=L.solver_maxit, stats=st_)
+            left = eigs_many(fam, cA, cM, W if allact else [W[:, s] for s in act], OP_C, sig, stol=L.solver_tol, smax=L.solver_maxit, stats=st_)
             st_["left_arnoldi_seconds"] += _time.perf_counter() - t_
         except WaeError as e:
             for s in act:
@@ -665,7 +673,7 @@ def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, orde
             else:
                 f = -3
         L.active, L.mode = active, mode
-        sol = Solution(L.params, V[:, s].copy(), W[:, s].copy(), L.eigval)
+        sol = Solution(L.params, V[:, s], W[:, s], L.eigval)        # (columns of the local column-major arrays: contiguous views, no copies)
         sol.history = hist[s]
         out.append((sol, n[s], f))
     L.active, L.mode = active, mode
