@@ -30,3 +30,10 @@ print("householder_many(%d): %.3f s" % (len(Om), time.time() - t0), [(o[1], o[2]
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(22)
 print(s.getvalue())
+if os.environ.get("NEWTON_SHOW_GRAM"):
+    Vn = P / np.linalg.norm(P, axis=0)
+    G = Vn.T @ Vn
+    np.set_printoptions(precision=2, linewidth=200, suppress=True)
+    print("eigenvalues / 2 pi:", Om / 2 / np.pi)
+    print("|V^T V| =\n", np.abs(G))
+    print("singular values of V^T V:", np.linalg.svd(G, compute_uv=False))

@@ -261,6 +261,47 @@ int wae_perturb(wae_family *h, const double *coeff_table, int32_t N, const doubl
                 int32_t norm_mode, const double *coeffsY, double tol, int32_t maxit, double *lambda_out,
                 double *v_out, wae_solve_info *info);
 
+/* -- device-resident multivectors ("slots") for the Newton-type solvers ------------------------------------------
+ * `householder` (Householder.jl:70-192) iterates, per start value, on a right and a left eigenvector estimate: every Newton step
+ * runs two shift-invert Arnoldi processes from them (Householder.jl:100-101), forms the Ritz vectors, and feeds both to the
+ * perturbation step (Householder.jl:115-116, perturbation.jl:319-367).  Through wae_arnoldi_shiftinvert_batch / wae_perturb those
+ * vectors cross the host boundary five times per step; with slots they stay in HBM from the first step to the last.
+ * A family owns WAE_NSLOTS slots; a slot holds d x ncols complex numbers (column-major for the caller, stored in the library's row
+ * numbering).  All arrays of column indices are 0-based.
+ *   wae_slot_write   (re)creates the slot with ncols_total columns if it has a different column count (new columns are zero) and
+ *                    copies X (d x ncols, column-major, host) into columns col0 .. col0+ncols-1.  ncols = 0: create / resize only.
+ *   wae_slot_read    copies columns col0 .. col0+ncols-1 to X (host).
+ *   wae_slot_axpby   dst[:, dst_cols[i]] = alpha[i] * src[:, src_cols[i]] + beta[i] * dst[:, dst_cols[i]],  i < n, one after the other
+ *                    (alpha, beta: n complex numbers; src and dst may be the same slot and column: a scaling; conj_src != 0: the
+ *                    conjugate of the source column is used).  The relaxed update of Householder.jl:173-176; with conj_src the left
+ *                    start vectors conj(v0) of Householder.jl:84-86 from the right ones.
+ *   wae_slot_forms   out[i] = a_i^H op(sum_k coeffs[i][k] A_k) b_i  for n pairs of columns a_i = slot a[:, a_cols[i]], b_i likewise
+ *                    (coeffs: n x T): the normalisations v^H M v and v_adj^H L'(z) v of Householder.jl:189-190 without moving a vector.
+ *   wae_arnoldi_shiftinvert_slots   wae_arnoldi_shiftinvert_batch with the start vectors taken from slot columns v0_cols[0..nsys-1] and
+ *                    the basis KEPT on the device (only H_out comes back): the caller solves the small Hessenberg eigenproblems and
+ *   wae_arnoldi_ritz_to_slot   writes  sum_j y[s][j] v_j^(s)  (y: nsys x ny complex, ny <= steps taken + 1; normalise != 0: scaled to
+ *                    unit 2-norm) of the basis of the LAST wae_arnoldi_shiftinvert_slots call (same nsys) into dst[:, dst_cols[s]].
+ *   wae_perturb_slots   wae_perturb with v0 = slot v[:, v_col], v0adj = slot vadj[:, vadj_col]; v_out may be NULL (eigenvalue series
+ *                    only: what householder / mslp need).
+ * Both Arnoldi entries: with ritz_tol > 0 a start column that is not close to an eigenvector (||M^-1 op(A) v0|| > 0.1 ||v0||, M^-1 the
+ * multigrid cycle: known before the first solve) is first replaced by one step of inverse iteration from it, solved to 1e-3 -- the
+ * process then starts from that vector (V[:,0] is the replaced start). */
+#define WAE_NSLOTS 8
+int wae_slot_write(wae_family *h, int32_t slot, int32_t ncols_total, int32_t col0, int32_t ncols, const double *X);
+int wae_slot_read(wae_family *h, int32_t slot, int32_t col0, int32_t ncols, double *X);
+int wae_slot_axpby(wae_family *h, int32_t n, int32_t dst_slot, const int32_t *dst_cols, int32_t src_slot, const int32_t *src_cols,
+                   const double *alpha, const double *beta, int32_t conj_src);
+int wae_slot_forms(wae_family *h, int32_t n, const double *coeffs, int32_t op, int32_t a_slot, const int32_t *a_cols, int32_t b_slot,
+                   const int32_t *b_cols, double *out);
+int wae_arnoldi_shiftinvert_slots(wae_family *h, int32_t nsys, const double *coeffsA, const double *coeffsM, int32_t m, int32_t v0_slot,
+                                  const int32_t *v0_cols, int32_t op, double tol, int32_t maxit, double ritz_tol, double *H_out,
+                                  wae_solve_info *info);
+int wae_arnoldi_ritz_to_slot(wae_family *h, int32_t nsys, int32_t ny, const double *y, int32_t dst_slot, const int32_t *dst_cols,
+                             int32_t normalise);
+int wae_perturb_slots(wae_family *h, const double *coeff_table, int32_t N, int32_t v_slot, int32_t v_col, int32_t vadj_slot, int32_t vadj_col,
+                      int32_t norm_mode, const double *coeffsY, double tol, int32_t maxit, double *lambda_out, double *v_out,
+                      wae_solve_info *info);
+
 /* -- P1 assembly on the device (input production) ------------------------------------------------
  * Mass and stiffness matrices of the P1 tetrahedral discretisation, as `discretize` assembles them for the "interior"
  * domain (src/Helmholtz.jl:405-441 with the element kernels src/FEM/FEM.jl:704-710,1745-1766):

@@ -667,10 +667,9 @@ function conjugate_span_start(V::Matrix{ComplexF64})
     return conj.(Vn * inv(G))
 end
 
-"[(sol, n, flag), ...] = householder_many(Ld, zs; maxiter, tol, relax, lam_tol, order, v0s, v0s_adj): `householder`
-(Householder.jl:70-192, nev = 1) for every start value in zs, the device work batched over the start values.  An empty zs returns
-an empty list."
-function householder_many(fam::DeviceFamily, zs; maxiter=10, tol=0., relax=1., lam_tol=Inf, order=1, v0s=nothing, v0s_adj=nothing, output=false)
+"`householder_many` with every vector passing through host memory between the device calls (wae_arnoldi_shiftinvert_batch,
+wae_perturb, wae_spmv_sum_cols): the cross-check of the device-resident form below, `householder_many(...; resident=false)`."
+function householder_many_host(fam::DeviceFamily, zs; maxiter=10, tol=0., relax=1., lam_tol=Inf, order=1, v0s=nothing, v0s_adj=nothing, output=false)
     L = fam.L
     z = ComplexF64.(collect(zs)); ns = length(z)
     ns == 0 && return Tuple{Solution,Int,Int}[]
@@ -737,6 +736,251 @@ function householder_many(fam::DeviceFamily, zs; maxiter=10, tol=0., relax=1., l
     merge!(L.params, saved); L.active, L.mode = active, mode
     DV = spmv_cols(fam, cD, V)
     for s in 1:ns; W[:, s] ./= conj(dot(W[:, s], DV[:, s])); end
+    out = Tuple{Solution,Int,Int}[]
+    for s in 1:ns
+        f = flag[s]
+        L.params[L.eigval] = z[s]; L.params[L.auxval] = isfinite(lam[s]) ? lam[s] : 0
+        if f == 1
+            f = n[s] >= maxiter ? -1 : (abs(lam[s]) <= lam_tol ? 1 : (abs(z[s] - z0[s]) <= tol ? 0 : (isnan(z[s]) ? -5 : -3)))
+        end
+        push!(out, (Solution(L.params, V[:, s], W[:, s], L.eigval), n[s], f))
+    end
+    L.active, L.mode = active, mode
+    return out
+end
+
+# ---------------------------------------------------------------------------------------------------------------
+# Device-resident multivectors ("slots", include/waehip.h): the vectors of the lock-step Newton iteration stay in HBM between the
+# calls.  Column indices are 0-based in the library; the wrappers below take Julia's 1-based indices.
+# ---------------------------------------------------------------------------------------------------------------
+const NSLOTS = 8
+_cols0(cols) = Int32[Int32(c - 1) for c in cols]
+
+"X (d x n) into columns col0, col0+1, ... (1-based) of the slot, (re)created with ncols_total columns if its width differs; X = nothing: create / resize only"
+function slot_write(fam::DeviceFamily, slot::Integer, X::Union{Nothing,Matrix{ComplexF64}}; ncols_total::Integer=(X === nothing ? 0 : size(X, 2)), col0::Integer=1)
+    n = X === nothing ? 0 : size(X, 2)
+    check(ccall((:wae_slot_write, libwaehip), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Int32, Ptr{ComplexF64}),
+                fam.handle, slot, ncols_total, col0 - 1, n, X === nothing ? C_NULL : X))
+    return
+end
+function slot_read(fam::DeviceFamily, slot::Integer, col0::Integer, ncols::Integer)
+    d = size(fam.L.terms[1].coeff, 1)
+    X = Matrix{ComplexF64}(undef, d, ncols)
+    check(ccall((:wae_slot_read, libwaehip), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{ComplexF64}), fam.handle, slot, col0 - 1, ncols, X))
+    return X
+end
+"dst[:, dst_cols[i]] = alpha[i] src[:, src_cols[i]] + beta[i] dst[:, dst_cols[i]], one column after the other (conj_src: conj of the source column)"
+function slot_axpby(fam::DeviceFamily, dst_slot::Integer, dst_cols, src_slot::Integer, src_cols, alpha, beta; conj_src::Bool=false)
+    n = length(dst_cols)
+    a = alpha isa Number ? fill(ComplexF64(alpha), n) : Vector{ComplexF64}(alpha)
+    b = beta isa Number ? fill(ComplexF64(beta), n) : Vector{ComplexF64}(beta)
+    check(ccall((:wae_slot_axpby, libwaehip), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{Int32}, Int32, Ptr{Int32}, Ptr{ComplexF64}, Ptr{ComplexF64}, Int32),
+                fam.handle, n, dst_slot, _cols0(dst_cols), src_slot, _cols0(src_cols), a, b, conj_src ? 1 : 0))
+    return
+end
+"out[i] = a_i' op(sum_k C[k, i] A_k) b_i for pairs of slot columns (C: T x n)"
+function slot_forms(fam::DeviceFamily, C::Matrix{ComplexF64}, a_slot::Integer, a_cols, b_slot::Integer, b_cols; op::Int32=OP_N)
+    n = length(a_cols)
+    out = zeros(ComplexF64, n)
+    check(ccall((:wae_slot_forms, libwaehip), Cint, (Ptr{Cvoid}, Int32, Ptr{ComplexF64}, Int32, Int32, Ptr{Int32}, Int32, Ptr{Int32}, Ptr{ComplexF64}),
+                fam.handle, n, C, op, a_slot, _cols0(a_cols), b_slot, _cols0(b_cols), out))
+    return out
+end
+"`arnoldi_batch` with the start vectors in slot columns and the basis kept on the device: returns H (m+1, m, nsys) and the solve statistics"
+function arnoldi_slots(fam::DeviceFamily, cA::Matrix{ComplexF64}, cM::Matrix{ComplexF64}, m::Integer, v0_slot::Integer, v0_cols, op::Int32;
+                       ritz_tol::Float64=0.0)
+    ensure_solver!(fam)
+    nsys = length(v0_cols)
+    H = zeros(ComplexF64, m + 1, m, nsys); info = Ref{SolveInfo}()
+    check(ccall((:wae_arnoldi_shiftinvert_slots, libwaehip), Cint,
+                (Ptr{Cvoid}, Int32, Ptr{ComplexF64}, Ptr{ComplexF64}, Int32, Int32, Ptr{Int32}, Int32, Float64, Int32, Float64,
+                 Ptr{ComplexF64}, Ref{SolveInfo}),
+                fam.handle, nsys, cA, cM, m, v0_slot, _cols0(v0_cols), op, fam.tol, fam.maxit, ritz_tol, H, info))
+    return H, info[]
+end
+"dst[:, dst_cols[s]] = sum_j Y[j, s] v_j^(s) of the basis of the last arnoldi_slots call (Y: ny x nsys)"
+function ritz_to_slot(fam::DeviceFamily, Y::Matrix{ComplexF64}, dst_slot::Integer, dst_cols; normalise::Bool=true)
+    ny, nsys = size(Y)
+    check(ccall((:wae_arnoldi_ritz_to_slot, libwaehip), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{ComplexF64}, Int32, Ptr{Int32}, Int32),
+                fam.handle, nsys, ny, Y, dst_slot, _cols0(dst_cols), normalise ? 1 : 0))
+    return
+end
+"the eigenvalue series of `perturb!(sol, L, param, N; mode = :householder)` (LinOpFam.jl:546-560, perturbation.jl:319-367) for the
+eigenpair in slot columns: L.params carries the expansion point, `eigval` names the pair's eigenvalue parameter.  No vector leaves the device."
+function eigval_series_slots(fam::DeviceFamily, eigval::Symbol, param::Symbol, N::Int, v_slot::Integer, v_col::Integer, w_slot::Integer, w_col::Integer)
+    ensure_solver!(fam)
+    L = fam.L; T = length(L.terms)
+    active, current_mode = L.active, L.mode
+    L.active = [eigval, param]; L.mode = :householder
+    table = zeros(ComplexF64, T, N + 1, N + 1)
+    try
+        for m in 0:N, n in 0:N-m
+            table[:, n+1, m+1] = coefficients(L, m, n)
+        end
+    finally
+        L.active, L.mode = active, current_mode
+    end
+    lam = zeros(ComplexF64, N + 1); info = Ref{SolveInfo}()
+    code = check(ccall((:wae_perturb_slots, libwaehip), Cint,
+                (Ptr{Cvoid}, Ptr{ComplexF64}, Int32, Int32, Int32, Int32, Int32, Int32, Ptr{ComplexF64}, Float64, Int32,
+                 Ptr{ComplexF64}, Ptr{ComplexF64}, Ref{SolveInfo}),
+                fam.handle, table, N, v_slot, v_col - 1, w_slot, w_col - 1, 16, C_NULL, fam.tol, fam.maxit, lam, C_NULL, info))
+    report(code, info[], "perturb_slots (order $N)"; quiet=true)
+    lam[1] = L.params[eigval]
+    return lam
+end
+
+"`eigs_many` (nev = 1) on device-resident vectors: start vectors = columns `cols` of slot v0_slot, the normalised Ritz vector of system q
+goes to column cols[q] of out_slot.  Returns per system (lam, gap) or an EigsError."
+function eigs_many_slots(fam::DeviceFamily, cA::Matrix{ComplexF64}, cM::Vector{ComplexF64}, v0_slot::Integer, cols::Vector{Int}, op::Int32,
+                         sigmas::Vector{Float64}, out_slot::Integer; tol::Float64=1e-12, maxiter::Int=300)
+    nsys = length(cols); d = size(fam.L.terms[1].coeff, 1)
+    step = min(d, 6)
+    cAs = cA .- reshape(ComplexF64.(sigmas), 1, :) .* cM
+    sig_out = op == OP_C ? conj.(ComplexF64.(sigmas)) : ComplexF64.(sigmas)
+    out = Vector{Any}(undef, nsys)
+    pending = collect(1:nsys); total = 0; src = v0_slot
+    while !isempty(pending) && total < maxiter
+        H, info = arnoldi_slots(fam, cAs[:, pending], repeat(cM, 1, length(pending)), step, src, cols[pending], op; ritz_tol=tol)
+        total += step
+        failed = info.n_unconverged > 0 && info.relres_max > 1e-4
+        Y = zeros(ComplexF64, step + 1, length(pending)); ny = 1
+        still = Int[]
+        for (q, s) in enumerate(pending)
+            Hs = H[:, :, q]
+            m = step
+            while m > 1 && all(Hs[:, m] .== 0); m -= 1; end            # steps not taken (early exit on the device)
+            taken = m
+            for j in 1:m
+                if Hs[j+1, j] == 0; m = j; break; end                  # invariant subspace
+            end
+            F = eigen(Hs[1:m, 1:m])
+            ord = sortperm(abs.(F.values); rev=true)
+            theta, Yr = F.values[ord], F.vectors[:, ord]
+            res = abs(Hs[m+1, m]) * abs(Yr[m, 1])
+            Y[1:m, q] = Yr[:, 1]; ny = max(ny, m)
+            gap = m > 1 ? abs(1.0 / theta[2]) : Inf
+            out[s] = (sig_out[s] + 1.0 / theta[1], gap)
+            if !(res <= tol * abs(theta[1]) || m < taken || m >= d)
+                if failed
+                    out[s] = EigsError("inner solves stalled")
+                else
+                    push!(still, s)                                     # restart from the Ritz vector (now in out_slot)
+                end
+            end
+        end
+        ritz_to_slot(fam, Y[1:ny, :], out_slot, cols[pending])
+        pending = still; src = out_slot
+    end
+    return out
+end
+
+"C (ns x ns) with W = conj(V C) the conjugate-span start of the left processes (see conjugate_span_start), or nothing for W = conj(V)"
+function conjugate_span_coefficients(V::Matrix{ComplexF64})
+    ns = size(V, 2)
+    ns < 2 && return nothing
+    nrm = [norm(view(V, :, j)) for j in 1:ns]; nrm[nrm .== 0] .= 1.0
+    G = (transpose(V) * V) ./ (nrm * transpose(nrm))
+    (all(isfinite, G) && minimum(svdvals(G)) >= 1e-6) || return nothing
+    return inv(G) ./ nrm
+end
+
+"[(sol, n, flag), ...] = householder_many(Ld, zs; maxiter, tol, relax, lam_tol, order, v0s, v0s_adj): `householder`
+(Householder.jl:70-192, nev = 1) for every start value in zs, the device work batched over the start values and every vector of the
+iteration resident in HBM (slots 5-8 of the family): the estimates go to the device once, the Arnoldi processes start from slot columns
+and leave their Ritz vectors there, the perturbation step reads them there, the relaxed update and the normalisations of
+Householder.jl:173-176,189-190 are slot operations, and the eigenvectors come back once at the end.  An empty zs returns an empty list.
+resident = false: the same iteration through host memory (householder_many_host)."
+function householder_many(fam::DeviceFamily, zs; maxiter=10, tol=0., relax=1., lam_tol=Inf, order=1, v0s=nothing, v0s_adj=nothing, output=false,
+                          resident::Bool=true)
+    resident || return householder_many_host(fam, zs; maxiter=maxiter, tol=tol, relax=relax, lam_tol=lam_tol, order=order, v0s=v0s,
+                                             v0s_adj=v0s_adj, output=output)
+    L = fam.L
+    z = ComplexF64.(collect(zs)); ns = length(z)
+    ns == 0 && return Tuple{Solution,Int,Int}[]
+    ensure_solver!(fam)
+    d = size(L.terms[1].coeff, 1); T = length(L.terms)
+    active, mode = L.active, L.mode
+    SV, SW, SXR, SXL = 4, 5, 6, 7                                       # (0-based slot numbers: the upper half, 0-3 stay the caller's)
+    allc = collect(1:ns)
+    V0 = v0s === nothing ? ones(ComplexF64, d, ns) : Matrix{ComplexF64}(reshape(v0s, d, ns))
+    slot_write(fam, SV, V0)
+    if v0s_adj === nothing
+        Cs = v0s === nothing ? nothing : conjugate_span_coefficients(V0)
+        slot_write(fam, SW, nothing; ncols_total=ns)
+        if Cs === nothing
+            slot_axpby(fam, SW, allc, SV, allc, 1.0, 0.0; conj_src=true)
+        else
+            for i in 1:ns
+                slot_axpby(fam, SW, allc, SV, fill(i, ns), conj.(Cs[i, :]), i == 1 ? 0.0 : 1.0; conj_src=true)
+            end
+        end
+    else
+        slot_write(fam, SW, Matrix{ComplexF64}(reshape(v0s_adj, d, ns)))
+    end
+    slot_write(fam, SXR, nothing; ncols_total=ns)
+    slot_write(fam, SXL, nothing; ncols_total=ns)
+    z0 = fill(complex(Inf), ns); lam = fill(complex(Inf), ns); n = zeros(Int, ns); flag = ones(Int, ns)
+    gaps = fill(Inf, ns); lams = fill(Inf, ns)
+    cM = zeros(ComplexF64, T); cM[end] = -1                             # M = -L.terms[end].coeff  (Householder.jl:92)
+    upd(c) = householder_update([factorial(i - 1) * c[i] for i in 1:length(c)])
+    while true
+        act = [s for s in 1:ns if flag[s] == 1 && abs(z[s] - z0[s]) > tol && n[s] < maxiter]
+        isempty(act) && break
+        cA = Matrix{ComplexF64}(undef, T, length(act)); sig = Float64[]
+        L.active = [L.eigval]; L.mode = :all
+        for (q, s) in enumerate(act)
+            z0[s] = z[s]
+            L.params[L.eigval] = z[s]; L.params[L.auxval] = 0
+            cA[:, q] = coefficients(L, z[s])
+            push!(sig, (isfinite(gaps[s]) && lams[s] < 1e-4 * gaps[s]) ? 1e-5 * gaps[s] : 0.0)
+        end
+        local right, left
+        try
+            right = eigs_many_slots(fam, cA, cM, SV, act, OP_N, sig, SXR)
+            left = eigs_many_slots(fam, cA, cM, SW, act, OP_C, sig, SXL)
+        catch excp
+            for s in act; flag[s] = excp isa LinearAlgebra.SingularException ? -6 : -2; end
+            break
+        end
+        moved = Int[]
+        for (q, s) in enumerate(act)
+            if right[q] isa EigsError || left[q] isa EigsError; flag[s] = -4; continue; end
+            lam_r, gap = right[q]
+            isfinite(gap) && (gaps[s] = gap)
+            lams[s] = abs(lam_r)
+            L.params[L.eigval] = z[s]; L.params[L.auxval] = lam_r
+            local dz
+            try
+                dz = upd(eigval_series_slots(fam, L.auxval, L.eigval, order, SXR, s, SXL, s))
+            catch excp
+                flag[s] = excp isa LinearAlgebra.SingularException ? -6 : -2
+                continue
+            end
+            lam[s] = lam_r
+            output && println(s, " ", n[s], "\t", abs(lam[s]), "\t", abs(dz), "\t", z[s])
+            z[s] += relax * dz
+            push!(moved, s)
+            n[s] += 1
+        end
+        if !isempty(moved)                                              # v0 = (1 - relax) v0 + relax v  (Householder.jl:173-176), on the device
+            slot_axpby(fam, SV, moved, SXR, moved, relax, 1 - relax)
+            slot_axpby(fam, SW, moved, SXL, moved, relax, 1 - relax)
+        end
+    end
+    # Householder.jl:189-190 for all start values at once: two batched forms, two scalings
+    nv = slot_forms(fam, repeat(cM, 1, ns), SV, allc, SV, allc)
+    slot_axpby(fam, SV, allc, SV, allc, 1.0 ./ sqrt.(nv), 0.0)
+    cD = Matrix{ComplexF64}(undef, T, ns)
+    saved = copy(L.params); L.active = [L.eigval]; L.mode = :all
+    for s in 1:ns
+        L.params[L.eigval] = z[s]; L.params[L.auxval] = isfinite(lam[s]) ? lam[s] : 0
+        cD[:, s] = coefficients(L, z[s], 1)
+    end
+    merge!(L.params, saved); L.active, L.mode = active, mode
+    dw = slot_forms(fam, cD, SW, allc, SV, allc)
+    slot_axpby(fam, SW, allc, SW, allc, 1.0 ./ conj.(dw), 0.0)
+    V = slot_read(fam, SV, 1, ns); W = slot_read(fam, SW, 1, ns)
     out = Tuple{Solution,Int,Int}[]
     for s in 1:ns
         f = flag[s]

@@ -158,7 +158,9 @@ def test_julia_ccall_signatures_match_the_header():
                 raise AssertionError((name, jt, ct))
         seen.add(name)
     for must in ("wae_family_create", "wae_spmv_sum", "wae_solver_setup", "wae_solve", "wae_solve_guess", "wae_beyn_moments",
-                 "wae_beyn_moments_rb", "wae_beyn_moments_mgpu", "wae_eig_residuals", "wae_arnoldi_shiftinvert_batch", "wae_perturb"):
+                 "wae_beyn_moments_rb", "wae_beyn_moments_mgpu", "wae_eig_residuals", "wae_arnoldi_shiftinvert_batch", "wae_perturb",
+                 "wae_slot_write", "wae_slot_read", "wae_slot_axpby", "wae_slot_forms", "wae_arnoldi_shiftinvert_slots", "wae_arnoldi_ritz_to_slot",
+                 "wae_perturb_slots"):
         assert must in seen, must
     # the file is at least bracket-balanced (a cheap stand-in for a parser)
     jl = open(os.path.join(ROOT, "julia", "WAEHip.jl"), encoding="utf-8").read()
@@ -183,7 +185,10 @@ def test_every_product_export_is_bound_from_julia():
     for fn in ("function householder_many(", "function solve_batched(", "function eigs_many(", "function conjugate_span_start(",
                "function assemble_p1(", "function assemble_p1_boundary(", "function assemble_p1_flame(",
                "function discrete_adjoint_shape_sensitivity_p1(", "function discrete_adjoint_shape_sensitivity_p1_flame(",
-               "function spmv_cols(", "function spmv_multi(", "function rb_export(", "function rb_import("):
+               "function spmv_cols(", "function spmv_multi(", "function rb_export(", "function rb_import(",
+               # the device-resident Newton-type refinement (round 4) and the host-memory form it is checked against
+               "function householder_many_host(", "function eigs_many_slots(", "function eigval_series_slots(", "function slot_write(",
+               "function slot_read(", "function slot_axpby(", "function slot_forms(", "function arnoldi_slots(", "function ritz_to_slot("):
         assert fn in jl, fn
 
 

@@ -36,7 +36,7 @@ _lib = None
 EXPORTS = [
     "wae_last_error", "wae_device_count", "wae_version", "wae_family_create", "wae_family_create_opts", "wae_family_destroy",
     "wae_family_info", "wae_family_spmv_bytes", "wae_spmv_sum", "wae_spmv_sum_cols", "wae_spmv_sum_multi", "wae_solver_setup",
-    "wae_solve", "wae_solve_guess", "wae_beyn_moments", "wae_beyn_moments_mgpu", "wae_beyn_moments_rb", "wae_rb_export", "wae_rb_import", "wae_eig_residuals", "wae_arnoldi_shiftinvert", "wae_arnoldi_shiftinvert_batch", "wae_perturb", "wae_p1_assemble", "wae_p1_assemble_boundary", "wae_p1_assemble_flame", "wae_p1_info", "wae_p1_get", "wae_p1_free", "wae_p1_shape_sensitivity", "wae_p1_shape_sensitivity_flame", "wae_bench_spmv", "wae_bench_spmv_level", "wae_bench_triad", "wae_debug_spmv",
+    "wae_solve", "wae_solve_guess", "wae_beyn_moments", "wae_beyn_moments_mgpu", "wae_beyn_moments_rb", "wae_rb_export", "wae_rb_import", "wae_eig_residuals", "wae_arnoldi_shiftinvert", "wae_arnoldi_shiftinvert_batch", "wae_perturb", "wae_slot_write", "wae_slot_read", "wae_slot_axpby", "wae_slot_forms", "wae_arnoldi_shiftinvert_slots", "wae_arnoldi_ritz_to_slot", "wae_perturb_slots", "wae_p1_assemble", "wae_p1_assemble_boundary", "wae_p1_assemble_flame", "wae_p1_info", "wae_p1_get", "wae_p1_free", "wae_p1_shape_sensitivity", "wae_p1_shape_sensitivity_flame", "wae_bench_spmv", "wae_bench_spmv_level", "wae_bench_triad", "wae_debug_spmv",
 ]
 
 
@@ -87,6 +87,16 @@ def lib():
                                                 dp, dp, C.POINTER(SolveInfo)]
     L.wae_perturb.argtypes = [C.c_void_p, dp, C.c_int32, dp, dp, C.c_int32, dp, C.c_double, C.c_int32, dp, dp,
                               C.POINTER(SolveInfo)]
+    ip = C.POINTER(C.c_int32)
+    L.wae_slot_write.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp]
+    L.wae_slot_read.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, dp]
+    L.wae_slot_axpby.argtypes = [C.c_void_p, C.c_int32, C.c_int32, ip, C.c_int32, ip, dp, dp, C.c_int32]
+    L.wae_slot_forms.argtypes = [C.c_void_p, C.c_int32, dp, C.c_int32, C.c_int32, ip, C.c_int32, ip, dp]
+    L.wae_arnoldi_shiftinvert_slots.argtypes = [C.c_void_p, C.c_int32, dp, dp, C.c_int32, C.c_int32, ip, C.c_int32, C.c_double, C.c_int32, C.c_double,
+                                                dp, C.POINTER(SolveInfo)]
+    L.wae_arnoldi_ritz_to_slot.argtypes = [C.c_void_p, C.c_int32, C.c_int32, dp, C.c_int32, ip, C.c_int32]
+    L.wae_perturb_slots.argtypes = [C.c_void_p, dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp, C.c_double, C.c_int32, dp, dp,
+                                    C.POINTER(SolveInfo)]
     L.wae_p1_assemble.argtypes = [C.c_int32, C.c_int64, dp, C.c_int64, C.POINTER(C.c_int32), dp, C.POINTER(C.c_void_p)]
     L.wae_p1_assemble_boundary.argtypes = [C.c_int32, C.c_int64, dp, C.c_int64, C.POINTER(C.c_int32), dp, C.POINTER(C.c_void_p)]
     L.wae_p1_assemble_flame.argtypes = [C.c_int32, C.c_int64, dp, C.c_int64, C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int32), C.c_int32, dp,

@@ -37,25 +37,41 @@ __device__ __forceinline__ cplx cdiv(cplx a, cplx b) {
     return cplx{(a.x * b.x + a.y * b.y) * s, (a.y * b.x - a.x * b.y) * s};
 }
 
-// Long rows (OpDev): long_acc[i][b] = sum over the entries of long row i of pc[sys(b)][slot] * val * X[col][b].  One workgroup
-// per (long row, 8-column chunk): 32 lanes stride over the entries, 8 lanes across the columns; fixed-order LDS reduction.
-__global__ __launch_bounds__(256) void spmv_long_kernel(OpDev op, const cplx *__restrict__ pc, int cps, const cplx *__restrict__ X, int nb,
-                                                        const unsigned char *__restrict__ cmask) {
+// Long rows (OpDev::long_*, TileDev::ls_*): acc[row][b] = sum over the entries of the row of pc[sys(b)][slot] * val * X[col][b].  A row of
+// the transposed flame term holds one entry per flame node (50 000 at 1M DoF): as ONE workgroup's loop that was 68-74 us per product --
+// a sixth of an adjoint Krylov step of the Newton-type solvers, whose narrow batches leave the rest of the chip idle meanwhile.  The
+// entries of a row are therefore split over WAE_LONG_SPLIT workgroups per 8-column chunk (32 lanes stride over a piece, 8 lanes across
+// the columns; fixed-order LDS reduction) that write partial sums, and long_reduce_kernel adds the partials in a fixed order.
+__device__ __forceinline__ void long_row_piece(const int *__restrict__ ptr, const int *__restrict__ col, const int *__restrict__ slot,
+                                               const cplx *__restrict__ val, int npl, int conj, const cplx *__restrict__ pc, int cps,
+                                               const cplx *__restrict__ X, int nb, const unsigned char *__restrict__ cmask, cplx *__restrict__ part) {
     __shared__ cplx red[256];
-    const int li = blockIdx.x, ch = blockIdx.y;
+    const int li = blockIdx.x / WAE_LONG_SPLIT, k = blockIdx.x - li * WAE_LONG_SPLIT, ch = blockIdx.y;
     if (cmask && !cmask[ch]) return;
     const int tid = threadIdx.x, c = tid & 7, seg = tid >> 3;
     const int b = ch * 8 + c;
     const int bb = b < nb ? b : nb - 1;
-    const int npl = op.nplanes_total;
     const cplx *mypc = pc + (size_t)(bb / cps) * npl;
-    const double sg = op.long_conj ? -1.0 : 1.0;
+    const double sg = conj ? -1.0 : 1.0;
+    const int beg = ptr[li], end = ptr[li + 1];
+    const int piece = ((end - beg + WAE_LONG_SPLIT - 1) / WAE_LONG_SPLIT + 31) & ~31;
+    const int p0 = beg + k * piece, p1 = min(end, p0 + piece);
     cplx acc = {0.0, 0.0};
-    for (int p = op.long_ptr[li] + seg; p < op.long_ptr[li + 1]; p += 32) {
-        cplx a = op.long_val[p];
+    int p = p0 + seg;
+    for (; p + 96 < p1; p += 128) {                      // four entries in flight per lane
+        int cc[4], sl[4];
+        cplx a[4], x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { cc[u] = col[p + 32 * u]; sl[u] = slot[p + 32 * u]; a[u] = val[p + 32 * u]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = X[(size_t)cc[u] * nb + bb];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u].y *= sg; cfma(acc, cmul(mypc[sl[u]], a[u]), x[u]); }
+    }
+    for (; p < p1; p += 32) {
+        cplx a = val[p];
         a.y *= sg;
-        const cplx m = cmul(mypc[op.long_slot[p]], a);
-        cfma(acc, m, X[(size_t)op.long_col[p] * nb + bb]);
+        cfma(acc, cmul(mypc[slot[p]], a), X[(size_t)col[p] * nb + bb]);
     }
     red[tid] = acc;
     __syncthreads();
@@ -63,7 +79,29 @@ __global__ __launch_bounds__(256) void spmv_long_kernel(OpDev op, const cplx *__
         if (tid < off) { red[tid].x += red[tid + off].x; red[tid].y += red[tid + off].y; }
         __syncthreads();
     }
-    if (tid < 8 && b < nb) op.long_acc[(size_t)li * nb + b] = red[tid];
+    if (tid < 8 && b < nb) part[((size_t)li * WAE_LONG_SPLIT + k) * nb + b] = red[tid];
+}
+__global__ __launch_bounds__(256) void spmv_long_kernel(OpDev op, const cplx *__restrict__ pc, int cps, const cplx *__restrict__ X, int nb,
+                                                        const unsigned char *__restrict__ cmask) {
+    long_row_piece(op.long_ptr, op.long_col, op.long_slot, op.long_val, op.nplanes_total, op.long_conj, pc, cps, X, nb, cmask, op.long_part);
+}
+// acc[map ? map[i] : i][b] = sum_k part[i][k][b], k ascending (one thread per (row, column))
+__global__ __launch_bounds__(256) void long_reduce_kernel(const cplx *__restrict__ part, int nrows, int nb, const int *__restrict__ map,
+                                                          cplx *__restrict__ acc, const unsigned char *__restrict__ cmask) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nrows * nb) return;
+    const int i = e / nb, b = e - i * nb;
+    if (cmask && !cmask[b >> 3]) return;
+    cplx s = {0.0, 0.0};
+    for (int k = 0; k < WAE_LONG_SPLIT; ++k) { const cplx t = part[((size_t)i * WAE_LONG_SPLIT + k) * nb + b]; s.x += t.x; s.y += t.y; }
+    acc[(size_t)(map ? map[i] : i) * nb + b] = s;
+}
+static void launch_long_rows(const OpDev &op, const cplx *pc, int cps, const cplx *X, int nb, const unsigned char *cmask, hipStream_t st) {
+    hipLaunchKernelGGL(spmv_long_kernel, dim3((unsigned)op.nlong * WAE_LONG_SPLIT, (unsigned)((nb + 7) / 8)), dim3(256), 0, st, op, pc, cps, X, nb, cmask);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(long_reduce_kernel, dim3((unsigned)((op.nlong * nb + 255) / 256)), dim3(256), 0, st, op.long_part, op.nlong, nb,
+                       (const int *)nullptr, op.long_acc, cmask);
+    HIP_CHECK(hipGetLastError());
 }
 // position of `row` in the sorted long-row list, or -1
 __device__ __forceinline__ int long_row_index(const OpDev &op, int64_t row) {
@@ -430,31 +468,11 @@ __global__ __launch_bounds__(256) void spmv_side_kernel(TileDev td, int npl, int
     td.side_acc[(size_t)i * nb + b] = acc;
 }
 
-// Long side rows (TileDev::nlong_side; the transposed orientation of a flame term): side_acc[ls_side[li]][b] = the row's sum, one
-// workgroup per (row, 8-column chunk) as spmv_long_kernel; runs after spmv_side_kernel, which wrote zeros there (empty CSR rows).
+// Long side rows (TileDev::nlong_side; the transposed orientation of a flame term): side_acc[ls_side[li]][b] = the row's sum, in pieces
+// like spmv_long_kernel (long_reduce_kernel then writes the sums over the zeros spmv_side_kernel left there: empty CSR rows).
 __global__ __launch_bounds__(256) void spmv_side_long_kernel(TileDev td, int npl, int conj, const cplx *__restrict__ pc, int cps,
                                                              const cplx *__restrict__ X, int nb, const unsigned char *__restrict__ cmask) {
-    __shared__ cplx red[256];
-    const int li = blockIdx.x, ch = blockIdx.y;
-    if (cmask && !cmask[ch]) return;
-    const int tid = threadIdx.x, c = tid & 7, seg = tid >> 3;
-    const int b = ch * 8 + c;
-    const int bb = b < nb ? b : nb - 1;
-    const cplx *mypc = pc + (size_t)(bb / cps) * npl;
-    const double sg = conj ? -1.0 : 1.0;
-    cplx acc = {0.0, 0.0};
-    for (int p = td.ls_ptr[li] + seg; p < td.ls_ptr[li + 1]; p += 32) {
-        cplx a = td.ls_val[p];
-        a.y *= sg;
-        cfma(acc, cmul(mypc[td.ls_slot[p]], a), X[(size_t)td.ls_col[p] * nb + bb]);
-    }
-    red[tid] = acc;
-    __syncthreads();
-    for (int off = 128; off >= 8; off >>= 1) {
-        if (tid < off) { red[tid].x += red[tid + off].x; red[tid].y += red[tid + off].y; }
-        __syncthreads();
-    }
-    if (tid < 8 && b < nb) td.side_acc[(size_t)td.ls_side[li] * nb + b] = red[tid];
+    long_row_piece(td.ls_ptr, td.ls_col, td.ls_slot, td.ls_val, npl, conj, pc, cps, X, nb, cmask, td.ls_part);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1303,8 +1321,11 @@ static void launch_spmv_tile(const OpDev &op, const TileDev &td, const cplx *pc,
                            op.conj_diag, pc, cps, X, nb, cmask);
         HIP_CHECK(hipGetLastError());
         if (td.nlong_side) {
-            hipLaunchKernelGGL(spmv_side_long_kernel, dim3((unsigned)td.nlong_side, (unsigned)nchunks), dim3(256), 0, st, td, op.nplanes_total,
-                               op.conj_diag, pc, cps, X, nb, cmask);
+            hipLaunchKernelGGL(spmv_side_long_kernel, dim3((unsigned)td.nlong_side * WAE_LONG_SPLIT, (unsigned)nchunks), dim3(256), 0, st, td,
+                               op.nplanes_total, op.conj_diag, pc, cps, X, nb, cmask);
+            HIP_CHECK(hipGetLastError());
+            hipLaunchKernelGGL(long_reduce_kernel, dim3((unsigned)((td.nlong_side * nb + 255) / 256)), dim3(256), 0, st, td.ls_part, td.nlong_side, nb,
+                               td.ls_side, td.side_acc, cmask);
             HIP_CHECK(hipGetLastError());
         }
     }
@@ -1358,9 +1379,7 @@ void launch_spmv(const OpDev &op, const cplx *pc, int cps, const cplx *X, cplx *
     }
     if (op.nlong) {
         if (nb > 256) throw WaeError(WAE_ERR_INVALID, "launch_spmv: batch wider than 256 columns");
-        hipLaunchKernelGGL(spmv_long_kernel, dim3((unsigned)op.nlong, (unsigned)((nb + 7) / 8)), dim3(256), 0, st, op, pc, cps, X, nb,
-                           nb >= 8 ? cmask : (const unsigned char *)nullptr);
-        HIP_CHECK(hipGetLastError());
+        launch_long_rows(op, pc, cps, X, nb, nb >= 8 ? cmask : (const unsigned char *)nullptr, st);
     }
     if (mode == MODE_AX_J0 && !(C == 8 && S == 1 && env_int("WAE_SPMV_LDS", 1))) {   // only the wide fine-level kernel fuses the sweep
         launch_spmv(op, pc, cps, X, Y, nullptr, 0.0, nb, MODE_AX, st, cmask);
@@ -2529,6 +2548,19 @@ void launch_scale_inv(const cplx *X, const cplx *alpha, cplx *Y, int64_t n, int 
 
 // The column-major side of these three is in the CALLER's row numbering, the interleaved side in the library's (tiles.h):
 // perm[i] = caller's row of internal row i (null: same numbering).
+// out = a x + b y (or a conj(x) + b y) for one vector (out may alias x or y): the column updates of the device-resident multivectors (wae_slot_axpby)
+__global__ __launch_bounds__(256) void axpby1_kernel(cplx a, const cplx *x, cplx b, const cplx *y, cplx *out, size_t n, int conj_x) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        cplx r = cmul(a, conj_x ? cconj(x[e]) : x[e]);
+        cfma(r, b, y[e]);
+        out[e] = r;
+    }
+}
+void launch_axpby1(cplx a, const cplx *x, cplx b, const cplx *y, cplx *out, size_t n, hipStream_t st, int conj_x) {
+    if (!n) return;
+    hipLaunchKernelGGL(axpby1_kernel, dim3(grid_for(n)), dim3(256), 0, st, a, x, b, y, out, n, conj_x);
+    HIP_CHECK(hipGetLastError());
+}
 __global__ __launch_bounds__(256) void colmajor_to_inter_kernel(const cplx *__restrict__ Xc, int64_t d, int r, cplx *__restrict__ Xi, int nb,
                                                                 const int *__restrict__ perm) {
     const size_t total = (size_t)d * nb;

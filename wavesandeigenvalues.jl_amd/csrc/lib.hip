@@ -31,7 +31,7 @@ OpDev LevelOp::dev(int op) const {
         const LongRows &LR = (op == WAE_OP_N) ? long_n : long_t;
         o.nlong = LR.n;
         o.long_rows = LR.rows.p; o.long_ptr = LR.ptr.p; o.long_col = LR.col.p; o.long_slot = LR.slot.p;
-        o.long_val = LR.val.p; o.long_acc = LR.acc.p;
+        o.long_val = LR.val.p; o.long_acc = LR.acc.p; o.long_part = LR.part.p;
         o.long_conj = (op == WAE_OP_C) ? 1 : 0;
     }
     for (size_t g = 0; g < groups.size(); ++g) {
@@ -134,6 +134,14 @@ struct wae_family {
     std::vector<int> pen_row_slot;
     DevBuf<int> pen_rows;
     DevBuf<cplx> pen_b, pen_x, pen_t;
+    // device-resident multivectors of the caller ("slots", wae_slot_*): d x ncols, column-major, in the library's row numbering
+    struct Slot { DevBuf<cplx> buf; int ncols = 0; };
+    Slot slots[WAE_NSLOTS];
+    // work space of the Arnoldi processes (kept between calls); after wae_arnoldi_shiftinvert_slots the basis of that call stays in
+    // arn_EV: arn_cols vectors of arn_nsys systems each, interleaved [row][system], for wae_arnoldi_ritz_to_slot
+    DevBuf<cplx> arn_EV, arn_t, arn_pcM, arn_hcol, arn_stage, arn_gdir;
+    int arn_nsys = 0, arn_cols = 0;
+    DevBuf<cplx> pt_ws, pt_Gd, pt_pcd;   // work space of wae_perturb / wae_perturb_slots (kept between calls)
     cplx *h_pinned = nullptr;        // (restart+2)*NB
     cplx *h_pin_pair = nullptr;      // staging of the pair steps of the narrow batches (gmres)
     size_t h_pin_pair_n = 0;
@@ -368,6 +376,7 @@ static std::vector<int> build_levelop(LevelOp &L, const std::vector<CsrZ> &plane
         LR.col.upload(col.data(), col.size(), st); LR.slot.upload(slot.data(), slot.size(), st);
         LR.val.upload(val.data(), val.size(), st);
         LR.acc.alloc((size_t)LR.n * 256);                     // batch widths up to 256 columns
+        LR.part.alloc((size_t)LR.n * WAE_LONG_SPLIT * 256);
         HIP_CHECK(hipStreamSynchronize(st));
     };
     upload_long(long_n, L.long_n);
@@ -553,6 +562,7 @@ static void build_level_tiles(LevelOp &L, const std::vector<CsrZ> &planes, const
             T.t_ls_slot.upload(S.ls_slot.data(), S.ls_slot.size(), st);
             T.t_ls_val.upload(S.ls_val.data(), S.ls_val.size(), st);
             T.t_ls_side.upload(S.ls_side.data(), S.ls_side.size(), st);
+            T.t_ls_part.alloc((size_t)nls * WAE_LONG_SPLIT * 256);
         }
         HIP_CHECK(hipStreamSynchronize(st));
         T.dev_t = T.dev;
@@ -563,6 +573,7 @@ static void build_level_tiles(LevelOp &L, const std::vector<CsrZ> &planes, const
         T.dev_t.nlong_side = nls;
         T.dev_t.ls_ptr = T.t_ls_ptr.p; T.dev_t.ls_col = T.t_ls_col.p; T.dev_t.ls_slot = T.t_ls_slot.p; T.dev_t.ls_val = T.t_ls_val.p;
         T.dev_t.ls_side = T.t_ls_side.p;
+        T.dev_t.ls_part = T.t_ls_part.p;
         T.ready_t = true;
         if (getenv("WAE_SETUP_DEBUG"))
             fprintf(stderr, "[tiles] transposed orientation: %d side rows with %d entries, %d long rows with %d entries\n", S.nside, S.ptr.back(), nls,
@@ -1190,9 +1201,11 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
     // residual, see add_alpha_g below; with a poor one -- the first left solve of a Newton step -- it does not: 1e-2..1e-3 of ||M^-1 b||
     // at 1M DoF).  What is left is a multiple of the near-null direction, which a further cycle cannot remove and an inverse-iteration
     // step does not care about.  A column whose recomputed residual is > 50 x the estimate its cycle ended with (estimate <= tol)
-    // continues in cycles of 10 steps, each of which has to halve the recomputed residual; otherwise it ends as stalled at once
-    // instead of after 30-50 steps without progress.
-    std::vector<double> drift_ref(nb, 0.0);
+    // switches the batch to cycles of 5 steps (enough to show whether a fresh recurrence still gains: the clean rate is ~0.55 per step),
+    // and from then on EVERY column has to halve its recomputed residual per cycle or ends as stalled -- whichever column raised the
+    // flag: the columns of a batch sit at their floors one after the other, and with the test tied to the flagged column only the
+    // right solves of a Newton step at 1M DoF spent 30 of their 78 steps on a residual that stayed at 2.6e-10.
+    std::vector<double> drift_ref(nb, 0.0);         // the recomputed residual at the previous cycle start
     bool drift_mode = false;
     for (int b = 0; b < nb; ++b) { bnorm[b] = hp[b].x; if (!(bnorm[b] > 0.0)) done[b] = 1; }
     std::vector<ColState> cs(nb);
@@ -1298,14 +1311,10 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
                 done[b] = relres[b] <= tol || stalled[b];
                 if (!done[b]) {
                     const double est = hist[b].empty() ? -1.0 : hist[b].back();
-                    if (drift_ref[b] > 0.0) {                        // a 10-step cycle lies behind this column
-                        if (relres[b] > 0.5 * drift_ref[b]) { stalled[b] = 1; done[b] = 1; }
-                        else drift_ref[b] = relres[b];
-                    } else if (est >= 0.0 && est <= tol && relres[b] > 50.0 * est) {
-                        drift_ref[b] = relres[b];
-                        drift_mode = true;
-                    }
+                    if (drift_mode && drift_ref[b] > 0.0 && relres[b] > 0.5 * drift_ref[b]) { stalled[b] = 1; done[b] = 1; }   // a 5-step cycle lies behind this column
+                    else if (est >= 0.0 && est <= tol && relres[b] > 50.0 * est) drift_mode = true;
                 }
+                drift_ref[b] = relres[b];
             }
             if (!done[b]) all_done = false;
         }
@@ -1391,7 +1400,7 @@ static int gmres(wae_family *h, const Batch &bt, const cplx *B, cplx *X, double 
         };
         std::vector<zc> rawcol((size_t)m + 3);
         int j = 0;
-        const int m_cycle = drift_mode ? std::min(m, 10) : m;
+        const int m_cycle = drift_mode ? std::min(m, 5) : m;
         while (j < m_cycle && total_it < maxit) {
             const cplx *vj = h->V.p + (size_t)(off + j) * vec;
             if (pair_cfg && j >= pair_min && j + 2 <= m_cycle && total_it + 2 <= maxit) {
@@ -2872,13 +2881,16 @@ static double dominant_ritz_residual(const std::vector<zc> &H, int ld, int k) {
     return INFINITY;
 }
 
-int wae_arnoldi_shiftinvert_batch(wae_family *h, int32_t nsys, const double *coeffsA, const double *coeffsM, int32_t m, const double *v0, int32_t op,
-                                  double tol, int32_t maxit, double ritz_tol, double *H_out, double *V_out, wae_solve_info *info) {
-    return guarded([&]() {
-        WAE_REQUIRE(h && nsys >= 1 && coeffsA && coeffsM && v0 && H_out && V_out && m >= 1 && m <= 256, "bad argument");
-        WAE_REQUIRE(op == WAE_OP_N || op == WAE_OP_C || op == WAE_OP_T, "bad op");
-        require_solver(h);
-        WAE_REQUIRE(nsys <= h->NB, "more systems than the solver batch width");
+static const cplx *slot_cols_ptr(wae_family *h, int32_t slot, const int32_t *cols, int n, DevBuf<cplx> &stage, hipStream_t st);   // (slots: below)
+
+// The Arnoldi processes behind wae_arnoldi_shiftinvert_batch (start vectors and basis through host memory) and
+// wae_arnoldi_shiftinvert_slots (start vectors from a device-resident multivector, basis kept on the device for wae_arnoldi_ritz_to_slot).
+// v0_host: d x nsys column-major in the caller's row numbering, or null: then v0_slot / v0_cols name the columns.  V_out null: the
+// basis stays in h->arn_EV (h->arn_nsys systems, h->arn_cols vectors each).
+static int arnoldi_core(wae_family *h, int32_t nsys, const double *coeffsA, const double *coeffsM, int32_t m, const double *v0_host, int32_t v0_slot,
+                        const int32_t *v0_cols, int32_t op, double tol, int32_t maxit, double ritz_tol, double *H_out, double *V_out,
+                        wae_solve_info *info) {
+    {
         HIP_CHECK(hipSetDevice(h->device));
         hipStream_t st = h->stream;
         wae_solve_info li;
@@ -2887,12 +2899,14 @@ int wae_arnoldi_shiftinvert_batch(wae_family *h, int32_t nsys, const double *coe
         const int64_t d = h->d;
         const int T = h->T;
         const size_t vec = (size_t)d * nsys;
-        DevBuf<cplx> EV, t, pcM, hcol, stage, gdir;
-        EV.alloc(vec * (m + 1));
-        t.alloc(vec);
-        if (m > 1) gdir.alloc(vec);
-        stage.alloc(vec);
-        hcol.alloc((size_t)2 * (m + 2) * nsys);
+        // (work space of the family, grown on demand and kept: a hipMalloc / hipFree pair of 0.9 GB per call at 1M DoF and 8 systems otherwise)
+        DevBuf<cplx> &EV = h->arn_EV, &t = h->arn_t, &pcM = h->arn_pcM, &hcol = h->arn_hcol, &stage = h->arn_stage, &gdir = h->arn_gdir;
+        h->arn_nsys = 0; h->arn_cols = 0;
+        ensure(EV, vec * (m + 1));
+        ensure(t, vec);
+        if (m > 1) ensure(gdir, vec);
+        ensure(stage, vec);
+        ensure(hcol, (size_t)2 * (m + 2) * nsys);
         // per-system plane coefficients of M (level-0 slot order) and of A (all levels)
         std::vector<cplx> tab((size_t)nsys * h->nplanes);
         std::vector<zc> pcm;
@@ -2910,8 +2924,13 @@ int wae_arnoldi_shiftinvert_batch(wae_family *h, int32_t nsys, const double *coe
         std::vector<std::vector<zc>> H(nsys, std::vector<zc>((size_t)(m + 1) * m, zc(0)));
         std::vector<char> dead(nsys, 0);
         // v_0 = v0 / ||v0||, column by column
-        HIP_CHECK(hipMemcpyAsync(stage.p, v0, vec * sizeof(cplx), hipMemcpyHostToDevice, st));
-        launch_colmajor_to_inter(stage.p, d, nsys, t.p, nsys, st, h->perm());
+        if (v0_host) {
+            HIP_CHECK(hipMemcpyAsync(stage.p, v0_host, vec * sizeof(cplx), hipMemcpyHostToDevice, st));
+            launch_colmajor_to_inter(stage.p, d, nsys, t.p, nsys, st, h->perm());
+        } else {                                             // (slot columns are in the library's row numbering already)
+            const cplx *S = slot_cols_ptr(h, v0_slot, v0_cols, nsys, stage, st);
+            launch_colmajor_to_inter(S, d, nsys, t.p, nsys, st, nullptr);
+        }
         launch_norms(t.p, d, nsys, h->partial.p, hcol.p, st);
         launch_scale_inv(t.p, hcol.p, EV.p, d, nsys, st);
         const OpDev Mop = h->ops[0].dev(op);
@@ -2925,6 +2944,54 @@ int wae_arnoldi_shiftinvert_batch(wae_family *h, int32_t nsys, const double *coe
         // evaluated anyway); a tenth of the bound, never looser than 1e-3, never tighter than tol.  WAE_ARNOLDI_RELAX=0: off.
         static const bool relax_on = !(getenv("WAE_ARNOLDI_RELAX") && atoi(getenv("WAE_ARNOLDI_RELAX")) == 0);
         double tol_j = tol;
+        // A poor start costs a whole process step at full accuracy: the left process of a Newton step on a non-symmetric family starts from
+        // a vector that is not close to the left eigenvector (relative Ritz residual 0.99 after its first step at 1M DoF), that step's
+        // solve ran 86 iterations to an estimate of 1e-12 whose recomputed residual stood at 2.5e-3 -- the deflation direction, the start
+        // itself, was useless -- and all it gave was a better direction.  The quality of a start is known beforehand:
+        // q = ||M^-1 A v0|| / ||v0|| (one product, one V-cycle; M^-1 A is close to the identity away from the operator's near-null space,
+        // so q ~ 1e-6 for an eigenvector estimate of that accuracy and ~ 1 for an arbitrary vector).  Columns with q > 0.1 are replaced by
+        // one step of inverse iteration from them, solved to 1e-3 only: the process then starts from a vector whose own step is worth its
+        // accuracy.  Only with the Ritz test on (the Newton-type solvers); WAE_ARNOLDI_PRESTEP=0: off.
+        static const bool prestep_on = !(getenv("WAE_ARNOLDI_PRESTEP") && atoi(getenv("WAE_ARNOLDI_PRESTEP")) == 0);
+        if (prestep_on && ritz_tol > 0.0 && m > 1 && h->ops.size() > 1 && tol < 1e-3) {
+            launch_spmv(h->ops[0].dev(op), pc_level(h, 0), bt.cps, EV.p, h->W.p, nullptr, 0.0, nsys, MODE_AX, st);
+            launch_norms(vcycle(h, bt, 0, h->W.p), d, nsys, h->partial.p, hcol.p, st);
+            HIP_CHECK(hipMemcpyAsync(hh.data(), hcol.p, (size_t)nsys * sizeof(cplx), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            std::vector<cplx> keep(nsys), take(nsys);
+            int npoor = 0;
+            for (int sy = 0; sy < nsys; ++sy) {
+                const bool poor = hh[sy].x > 0.1;
+                npoor += poor;
+                keep[sy] = cplx{poor ? 0.0 : 1.0, 0.0};
+                take[sy] = cplx{poor ? 1.0 : 0.0, 0.0};
+            }
+            if (getenv("WAE_GMRES_DEBUG")) {
+                double qmax = 0.0;
+                for (int sy = 0; sy < nsys; ++sy) qmax = std::max(qmax, hh[sy].x);
+                fprintf(stderr, "[arnoldi] start quality max %.2e: %d of %d columns take a step of inverse iteration first\n", qmax, npoor, nsys);
+                if (atoi(getenv("WAE_GMRES_DEBUG")) > 2) { fprintf(stderr, "[arnoldi]   q ="); for (int sy = 0; sy < nsys; ++sy) fprintf(stderr, " %.2e", hh[sy].x); fprintf(stderr, "\n"); }
+            }
+            if (npoor) {
+                wae_solve_info lpre;
+                memset(&lpre, 0, sizeof(lpre));
+                launch_spmv(Mop, pcM.p, 1, EV.p, t.p, nullptr, 0.0, nsys, MODE_AX, st);
+                // (no deflation direction: the start is the only candidate and deflating a vector that is NOT near the null space costs
+                // iterations -- 93 against 50 at 1M DoF; the restarted wide recurrence stalls on these systems: 161 steps)
+                gmres(h, bt, t.p, h->Xs.p, 1e-3, maxit, &lpre, nullptr);
+                li.iters_max = std::max(li.iters_max, lpre.iters_max);
+                li.iters_total += lpre.iters_total;
+                launch_norms(h->Xs.p, d, nsys, h->partial.p, hcol.p, st);
+                launch_scale_inv(h->Xs.p, hcol.p, t.p, d, nsys, st);                 // t = the normalised iterates
+                h->ydev.upload(keep.data(), nsys, st);
+                launch_mask_cols(EV.p, h->ydev.p, d, nsys, st);
+                HIP_CHECK(hipStreamSynchronize(st));                                 // (ydev is read by the kernel: before the next upload)
+                h->ydev.upload(take.data(), nsys, st);
+                launch_mask_cols(t.p, h->ydev.p, d, nsys, st);
+                launch_add(t.p, EV.p, vec, st);
+                HIP_CHECK(hipStreamSynchronize(st));
+            }
+        }
         for (int j = 0; j < m; ++j) {
             launch_spmv(Mop, pcM.p, 1, EV.p + (size_t)j * vec, t.p, nullptr, 0.0, nsys, MODE_AX, st);
             // the start vector is the caller's estimate of the wanted eigenvector: deflated out of the first solve of the process; the
@@ -2979,22 +3046,37 @@ int wae_arnoldi_shiftinvert_batch(wae_family *h, int32_t nsys, const double *coe
         // V_out[sys] = d x (m+1) column-major; only the columns the processes produced are written (steps taken + 1): the rest
         // of the caller's buffer is left as it was (the H columns beyond them are zero) -- at 1M DoF and 8 systems every column is
         // 128 MB of host memory to touch
-        for (int j = 0; j <= std::min(done, m); ++j) {
-            launch_inter_to_colmajor(EV.p + (size_t)j * vec, nsys, d, nsys, stage.p, st, h->perm());
-            for (int sy = 0; sy < nsys; ++sy)
-                HIP_CHECK(hipMemcpyAsync(V_out + ((size_t)sy * (m + 1) + j) * d * 2, stage.p + (size_t)sy * d, (size_t)d * sizeof(cplx),
-                                         hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipStreamSynchronize(st));
+        if (V_out) {
+            for (int j = 0; j <= std::min(done, m); ++j) {
+                launch_inter_to_colmajor(EV.p + (size_t)j * vec, nsys, d, nsys, stage.p, st, h->perm());
+                for (int sy = 0; sy < nsys; ++sy)
+                    HIP_CHECK(hipMemcpyAsync(V_out + ((size_t)sy * (m + 1) + j) * d * 2, stage.p + (size_t)sy * d, (size_t)d * sizeof(cplx),
+                                             hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+            }
+            if (done < m && !(ritz_tol > 0.0))               // every process ended in an invariant subspace: the documented zeros
+                for (int sy = 0; sy < nsys; ++sy)
+                    memset(V_out + ((size_t)sy * (m + 1) + done + 1) * d * 2, 0, (size_t)(m - done) * d * sizeof(cplx));
+        } else {
+            h->arn_nsys = nsys;
+            h->arn_cols = std::min(done, m) + 1;
         }
-        if (done < m && !(ritz_tol > 0.0))               // every process ended in an invariant subspace: the documented zeros
-            for (int sy = 0; sy < nsys; ++sy)
-                memset(V_out + ((size_t)sy * (m + 1) + done + 1) * d * 2, 0, (size_t)(m - done) * d * sizeof(cplx));
         for (int sy = 0; sy < nsys; ++sy) memcpy(H_out + (size_t)sy * (m + 1) * m * 2, H[sy].data(), H[sy].size() * sizeof(zc));
-        EV.release(); t.release(); pcM.release(); hcol.release(); stage.release(); gdir.release();
         li.seconds = now_s() - t0;
         const int rc_ = info_code(li);
         if (info) *info = li;
         return rc_;
+    }
+}
+
+int wae_arnoldi_shiftinvert_batch(wae_family *h, int32_t nsys, const double *coeffsA, const double *coeffsM, int32_t m, const double *v0, int32_t op,
+                                  double tol, int32_t maxit, double ritz_tol, double *H_out, double *V_out, wae_solve_info *info) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && nsys >= 1 && coeffsA && coeffsM && v0 && H_out && V_out && m >= 1 && m <= 256, "bad argument");
+        WAE_REQUIRE(op == WAE_OP_N || op == WAE_OP_C || op == WAE_OP_T, "bad op");
+        require_solver(h);
+        WAE_REQUIRE(nsys <= h->NB, "more systems than the solver batch width");
+        return arnoldi_core(h, nsys, coeffsA, coeffsM, m, v0, -1, nullptr, op, tol, maxit, ritz_tol, H_out, V_out, info);
     });
 }
 
@@ -3003,10 +3085,11 @@ int wae_arnoldi_shiftinvert(wae_family *h, const double *coeffsA, const double *
     return wae_arnoldi_shiftinvert_batch(h, 1, coeffsA, coeffsM, m, v0, op, tol, maxit, 0.0, H_out, V_out, info);
 }
 
-int wae_perturb(wae_family *h, const double *coeff_table, int32_t N, const double *v0, const double *v0adj, int32_t norm_mode_in, const double *coeffsY,
-                double tol, int32_t maxit, double *lambda_out, double *v_out, wae_solve_info *info) {
-    return guarded([&]() {
-        WAE_REQUIRE(h && coeff_table && v0 && v0adj && lambda_out && v_out && N >= 0 && N <= 200, "bad argument");
+// wae_perturb (v0, v0adj, v_out in host memory) and wae_perturb_slots (v0d, v0adjd: device columns in the library's row numbering;
+// v_out may be null: eigenvalue series only)
+static int perturb_core(wae_family *h, const double *coeff_table, int32_t N, const double *v0, const double *v0adj, const cplx *v0d, const cplx *v0adjd,
+                        int32_t norm_mode_in, const double *coeffsY, double tol, int32_t maxit, double *lambda_out, double *v_out, wae_solve_info *info) {
+    {
         const bool skip_last = (norm_mode_in & 16) != 0;    // eigenvalue series only: no solve at order N
         const int norm_mode = norm_mode_in & 15;
         WAE_REQUIRE(norm_mode >= 0 && norm_mode <= 2 && (norm_mode != 2 || coeffsY), "bad norm_mode");
@@ -3019,9 +3102,19 @@ int wae_perturb(wae_family *h, const double *coeff_table, int32_t N, const doubl
         const int64_t d = h->d;
         const int T = h->T;
         auto F = [&](int m, int n, int k) { return zc(coeff_table[((size_t)(m * (N + 1) + n) * T + k) * 2], coeff_table[((size_t)(m * (N + 1) + n) * T + k) * 2 + 1]); };
-        DevBuf<cplx> PV, Ub, rb, rhs, u10, wl, tmp, tmp2, tmp3, sc, Gd, pcd;
-        PV.alloc((size_t)d * (N + 1)); Ub.alloc((size_t)d * T); rb.alloc(d); rhs.alloc(d); u10.alloc(d); wl.alloc(d); tmp.alloc(d); tmp2.alloc(d); tmp3.alloc(d);
-        sc.alloc(8); Gd.alloc((size_t)(N + 1) * T + 4);
+        // (one allocation of the family, carved up and kept: twelve hipMalloc / hipFree pairs per call otherwise -- a Newton step of the
+        // Householder iteration calls this once per start value)
+        struct Span { cplx *p = nullptr; } PV, Ub, rb, rhs, u10, wl, tmp, tmp2, tmp3, sc;
+        ensure(h->pt_ws, (size_t)d * (N + 1) + (size_t)d * T + (size_t)7 * d + 8);
+        {
+            cplx *q = h->pt_ws.p;
+            PV.p = q; q += (size_t)d * (N + 1);
+            Ub.p = q; q += (size_t)d * T;
+            for (Span *sp : {&rb, &rhs, &u10, &wl, &tmp, &tmp2, &tmp3}) { sp->p = q; q += d; }
+            sc.p = q;
+        }
+        DevBuf<cplx> &Gd = h->pt_Gd, &pcd = h->pt_pcd;
+        ensure(Gd, (size_t)(N + 1) * T + 4);
         const OpDev A0 = h->ops[0].dev(WAE_OP_N);
         cplx hs[4];
         auto plane_tab = [&](const double *coeffs, int op) {     // level-0 plane table for an spmv
@@ -3065,11 +3158,16 @@ int wae_perturb(wae_family *h, const double *coeff_table, int32_t N, const doubl
         }
         // v[0] = v0 / sqrt(ip(v0,v0))
         cplx *V0 = PV.p;
-        ensure(h->io_a, (size_t)2 * d);                                   // caller's row numbering -> the library's
-        HIP_CHECK(hipMemcpyAsync(h->io_a.p, v0, (size_t)d * sizeof(cplx), hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(h->io_a.p + d, v0adj, (size_t)d * sizeof(cplx), hipMemcpyHostToDevice, st));
-        launch_colmajor_to_inter(h->io_a.p, d, 1, V0, 1, st, h->perm());
-        launch_colmajor_to_inter(h->io_a.p + d, d, 1, wl.p, 1, st, h->perm());
+        if (v0d) {
+            launch_copy(v0d, V0, (size_t)d, st);
+            launch_copy(v0adjd, wl.p, (size_t)d, st);
+        } else {
+            ensure(h->io_a, (size_t)2 * d);                               // caller's row numbering -> the library's
+            HIP_CHECK(hipMemcpyAsync(h->io_a.p, v0, (size_t)d * sizeof(cplx), hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(h->io_a.p + d, v0adj, (size_t)d * sizeof(cplx), hipMemcpyHostToDevice, st));
+            launch_colmajor_to_inter(h->io_a.p, d, 1, V0, 1, st, h->perm());
+            launch_colmajor_to_inter(h->io_a.p + d, d, 1, wl.p, 1, st, h->perm());
+        }
         {
             const zc nn = ipY(V0, V0);
             axpby(1.0 / std::sqrt(nn), V0, 0.0, V0, V0);
@@ -3165,16 +3263,190 @@ int wae_perturb(wae_family *h, const double *coeff_table, int32_t N, const doubl
                 }
             }
         }
-        ensure(h->io_b, (size_t)d * (N + 1));
-        for (int k = 0; k <= N; ++k) launch_inter_to_colmajor(PV.p + (size_t)k * d, 1, d, 1, h->io_b.p + (size_t)k * d, st, h->perm());
-        HIP_CHECK(hipMemcpyAsync(v_out, h->io_b.p, (size_t)d * (N + 1) * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        if (v_out) {
+            ensure(h->io_b, (size_t)d * (N + 1));
+            for (int k = 0; k <= N; ++k) launch_inter_to_colmajor(PV.p + (size_t)k * d, 1, d, 1, h->io_b.p + (size_t)k * d, st, h->perm());
+            HIP_CHECK(hipMemcpyAsync(v_out, h->io_b.p, (size_t)d * (N + 1) * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        }
         HIP_CHECK(hipStreamSynchronize(st));
         for (int k = 1; k <= N; ++k) { lambda_out[2 * k] = lam[k].real(); lambda_out[2 * k + 1] = lam[k].imag(); }
-        for (auto *bf : {&PV, &Ub, &rb, &rhs, &u10, &wl, &tmp, &tmp2, &tmp3, &sc, &Gd, &pcd}) bf->release();
         li.seconds = now_s() - t0;
         const int rc_ = info_code(li);
         if (info) *info = li;
         return rc_;
+    }
+}
+
+int wae_perturb(wae_family *h, const double *coeff_table, int32_t N, const double *v0, const double *v0adj, int32_t norm_mode_in, const double *coeffsY,
+                double tol, int32_t maxit, double *lambda_out, double *v_out, wae_solve_info *info) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && coeff_table && v0 && v0adj && lambda_out && v_out && N >= 0 && N <= 200, "bad argument");
+        return perturb_core(h, coeff_table, N, v0, v0adj, nullptr, nullptr, norm_mode_in, coeffsY, tol, maxit, lambda_out, v_out, info);
+    });
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Device-resident multivectors ("slots").  The Newton-type solvers iterate on a handful of vectors per start value (right and left
+// eigenvector estimates, the Ritz vectors of the step): with the processes' inputs and outputs in host memory a Householder step of 8
+// start values at 1M DoF moved 2 GB over PCIe into freshly touched pages and spent as long in host copies as the GPU spent computing
+// (45 % idle in the kernel trace).  A slot holds d x ncols in the library's row numbering; the calls below read and write slot columns
+// in place of host arrays, so that an iteration touches host memory once at its start and once at its end.
+// ----------------------------------------------------------------------------------------------------
+static wae_family::Slot &slot_ref(wae_family *h, int32_t slot) {
+    WAE_REQUIRE(slot >= 0 && slot < WAE_NSLOTS, "slot index out of range");
+    return h->slots[slot];
+}
+static cplx *slot_col(wae_family *h, int32_t slot, int32_t col) {
+    wae_family::Slot &S = slot_ref(h, slot);
+    WAE_REQUIRE(S.ncols > 0, "slot is empty");
+    WAE_REQUIRE(col >= 0 && col < S.ncols, "slot column out of range");
+    return S.buf.p + (size_t)col * h->d;
+}
+// n columns of a slot as one contiguous column-major block: the slot's own memory if they are consecutive, a copy in `stage` otherwise
+static const cplx *slot_cols_ptr(wae_family *h, int32_t slot, const int32_t *cols, int n, DevBuf<cplx> &stage, hipStream_t st) {
+    WAE_REQUIRE(cols && n >= 1, "bad argument");
+    bool consecutive = true;
+    for (int i = 0; i < n; ++i) { (void)slot_col(h, slot, cols[i]); consecutive = consecutive && cols[i] == cols[0] + i; }
+    if (consecutive) return slot_col(h, slot, cols[0]);
+    ensure(stage, (size_t)n * h->d);
+    for (int i = 0; i < n; ++i) launch_copy(slot_col(h, slot, cols[i]), stage.p + (size_t)i * h->d, (size_t)h->d, st);
+    return stage.p;
+}
+
+int wae_slot_write(wae_family *h, int32_t slot, int32_t ncols_total, int32_t col0, int32_t ncols, const double *X) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && ncols_total >= 1 && ncols_total <= 256 && col0 >= 0 && ncols >= 0 && col0 + ncols <= ncols_total && (ncols == 0 || X), "bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        wae_family::Slot &S = slot_ref(h, slot);
+        const int64_t d = h->d;
+        if (S.ncols != ncols_total) {                        // (re)created: zero columns
+            S.buf.alloc((size_t)d * ncols_total);
+            S.ncols = ncols_total;
+            launch_fill_zero(S.buf.p, (size_t)d * ncols_total, st);
+        }
+        if (ncols) {
+            ensure(h->io_a, (size_t)d * ncols);
+            HIP_CHECK(hipMemcpyAsync(h->io_a.p, X, (size_t)d * ncols * sizeof(cplx), hipMemcpyHostToDevice, st));
+            for (int c = 0; c < ncols; ++c) launch_colmajor_to_inter(h->io_a.p + (size_t)c * d, d, 1, S.buf.p + (size_t)(col0 + c) * d, 1, st, h->perm());
+        }
+        HIP_CHECK(hipStreamSynchronize(st));
+        return WAE_OK;
+    });
+}
+
+int wae_slot_read(wae_family *h, int32_t slot, int32_t col0, int32_t ncols, double *X) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && col0 >= 0 && ncols >= 0 && (ncols == 0 || X), "bad argument");
+        if (!ncols) return WAE_OK;
+        HIP_CHECK(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        (void)slot_col(h, slot, col0);
+        (void)slot_col(h, slot, col0 + ncols - 1);
+        const int64_t d = h->d;
+        ensure(h->io_b, (size_t)d * ncols);
+        for (int c = 0; c < ncols; ++c) launch_inter_to_colmajor(slot_col(h, slot, col0 + c), 1, d, 1, h->io_b.p + (size_t)c * d, st, h->perm());
+        HIP_CHECK(hipMemcpyAsync(X, h->io_b.p, (size_t)d * ncols * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        return WAE_OK;
+    });
+}
+
+int wae_slot_axpby(wae_family *h, int32_t n, int32_t dst_slot, const int32_t *dst_cols, int32_t src_slot, const int32_t *src_cols, const double *alpha,
+                   const double *beta, int32_t conj_src) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && n >= 0 && (n == 0 || (dst_cols && src_cols && alpha && beta)), "bad argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        for (int i = 0; i < n; ++i) {
+            cplx *y = slot_col(h, dst_slot, dst_cols[i]);
+            const cplx *x = slot_col(h, src_slot, src_cols[i]);
+            launch_axpby1(cplx{alpha[2 * i], alpha[2 * i + 1]}, x, cplx{beta[2 * i], beta[2 * i + 1]}, y, y, (size_t)h->d, st, conj_src ? 1 : 0);
+        }
+        HIP_CHECK(hipStreamSynchronize(st));
+        return WAE_OK;
+    });
+}
+
+int wae_slot_forms(wae_family *h, int32_t n, const double *coeffs, int32_t op, int32_t a_slot, const int32_t *a_cols, int32_t b_slot, const int32_t *b_cols,
+                   double *out) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && n >= 0 && (n == 0 || (coeffs && a_cols && b_cols && out)), "bad argument");
+        WAE_REQUIRE(op == WAE_OP_N || op == WAE_OP_C || op == WAE_OP_T, "bad op");
+        if (!n) return WAE_OK;
+        WAE_REQUIRE(n <= 256, "more than 256 forms in one call");
+        HIP_CHECK(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        const int64_t d = h->d;
+        const int T = h->T;
+        const size_t vec = (size_t)d * n;
+        ensure(h->io_b, 3 * vec);
+        cplx *Bi = h->io_b.p, *ABi = Bi + vec, *Ai = ABi + vec;
+        launch_colmajor_to_inter(slot_cols_ptr(h, b_slot, b_cols, n, h->io_a, st), d, n, Bi, n, st, nullptr);
+        launch_colmajor_to_inter(slot_cols_ptr(h, a_slot, a_cols, n, h->io_a, st), d, n, Ai, n, st, nullptr);
+        std::vector<cplx> tab((size_t)n * h->nplanes);
+        std::vector<zc> pc;
+        for (int i = 0; i < n; ++i) {
+            plane_coeffs(h, coeffs + (size_t)i * 2 * T, op, pc);
+            for (int q = 0; q < h->nplanes; ++q) { const zc c = pc[h->slot_plane[0][q]]; tab[(size_t)i * h->nplanes + q] = cplx{c.real(), c.imag()}; }
+        }
+        h->pt_pcd.upload(tab.data(), tab.size(), st);
+        launch_spmv(h->ops[0].dev(op), h->pt_pcd.p, 1, Bi, ABi, nullptr, 0.0, n, MODE_AX, st);
+        ensure(h->partial, (size_t)1024 * 32 * std::max(n, 8));      // (launch_dots: DOT_BLOCKS x vectors x columns; the solver set-up allocates more)
+        ensure(h->pt_Gd, (size_t)n);
+        launch_dots(Ai, 0, 1, ABi, d, n, h->partial.p, h->pt_Gd.p, st);
+        std::vector<cplx> r(n);
+        HIP_CHECK(hipMemcpyAsync(r.data(), h->pt_Gd.p, (size_t)n * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        for (int i = 0; i < n; ++i) { out[2 * i] = r[i].x; out[2 * i + 1] = r[i].y; }
+        return WAE_OK;
+    });
+}
+
+int wae_arnoldi_shiftinvert_slots(wae_family *h, int32_t nsys, const double *coeffsA, const double *coeffsM, int32_t m, int32_t v0_slot,
+                                  const int32_t *v0_cols, int32_t op, double tol, int32_t maxit, double ritz_tol, double *H_out, wae_solve_info *info) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && nsys >= 1 && coeffsA && coeffsM && v0_cols && H_out && m >= 1 && m <= 256, "bad argument");
+        WAE_REQUIRE(op == WAE_OP_N || op == WAE_OP_C || op == WAE_OP_T, "bad op");
+        require_solver(h);
+        WAE_REQUIRE(nsys <= h->NB, "more systems than the solver batch width");
+        for (int i = 0; i < nsys; ++i) (void)slot_col(h, v0_slot, v0_cols[i]);
+        return arnoldi_core(h, nsys, coeffsA, coeffsM, m, nullptr, v0_slot, v0_cols, op, tol, maxit, ritz_tol, H_out, nullptr, info);
+    });
+}
+
+int wae_arnoldi_ritz_to_slot(wae_family *h, int32_t nsys, int32_t ny, const double *y, int32_t dst_slot, const int32_t *dst_cols, int32_t normalise) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && nsys >= 1 && ny >= 1 && y && dst_cols, "bad argument");
+        WAE_REQUIRE(h->arn_nsys == nsys && ny <= h->arn_cols, "no Arnoldi basis of that shape on the device (wae_arnoldi_shiftinvert_slots first)");
+        HIP_CHECK(hipSetDevice(h->device));
+        hipStream_t st = h->stream;
+        const int64_t d = h->d;
+        const size_t vec = (size_t)d * nsys;
+        for (int i = 0; i < nsys; ++i) (void)slot_col(h, dst_slot, dst_cols[i]);
+        std::vector<cplx> yc((size_t)ny * nsys);
+        for (int sy = 0; sy < nsys; ++sy)
+            for (int j = 0; j < ny; ++j) yc[(size_t)j * nsys + sy] = cplx{y[((size_t)sy * ny + j) * 2], y[((size_t)sy * ny + j) * 2 + 1]};
+        ensure(h->arn_hcol, yc.size() + (size_t)nsys);
+        HIP_CHECK(hipMemcpyAsync(h->arn_hcol.p, yc.data(), yc.size() * sizeof(cplx), hipMemcpyHostToDevice, st));
+        launch_lincomb(h->arn_EV.p, vec, ny, h->arn_hcol.p, h->arn_t.p, d, nsys, st);
+        if (normalise) {
+            launch_norms(h->arn_t.p, d, nsys, h->partial.p, h->arn_hcol.p + yc.size(), st);
+            launch_scale_inv(h->arn_t.p, h->arn_hcol.p + yc.size(), h->arn_t.p, d, nsys, st);
+        }
+        launch_inter_to_colmajor(h->arn_t.p, nsys, d, nsys, h->arn_stage.p, st, nullptr);
+        for (int i = 0; i < nsys; ++i) launch_copy(h->arn_stage.p + (size_t)i * d, slot_col(h, dst_slot, dst_cols[i]), (size_t)d, st);
+        HIP_CHECK(hipStreamSynchronize(st));                 // (yc is a stack vector)
+        return WAE_OK;
+    });
+}
+
+int wae_perturb_slots(wae_family *h, const double *coeff_table, int32_t N, int32_t v_slot, int32_t v_col, int32_t vadj_slot, int32_t vadj_col,
+                      int32_t norm_mode_in, const double *coeffsY, double tol, int32_t maxit, double *lambda_out, double *v_out, wae_solve_info *info) {
+    return guarded([&]() {
+        WAE_REQUIRE(h && coeff_table && lambda_out && N >= 0 && N <= 200, "bad argument");
+        return perturb_core(h, coeff_table, N, nullptr, nullptr, slot_col(h, v_slot, v_col), slot_col(h, vadj_slot, vadj_col), norm_mode_in, coeffsY,
+                            tol, maxit, lambda_out, v_out, info);
     });
 }
 

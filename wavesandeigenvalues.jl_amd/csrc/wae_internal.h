@@ -102,6 +102,7 @@ struct TileDev {
     int nlong_side;
     const int *ls_ptr, *ls_col, *ls_slot, *ls_side;   // per long side row: entry offsets; per entry: column, plane slot; side-row index
     const cplx *ls_val;
+    cplx *ls_part;                  // [nlong_side][WAE_LONG_SPLIT][nb max] partial sums of the pieces of the long side rows
 };
 struct OpDev {
     int ngroups;
@@ -120,10 +121,12 @@ struct OpDev {
     const int *long_ptr;            // nlong+1 offsets into the entries
     const int *long_col, *long_slot;   // per entry: column, plane slot (coefficient index)
     const cplx *long_val;           // per entry: value
-    cplx *long_acc;                 // [nlong][nb max] scratch filled by launch_spmv's pre-kernel
+    cplx *long_acc;                 // [nlong][nb max] scratch filled by launch_spmv's pre-kernels
+    cplx *long_part;                // [nlong][WAE_LONG_SPLIT][nb max] partial sums of the pieces the rows are summed in
     int long_conj;                  // conjugate the entry values (op = C on complex planes)
 };
 constexpr int WAE_LONG_ROW = 256;
+constexpr int WAE_LONG_SPLIT = 32;       // workgroups a long row's entries are split over (kernels.hip long_row_piece)
 
 // device buffer: owns its allocation (freed on destruction, so an exception that leaves a C-ABI entry through guarded()
 // releases every function-local buffer); movable, not copyable
@@ -179,7 +182,7 @@ struct TileStore {                  // device arrays behind a TileDev
     // transposed orientation (round 3): the bulk group is symmetric, so the tile storage itself serves op = T/C; only the side rows
     // (rows of the other groups' TRANSPOSES) are their own
     DevBuf<int> t_side_of_row, t_side_ptr, t_side_col, t_side_slot, t_ls_ptr, t_ls_col, t_ls_slot, t_ls_side;
-    DevBuf<cplx> t_side_val, t_side_acc, t_ls_val;
+    DevBuf<cplx> t_side_val, t_side_acc, t_ls_val, t_ls_part;
     TileDev dev_t;
     bool ready_t = false;
 };
@@ -187,7 +190,7 @@ struct TileStore {                  // device arrays behind a TileDev
 struct LongRows {                   // device arrays of the long rows of one orientation (see OpDev)
     int n = 0;
     DevBuf<int> rows, ptr, col, slot;
-    DevBuf<cplx> val, acc;
+    DevBuf<cplx> val, acc, part;
 };
 
 struct LevelOp {                    // sum_q pc[q] * plane_q  at one multigrid level
@@ -282,6 +285,8 @@ void launch_lincomb_add(const cplx *V, size_t stride, int nv, const cplx *y, cpl
 void launch_norms(const cplx *X, int64_t n, int nb, cplx *partial, cplx *out, hipStream_t s, const unsigned char *cmask = nullptr);
 // Y[:,b] = X[:,b] * (1/alpha[b].x)  (0 if alpha tiny)
 void launch_scale_inv(const cplx *X, const cplx *alpha, cplx *Y, int64_t n, int nb, hipStream_t s, const unsigned char *cmask = nullptr);
+// out = a x + b y, one vector (out may alias x or y); conj_x: a conj(x) + b y
+void launch_axpby1(cplx a, const cplx *x, cplx b, const cplx *y, cplx *out, size_t n, hipStream_t s, int conj_x = 0);
 // Y += X
 void launch_add(const cplx *X, cplx *Y, size_t count, hipStream_t s);
 // layout changes: column-major d x r  <->  interleaved [d][nb] (columns >= r zero-filled / ignored)

@@ -317,6 +317,90 @@ class DeviceFamily:
         self._report(code, info, f"perturb (order {N})", quiet=quiet)
         return lam, V
 
+    # -- device-resident multivectors ("slots", include/waehip.h): the vectors of the Newton-type solvers stay in HBM between the calls
+    NSLOTS = 8
+
+    @staticmethod
+    def _icols(cols):
+        a = np.ascontiguousarray(cols, dtype=np.int32).reshape(-1)
+        return a, a.ctypes.data_as(C.POINTER(C.c_int32))
+
+    def slot_write(self, slot, X=None, ncols_total=None, col0=0):
+        """wae_slot_write: X (d x ncols) into columns col0.. of the slot, (re)created with ncols_total columns (default: X's) if its width differs"""
+        if X is None:
+            check(_lib.lib().wae_slot_write(self.handle, int(slot), int(ncols_total), int(col0), 0, None))
+            return
+        Xf = np.asarray(X, dtype=np.complex128)
+        Xf = Xf.reshape(self.d, -1)
+        if not Xf.flags.f_contiguous:
+            Xf = np.asfortranarray(Xf)
+        n = Xf.shape[1]
+        check(_lib.lib().wae_slot_write(self.handle, int(slot), int(n if ncols_total is None else ncols_total), int(col0), n, zptr(Xf)))
+
+    def slot_read(self, slot, col0, ncols):
+        X = np.empty((self.d, int(ncols)), dtype=np.complex128, order="F")
+        check(_lib.lib().wae_slot_read(self.handle, int(slot), int(col0), int(ncols), zptr(X)))
+        return X
+
+    def slot_axpby(self, dst_slot, dst_cols, src_slot, src_cols, alpha=1.0, beta=0.0, conj_src=False):
+        """dst[:, dst_cols[i]] = alpha[i] src[:, src_cols[i]] + beta[i] dst[:, dst_cols[i]], one column after the other (conj_src: the
+        conjugate of the source column)"""
+        dc, dcp = self._icols(dst_cols)
+        sc, scp = self._icols(src_cols)
+        n = len(dc)
+        assert len(sc) == n
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(alpha, dtype=np.complex128), (n,)))
+        b = np.ascontiguousarray(np.broadcast_to(np.asarray(beta, dtype=np.complex128), (n,)))
+        check(_lib.lib().wae_slot_axpby(self.handle, n, int(dst_slot), dcp, int(src_slot), scp, zptr(a), zptr(b), 1 if conj_src else 0))
+
+    def slot_forms(self, coeffs, a_slot, a_cols, b_slot, b_cols, op=OP_N):
+        """out[i] = a_i^H op(sum_k coeffs[i, k] A_k) b_i for pairs of slot columns"""
+        ac, acp = self._icols(a_cols)
+        bc, bcp = self._icols(b_cols)
+        n = len(ac)
+        assert len(bc) == n
+        c = np.ascontiguousarray(np.broadcast_to(np.asarray(coeffs, dtype=np.complex128).reshape(-1, self.T), (n, self.T)))
+        out = np.zeros(n, dtype=np.complex128)
+        check(_lib.lib().wae_slot_forms(self.handle, n, zptr(c), int(op), int(a_slot), acp, int(b_slot), bcp, zptr(out)))
+        return out
+
+    def arnoldi_slots(self, coeffsA, coeffsM, m, v0_slot, v0_cols, op=OP_N, tol=1e-12, maxit=300, ritz_tol=0.0, quiet=False):
+        """wae_arnoldi_shiftinvert_slots: as arnoldi_batch with the start vectors in slot columns; returns H (nsys, m+1, m) only --
+        the basis stays on the device for ritz_to_slot"""
+        cA = np.ascontiguousarray(coeffsA, dtype=np.complex128).reshape(-1, self.T)
+        nsys = cA.shape[0]
+        cM = np.ascontiguousarray(np.broadcast_to(np.asarray(coeffsM, dtype=np.complex128).reshape(-1, self.T), (nsys, self.T)))
+        vc, vcp = self._icols(v0_cols)
+        assert len(vc) == nsys
+        H = np.zeros((nsys, m, m + 1), dtype=np.complex128)            # each block column-major (m+1) x m
+        info = SolveInfo()
+        code = check(_lib.lib().wae_arnoldi_shiftinvert_slots(self.handle, nsys, zptr(cA), zptr(cM), m, int(v0_slot), vcp, op, tol, maxit,
+                                                              float(ritz_tol), zptr(H), C.byref(info)))
+        self._report(code, info, "arnoldi_slots", quiet=quiet)
+        return H.transpose(0, 2, 1)
+
+    def ritz_to_slot(self, Y, dst_slot, dst_cols, normalise=True):
+        """wae_arnoldi_ritz_to_slot: dst[:, dst_cols[s]] = sum_j Y[s, j] v_j^(s) of the basis of the last arnoldi_slots call"""
+        Yc = np.ascontiguousarray(Y, dtype=np.complex128)
+        nsys, ny = Yc.shape
+        dc, dcp = self._icols(dst_cols)
+        assert len(dc) == nsys
+        check(_lib.lib().wae_arnoldi_ritz_to_slot(self.handle, nsys, ny, zptr(Yc), int(dst_slot), dcp, 1 if normalise else 0))
+
+    def perturb_slots(self, coeff_table, N, v_slot, v_col, vadj_slot, vadj_col, norm_mode=1, coeffsY=None, tol=1e-12, maxit=400, quiet=False,
+                      vectors=False):
+        """wae_perturb_slots: wae_perturb on slot columns; vectors=False: the eigenvalue series only (no vector leaves the device)"""
+        ct = np.ascontiguousarray(coeff_table, dtype=np.complex128).reshape((N + 1) * (N + 1), self.T)
+        lam = np.zeros(N + 1, dtype=np.complex128)
+        V = np.zeros((self.d, N + 1), dtype=np.complex128, order="F") if vectors else None
+        cy = None if coeffsY is None else np.ascontiguousarray(coeffsY, dtype=np.complex128)
+        info = SolveInfo()
+        code = check(_lib.lib().wae_perturb_slots(self.handle, zptr(ct), N, int(v_slot), int(v_col), int(vadj_slot), int(vadj_col), norm_mode,
+                                                  None if cy is None else zptr(cy), tol, maxit, zptr(lam), None if V is None else zptr(V),
+                                                  C.byref(info)))
+        self._report(code, info, f"perturb_slots (order {N})", quiet=quiet)
+        return lam, V
+
     def debug_spmv(self, coeffs, X, mode=0, B=None, Y0=None, op=OP_N, jac_w=0.8, cmask=None, level=0, which=0, no_tiles=False):
         """wae_debug_spmv (test hook): one launch of the fused operator product in any of the solver's forms.  Returns Y, or
         (Y, B2) for mode 6.  ``level``/``which`` select a coarse-level operator or a restriction of the multigrid hierarchy."""

@@ -15,7 +15,7 @@ import scipy.sparse as sp
 from .._lib import OP_C, OP_N, WaeError
 from .algebra import pow1
 from .linopfam import Operator, Solution, Term, pade, poly_roots, polyval
-from .perturbation import perturb_
+from .perturbation import eigval_series_slots, perturb_
 
 # iterative_solvers.jl:4-14
 itsol_converged = 0
@@ -518,32 +518,36 @@ def eigs_many(fam, cA, cM, v0s, op, sigmas, nev=1, tol=1e-12, maxiter=300, stol=
     return out
 
 
-def _conjugate_span_start(V):
-    """Start vectors of the left (adjoint) Arnoldi processes when the caller gives none.  `householder` starts from conj(v0)
-    (Householder.jl:84-86), the left eigenvector of a complex-symmetric L(z) -- as long as v0^T v0 != 0.  For a (nearly) degenerate
-    pair that fails: a spinning mode e^{im phi} of an annulus has v^T v = 0 and conj(v) is the OTHER mode of the pair, so the left
-    process starts orthogonal to what it looks for (four Arnoldi steps instead of two at 1M DoF).  With several start vectors at
-    hand the left vectors are taken from their conjugate span instead, bi-orthogonal to them in the bilinear form:
-    W = conj(V G^-1), G = V^T V -- conj(v0) up to scale for an isolated mode, the partner's conjugate for a spinning pair.  Only a
-    start: the converged left eigenvectors do not depend on it.  Falls back to conj(V) when G is numerically singular (dependent
-    start vectors, or a spinning mode without its partner)."""
+def _conjugate_span_coefficients(V):
+    """C (ns x ns) with  W = conj(V C)  the start vectors of the left (adjoint) Arnoldi processes when the caller gives none, or None for
+    W = conj(V).  `householder` starts from conj(v0) (Householder.jl:84-86), the left eigenvector of a complex-symmetric L(z) -- as long
+    as v0^T v0 != 0.  For a (nearly) degenerate pair that fails: a spinning mode e^{im phi} of an annulus has v^T v = 0 and conj(v) is the
+    OTHER mode of the pair, so the left process starts orthogonal to what it looks for (four Arnoldi steps instead of two at 1M DoF).
+    With several start vectors at hand the left vectors are taken from their conjugate span instead, bi-orthogonal to them in the
+    bilinear form: W = conj(Vn G^-1), Vn = V with unit columns, G = Vn^T Vn -- conj(v0) up to scale for an isolated mode, the partner's
+    conjugate for a spinning pair.  Only a start: the converged left eigenvectors do not depend on it.  None when G is numerically
+    singular (dependent start vectors, or a spinning mode without its partner).  (Two readings of V, no copy of it.)"""
     ns = V.shape[1]
     if ns < 2:
-        return np.conj(V)
-    nrm = np.linalg.norm(V, axis=0)
+        return None
+    nrm = np.sqrt(np.einsum("ij,ij->j", V.real, V.real) + np.einsum("ij,ij->j", V.imag, V.imag))
     nrm[nrm == 0] = 1.0
-    Vn = V / nrm
-    G = Vn.T @ Vn
+    G = (V.T @ V) / np.outer(nrm, nrm)
     if not np.all(np.isfinite(G)) or np.linalg.svd(G, compute_uv=False)[-1] < 1e-6:      # (unit columns: |G_ij| <= 1, the bound is absolute)
-        return np.conj(V)
-    return np.conj(Vn @ np.linalg.inv(G))
+        return None
+    return np.linalg.inv(G) / nrm[:, None]
 
 
-def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, v0s=None, v0s_adj=None, output=False, stats=None):
-    """[(sol, n, flag), ...] = householder_many(L, zs; ...): `householder` for several start values, the device work
-    (two shift-invert Arnoldi processes per Newton step and start value) batched over the start values.
-    stats (optional dict): receives the seconds spent in the right / left Arnoldi processes and in the perturbation step, the
-    number of lock-step Newton rounds and the inner (Krylov) column-iterations."""
+def _conjugate_span_start(V):
+    """conj(V C), C = _conjugate_span_coefficients(V) (host arrays: householder_many_host)"""
+    C = _conjugate_span_coefficients(V)
+    return np.conj(V) if C is None else np.conj(V @ C)
+
+
+def householder_many_host(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, v0s=None, v0s_adj=None, output=False, stats=None):
+    """`householder_many` with every vector passing through host memory between the device calls (wae_arnoldi_shiftinvert_batch,
+    wae_perturb, wae_spmv_sum): the form of rounds 2-3, kept as the cross-check of the device-resident one below
+    (tests/test_gpu_parity.py) and for `householder_many(..., resident=False)`."""
     import time as _time
     st_ = {"right_arnoldi_seconds": 0.0, "left_arnoldi_seconds": 0.0, "perturbation_seconds": 0.0, "newton_rounds": 0,
            "inner_column_iterations": 0}
@@ -655,6 +659,223 @@ def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, orde
         W[:, s] *= 1.0 / np.conj(np.vdot(W[:, s], DV[:, s]))
     del DV
     st_["normalisation_seconds"] = _time.perf_counter() - t_
+    out = []
+    for s in range(ns):
+        f = flag[s]
+        L.params[L.eigval] = z[s]
+        L.params[L.auxval] = lam[s] if np.isfinite(lam[s]) else 0
+        if f == 1:
+            hist[s].append(z[s])
+            if n[s] >= maxiter:
+                f = -1
+            elif abs(lam[s]) <= lam_tol:
+                f = 1
+            elif abs(z[s] - z0[s]) <= tol:
+                f = 0
+            elif np.isnan(z[s]):
+                f = -5
+            else:
+                f = -3
+        L.active, L.mode = active, mode
+        sol = Solution(L.params, V[:, s], W[:, s], L.eigval)        # (columns of the local column-major arrays: contiguous views, no copies)
+        sol.history = hist[s]
+        out.append((sol, n[s], f))
+    L.active, L.mode = active, mode
+    if stats is not None:
+        stats.update(st_)
+    return out
+
+
+# slots of the family the lock-step Newton iteration keeps its vectors in (the upper half of DeviceFamily.NSLOTS: 0-3 stay the caller's)
+_SV, _SW, _SXR, _SXL = 4, 5, 6, 7
+
+
+def eigs_many_slots(fam, cA, cM, v0_slot, cols, op, sigmas, out_slot, tol=1e-12, maxiter=300, stol=1e-12, smax=400, stats=None):
+    """`eigs_many` (nev = 1) on device-resident vectors: start vectors = columns `cols` of slot v0_slot, the normalised Ritz vector of
+    system q is written to column cols[q] of out_slot; only the small Hessenberg matrices come back to the host.  Returns per system
+    (lam, gap) or an EigsError instance."""
+    cA = np.asarray(cA, dtype=np.complex128)
+    nsys, d = cA.shape[0], fam.d
+    step = int(min(d, 6))
+    cAs = cA - np.asarray(sigmas, dtype=np.complex128)[:, None] * cM[None, :]
+    sig_out = np.conj(sigmas) if op == OP_C else np.asarray(sigmas)
+    out = [None] * nsys
+    pending = list(range(nsys))
+    total = 0
+    src = v0_slot
+    while pending and total < maxiter:
+        H = fam.arnoldi_slots(cAs[pending], cM, step, src, [cols[s] for s in pending], op=op, tol=stol, maxit=smax, ritz_tol=tol, quiet=True)
+        total += step
+        if stats is not None:
+            stats["inner_column_iterations"] = stats.get("inner_column_iterations", 0) + int(fam.last_info.get("iters_total", 0))
+        failed = fam.last_info["n_unconverged"] > 0 and fam.last_info["relres_max"] > 1e-4
+        Y = np.zeros((len(pending), step + 1), dtype=np.complex128)
+        ny = 1
+        still = []
+        for q, s in enumerate(pending):
+            Hs = H[q]
+            m = step
+            while m > 1 and not Hs[:, m - 1].any():
+                m -= 1
+            taken = m
+            for j in range(m):
+                if Hs[j + 1, j] == 0:
+                    m = j + 1
+                    break
+            theta, Yr = np.linalg.eig(Hs[:m, :m])
+            order = np.argsort(-np.abs(theta))
+            theta, Yr = theta[order], Yr[:, order]
+            res = np.abs(Hs[m, m - 1]) * np.abs(Yr[m - 1, 0])
+            Y[q, :m] = Yr[:, 0]
+            ny = max(ny, m)
+            gap = abs(1.0 / theta[1]) if m > 1 else np.inf
+            out[s] = (sig_out[s] + 1.0 / theta[0], gap)
+            if not (res <= tol * np.abs(theta[0]) or m < taken or m >= d):
+                if failed:
+                    out[s] = EigsError("inner solves stalled")
+                else:
+                    still.append(s)                           # restart from the Ritz vector (now in out_slot)
+        fam.ritz_to_slot(Y[:, :ny], out_slot, [cols[s] for s in pending], normalise=True)
+        pending = still
+        src = out_slot
+    return out
+
+
+def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, v0s=None, v0s_adj=None, output=False, stats=None, resident=True):
+    """[(sol, n, flag), ...] = householder_many(L, zs; ...): `householder` (Householder.jl:70-192) for several start values, the device
+    work (two shift-invert Arnoldi processes per Newton step and start value) batched over the start values, and every vector of the
+    iteration resident in HBM: the estimates go to the device once (wae_slot_write), the Arnoldi processes start from slot columns and
+    leave their Ritz vectors in slot columns (wae_arnoldi_shiftinvert_slots, wae_arnoldi_ritz_to_slot), the perturbation step reads them
+    there (wae_perturb_slots), the relaxed update and the two normalisations of Householder.jl:173-176,189-190 are slot operations
+    (wae_slot_axpby, wae_slot_forms), and the eigenvectors come back once at the end.  The host sees Hessenberg matrices and scalars.
+    (Through host memory -- householder_many_host, resident=False -- a step of 8 start values at 1M DoF moved 2 GB over PCIe and the
+    GPU idled 45 % of the time.)
+    stats (optional dict): receives the seconds spent in the right / left Arnoldi processes and in the perturbation step, the
+    number of lock-step Newton rounds and the inner (Krylov) column-iterations."""
+    if not resident:
+        return householder_many_host(L, zs, maxiter=maxiter, tol=tol, relax=relax, lam_tol=lam_tol, order=order, v0s=v0s, v0s_adj=v0s_adj,
+                                     output=output, stats=stats)
+    import time as _time
+    st_ = {"right_arnoldi_seconds": 0.0, "left_arnoldi_seconds": 0.0, "perturbation_seconds": 0.0, "newton_rounds": 0,
+           "inner_column_iterations": 0}
+    zs = [complex(z) for z in zs]
+    ns = len(zs)
+    if ns == 0:                                           # an empty batch of start values: nothing to refine
+        if stats is not None:
+            stats.update(st_)
+        return []
+    d = L.size()
+    fam = L.ensure_solver()
+    active, mode = L.active, L.mode
+    allc = list(range(ns))
+    t_ = _time.perf_counter()
+    if v0s is None:
+        fam.slot_write(_SV, np.ones((d, ns), dtype=np.complex128, order="F"))
+    else:
+        fam.slot_write(_SV, np.asarray(v0s, dtype=np.complex128).reshape(d, ns))
+    if v0s_adj is None:
+        # the conjugate-span start W = conj(V C): the small matrix C from the caller's array, the combination on the device (column i of V,
+        # conjugated, into every column of W with its weight)
+        Cs = None if v0s is None else _conjugate_span_coefficients(np.asarray(v0s, dtype=np.complex128).reshape(d, ns))
+        fam.slot_write(_SW, None, ncols_total=ns)
+        if Cs is None:
+            fam.slot_axpby(_SW, allc, _SV, allc, alpha=1.0, beta=0.0, conj_src=True)
+        else:
+            for i in range(ns):
+                fam.slot_axpby(_SW, allc, _SV, [i] * ns, alpha=np.conj(Cs[i, :]), beta=0.0 if i == 0 else 1.0, conj_src=True)
+    else:
+        fam.slot_write(_SW, np.asarray(v0s_adj, dtype=np.complex128).reshape(d, ns))
+    fam.slot_write(_SXR, None, ncols_total=ns)
+    fam.slot_write(_SXL, None, ncols_total=ns)
+    st_["upload_seconds"] = _time.perf_counter() - t_
+    z = list(zs)
+    z0 = [complex(np.inf)] * ns
+    lam = [np.inf] * ns
+    n = [0] * ns
+    flag = [1] * ns
+    hist = [[] for _ in range(ns)]
+    state = [dict() for _ in range(ns)]
+    T = len(L.terms)
+    cM = np.zeros(T, dtype=np.complex128)
+    cM[T - 1] = -1.0                                      # M = -L.terms[end].coeff  (Householder.jl:92)
+    upd = lambda c: householder_update([factorial(i) * ci for i, ci in enumerate(c)])   # noqa: E731
+    while True:
+        act = [s for s in range(ns) if flag[s] == 1 and abs(z[s] - z0[s]) > tol and n[s] < maxiter]
+        if not act:
+            break
+        cA, sig = [], []
+        for s in act:
+            hist[s].append(z[s])
+            z0[s] = z[s]
+            L.params[L.eigval] = z[s]
+            L.params[L.auxval] = 0
+            cA.append(L.coefficients(z[s]))
+            gp, lp = state[s].get("gap", np.inf), state[s].get("lam", np.inf)
+            sig.append(1e-5 * gp if (np.isfinite(gp) and lp < 1e-4 * gp) else 0.0)
+        cA = np.array(cA)
+        try:
+            st_["newton_rounds"] += 1
+            t_ = _time.perf_counter()
+            right = eigs_many_slots(fam, cA, cM, _SV, act, OP_N, sig, _SXR, stol=L.solver_tol, smax=L.solver_maxit, stats=st_)
+            st_["right_arnoldi_seconds"] += _time.perf_counter() - t_
+            t_ = _time.perf_counter()
+            left = eigs_many_slots(fam, cA, cM, _SW, act, OP_C, sig, _SXL, stol=L.solver_tol, smax=L.solver_maxit, stats=st_)
+            st_["left_arnoldi_seconds"] += _time.perf_counter() - t_
+        except WaeError as e:
+            for s in act:
+                flag[s] = -6 if e.code == -2 else -2
+            break
+        moved = []
+        for q, s in enumerate(act):
+            if isinstance(right[q], Exception) or isinstance(left[q], Exception):
+                flag[s] = -4
+                continue
+            lam_r, gap = right[q]
+            state[s]["gap"] = gap if np.isfinite(gap) else state[s].get("gap", np.inf)
+            state[s]["lam"] = float(abs(lam_r))
+            L.params[L.eigval] = z[s]
+            L.params[L.auxval] = lam_r
+            try:
+                t_ = _time.perf_counter()
+                series = eigval_series_slots(L, L.auxval, L.eigval, order, _SXR, s, _SXL, s)
+                dz = upd(series)
+                st_["perturbation_seconds"] += _time.perf_counter() - t_
+            except WaeError as e:
+                flag[s] = -6 if e.code == -2 else -2
+                continue
+            finally:
+                L.active = [L.eigval]
+            lam[s] = lam_r
+            if output:
+                print(s, n[s], "\t", abs(lam[s]), "\t", abs(dz), "\t", z[s])
+            z[s] = z[s] + relax * dz
+            moved.append(s)
+            n[s] += 1
+        if moved:                                         # v0 = (1 - relax) v0 + relax v  (Householder.jl:173-176), both vectors, on the device
+            fam.slot_axpby(_SV, moved, _SXR, moved, alpha=relax, beta=1.0 - relax)
+            fam.slot_axpby(_SW, moved, _SXL, moved, alpha=relax, beta=1.0 - relax)
+    # Householder.jl:189-190 for all start values at once: v / sqrt(v' M v), v_adj / conj(v_adj' L'(z) v) -- two batched forms
+    t_ = _time.perf_counter()
+    nv = fam.slot_forms(cM, _SV, allc, _SV, allc)
+    fam.slot_axpby(_SV, allc, _SV, allc, alpha=1.0 / np.sqrt(nv), beta=0.0)
+    cD = np.zeros((ns, T), dtype=np.complex128)
+    saved_p = dict(L.params)
+    L.active, L.mode = [L.eigval], "all"
+    try:
+        for s in range(ns):
+            L.params[L.eigval] = z[s]
+            L.params[L.auxval] = lam[s] if np.isfinite(lam[s]) else 0
+            cD[s] = L.coefficients(z[s], 1)
+    finally:
+        L.active, L.mode = active, mode
+        L.params.update(saved_p)
+    dw = fam.slot_forms(cD, _SW, allc, _SV, allc)
+    fam.slot_axpby(_SW, allc, _SW, allc, alpha=1.0 / np.conj(dw), beta=0.0)
+    st_["normalisation_seconds"] = _time.perf_counter() - t_
+    t_ = _time.perf_counter()
+    V = fam.slot_read(_SV, 0, ns)
+    W = fam.slot_read(_SW, 0, ns)
+    st_["download_seconds"] = _time.perf_counter() - t_
     out = []
     for s in range(ns):
         f = flag[s]

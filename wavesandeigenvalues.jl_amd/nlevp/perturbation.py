@@ -194,6 +194,28 @@ def _wrapper(kernel, sol, L, param, N, mode):
     sol.eigval_pert[key], sol.v_pert[key] = lam, v
 
 
+def eigval_series_slots(L, eigval, param, N, v_slot, v_col, w_slot, w_col):
+    """The eigenvalue series of `perturb!(sol, L, param, N; mode = :householder)` (LinOpFam.jl:546-560 with perturbation.jl:319-367)
+    for the eigenpair held in slot columns of the family (wae_perturb_slots): L.params carries the expansion point, `eigval` names the
+    eigenvalue parameter of the pair (the auxiliary eigenvalue of Householder.jl:115-116), `param` the perturbed one.  Returns the
+    Taylor coefficients lam[0..N] (lam[0] = L.params[eigval]); no vector leaves the device."""
+    fam = L.ensure_solver()
+    T = len(L.terms)
+    active, cur_mode = L.active, L.mode
+    L.active = [eigval, param]
+    L.mode = "householder"
+    try:
+        table = np.zeros((N + 1, N + 1, T), dtype=np.complex128)
+        for m in range(N + 1):
+            for n in range(N + 1 - m):
+                table[m, n] = L.coefficients(m, n)
+    finally:
+        L.active, L.mode = active, cur_mode
+    lam, _ = fam.perturb_slots(table, N, v_slot, v_col, w_slot, w_col, norm_mode=16, tol=L.solver_tol, maxit=L.solver_maxit, quiet=True)
+    lam[0] = L.params[eigval]
+    return lam
+
+
 def perturb_(sol, L, param, N, mode="compact"):
     """perturb!(sol,L,param,N;mode)"""
     _wrapper(perturb, sol, L, param, N, mode)
