@@ -88,13 +88,23 @@ def assert_close(got, want, bound, what, cols=None, tol=TOL):
         assert ew <= tol, f"{what}: column {j} element-wise error {ew:.2e} of the row's rounding bound"
 
 
+_RANDOM = {}
+
+
+def _random_block(rng, d, r):
+    """(B0, Y0) of a shape, drawn once per process: at 1M unknowns and 64 columns three normal draws are 2.5 s of every call below"""
+    if (d, r) not in _RANDOM:
+        _RANDOM.clear()                                              # (one shape at a time: a block is 1 GB at the benchmark size)
+        _RANDOM[(d, r)] = (rng.standard_normal((d, r)) + 1j * rng.standard_normal((d, r)), rng.standard_normal((d, r)) + 7j)
+    return _RANDOM[(d, r)]
+
+
 def check_modes(fam, tp, ct, X, rng, what, modes=(0, 1, 2, 3, 4, 5, 6), cmask=None, op=0, jac_w=0.8):
     """every fused form of the operator product (include/waehip.h wae_debug_spmv) against the scipy term products `tp`"""
     want, bound, dg = tp.apply(ct)
     d, r = X.shape
-    B = rng.standard_normal((d, r)) + 1j * rng.standard_normal((d, r))
-    B *= np.maximum(np.abs(dg), 1.0)                                # right-hand sides of the size of the rows they meet
-    Y0 = rng.standard_normal((d, r)) + 7j                            # what a masked chunk must keep
+    B0, Y0 = _random_block(rng, d, r)                                # Y0: what a masked chunk must keep
+    B = B0 * np.maximum(np.abs(dg), 1.0)                             # right-hand sides of the size of the rows they meet
     act = np.ones(r, dtype=bool)
     if cmask is not None:
         act = np.repeat(np.asarray(cmask, dtype=bool), 8)[:r]
