@@ -18,9 +18,9 @@ Gd = np.asfortranarray(rng.standard_normal((d, 8)) + 1j * rng.standard_normal((d
 zs = 2 * np.pi * (np.array([310.0, 455.0, 520.0, 610.0, 700.0, 745.0, 820.0, 905.0]) + 1j * np.linspace(-60, 60, 8))
 ct = np.array([L.coefficients(z) for z in zs])
 only = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else None
-for r in (8, 4):
+for r in (8, 4, 2, 1):
     for op in (0, 2):
-        if only and (r, op) != only:
+        if (only and (r, op) != only) or (not only and r < 4):
             continue
         for g in (None, Gd):
             for rep in range(2):

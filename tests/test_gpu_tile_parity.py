@@ -67,6 +67,16 @@ def test_tile_kernel_at_benchmark_size_against_scipy(preset, d_expect, request):
     tp8c = TermProducts(T, X8, "C")
     want, bound, _ = tp8c.apply(ct1)
     assert_close(fam.spmv(ct1[0], X8, op=2), want, bound, f"{preset} wae_spmv_sum r=8 op C")
+    # fewer than 8 columns on a large operator (the Newton-type solvers' batches: general CSR kernel, teams of 8 lanes per row -- 8 / C
+    # lanes per row at C column lanes), both orientations, one system and one system per column
+    if preset == "C2":
+        for r in (4, 3, 2, 1):
+            Xr = np.ascontiguousarray(X[:, 16:16 + r])
+            for opn, opi in (("N", 0), ("C", 2)):
+                tpr = TermProducts(T, Xr, opn)
+                for ct in (ct1, ct64[:r]):
+                    want, bound, _ = tpr.apply(ct)
+                    assert_close(fam.spmv(ct if len(ct) > 1 else ct[0], Xr, op=opi), want, bound, f"C2 wae_spmv_sum r={r} op {opn}")
     # more than 256 columns through the public entry (column groups inside the library)
     if preset == "C2":
         X300 = rng.standard_normal((d, 300)) + 1j * rng.standard_normal((d, 300))

@@ -1370,6 +1370,10 @@ void launch_spmv(const OpDev &op, const cplx *pc, int cps, const cplx *X, cplx *
     // small (coarse-level / transfer) operators are latency-bound with one lane per row: split each row over S lanes
     if (C == 8 && op.n < env_int("WAE_SPMV_SMALL8", 4096)) S = 8;
     else if (C == 8 && op.n < env_int("WAE_SPMV_SMALL4", 65536)) S = 4;
+    // narrow batches (the Newton-type solvers; no tile path below 8 columns) on a large operator: teams of 8 lanes -- with 15-48 entries
+    // per row more lanes per row leave most of a team idle in the reduction (4 columns at 1M unknowns, solve of 26 iterations: 8 / 4 / 2 /
+    // 1 lanes per row 66 / 51 / 47 / 53 ms; 2 columns 35 / 29 / 31 / 39 ms; 1 column 17.5 / 18.5 / 22.6 / 32 ms)
+    else if (C < 8 && op.n >= env_int("WAE_SPMV_SMALL4", 65536)) S = 8 / C;
     if (envC > 0 && envC <= nb) C = envC;
     if (envS > 0) S = envS;
     if (op.n <= 0) return;
