@@ -8,8 +8,22 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# Host BLAS threads: a GPU box shows the test process all 256 cores of its host but gives it a share of 16; OpenBLAS then starts 256
+# threads and scipy's SuperLU (the sparse-LU references of the parity tests) takes 2.9 s per factorisation of an 8 736-DoF matrix
+# instead of 0.1 s.  Four threads here and in the child processes the tests start (they inherit the environment).
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "4")
+_BLAS_LIMIT = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    global _BLAS_LIMIT
+    try:                                              # (numpy may have been imported before this file: limit the loaded pools too)
+        from threadpoolctl import threadpool_limits
+        _BLAS_LIMIT = threadpool_limits(limits=4)
+    except Exception:
+        pass
 
 
 def _has_gpu():
