@@ -1,6 +1,8 @@
 // libwaehip.so -- family handle, multigrid-preconditioned batched GMRES, Beyn moment loop, C ABI.
 // gfx950 only.  See include/waehip.h for the contract of every exported function.
 #include <algorithm>
+#include <atomic>
+#include <exception>
 #include <future>
 #include <chrono>
 #include <cmath>
@@ -585,6 +587,22 @@ static void build_level_tiles(LevelOp &L, const std::vector<CsrZ> &planes, const
 // ----------------------------------------------------------------------------------------------------
 // input conversion
 // ----------------------------------------------------------------------------------------------------
+// body(lo, hi) over contiguous ranges of [0, n) on up to nth host threads; an exception of any range is rethrown here
+template <class F> static void host_ranges(int64_t n, int nth, F &&body) {
+    nth = (int)std::max<int64_t>(1, std::min<int64_t>(nth, n / 65536 + 1));
+    if (nth == 1) { body((int64_t)0, n); return; }
+    std::vector<std::future<void>> jobs;
+    for (int t = 0; t < nth; ++t) {
+        const int64_t lo = n * t / nth, hi = n * (t + 1) / nth;
+        jobs.push_back(std::async(std::launch::async, [&body, lo, hi]() { body(lo, hi); }));
+    }
+    std::exception_ptr first;
+    for (auto &j : jobs) {
+        try { j.get(); } catch (...) { if (!first) first = std::current_exception(); }
+    }
+    if (first) std::rethrow_exception(first);
+}
+
 static CsrZ term_to_csr(int64_t d, int index_bytes, int base, int orientation, const void *ptr, const void *idx, const double *val) {
     auto getp = [&](int64_t i) -> int64_t { return index_bytes == 4 ? (int64_t)((const uint32_t *)ptr)[i] : ((const int64_t *)ptr)[i]; };
     auto geti = [&](int64_t i) -> int64_t { return index_bytes == 4 ? (int64_t)((const uint32_t *)idx)[i] : ((const int64_t *)idx)[i]; };
@@ -595,24 +613,41 @@ static CsrZ term_to_csr(int64_t d, int index_bytes, int base, int orientation, c
     A.ptr.resize(d + 1);
     A.col.resize(nnz);
     A.val.resize(nnz);
-    for (int64_t i = 0; i <= d; ++i) {
-        const int64_t p = getp(i) - base;
-        WAE_REQUIRE(p >= 0 && p <= nnz, "pointer array out of range");
-        A.ptr[i] = (int)p;
-    }
-    for (int64_t p = 0; p < nnz; ++p) {
-        const int64_t j = geti(p) - base;
-        WAE_REQUIRE(j >= 0 && j < d, "index out of range");
-        A.col[p] = (int)j;
-        A.val[p] = zc(val[2 * p], val[2 * p + 1]);
-    }
+    // (four threads per term, the terms themselves side by side in wae_family_create_opts: copying and checking 30 M entries of a
+    // 1M-unknown family on one thread was 1.0 s of the 1.7 s a family takes to create)
+    constexpr int NTH = 4;
+    host_ranges(d + 1, NTH, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t p = getp(i) - base;
+            WAE_REQUIRE(p >= 0 && p <= nnz, "pointer array out of range");
+            A.ptr[i] = (int)p;
+        }
+    });
+    host_ranges(nnz, NTH, [&](int64_t lo, int64_t hi) {
+        for (int64_t p = lo; p < hi; ++p) {
+            const int64_t j = geti(p) - base;
+            WAE_REQUIRE(j >= 0 && j < d, "index out of range");
+            A.col[p] = (int)j;
+            A.val[p] = zc(val[2 * p], val[2 * p + 1]);
+        }
+    });
+    // rows already sorted without duplicates (what scipy and SparseArrays hand over): taken as they are
+    std::atomic<bool> canonical{true};
+    host_ranges(d, NTH, [&](int64_t lo, int64_t hi) {
+        bool ok = true;
+        for (int64_t i = lo; i < hi; ++i) {
+            WAE_REQUIRE(A.ptr[i] <= A.ptr[i + 1], "pointer array not monotone");
+            for (int p = A.ptr[i] + 1; p < A.ptr[i + 1]; ++p) ok = ok && A.col[p - 1] < A.col[p];
+        }
+        if (!ok) canonical = false;
+    });
+    if (canonical) return orientation == WAE_CSC ? csr_transpose(A) : A;
     // sort + merge duplicates per row
     CsrZ S;
     S.n = S.m = d;
     S.ptr.assign(d + 1, 0);
     std::vector<std::pair<int, zc>> row;
     for (int64_t i = 0; i < d; ++i) {
-        WAE_REQUIRE(A.ptr[i] <= A.ptr[i + 1], "pointer array not monotone");
         row.clear();
         for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) row.emplace_back(A.col[p], A.val[p]);
         std::stable_sort(row.begin(), row.end(), [](const std::pair<int, zc> &a, const std::pair<int, zc> &b) { return a.first < b.first; });
@@ -1979,8 +2014,22 @@ int wae_family_create_opts(wae_family **out, int64_t d, int32_t T, int32_t index
         h->term_plane.resize(T);
         h->term_scale.resize(T);
         h->term_nnz.resize(T);
+        const bool cdbg = getenv("WAE_SETUP_DEBUG") != nullptr;
+        double tc = now_s();
+        auto clap = [&](const char *what) { if (cdbg) { const double t = now_s(); fprintf(stderr, "[create] %-34s %.3f s\n", what, t - tc); tc = t; } };
+        std::vector<std::future<CsrZ>> conv;                     // the terms' conversions side by side
+        for (int k = 0; k < T; ++k)
+            conv.push_back(std::async(std::launch::async, [&, k]() { return term_to_csr(d, index_bytes, base, orientation, ptr[k], idx[k], val[k]); }));
+        std::vector<CsrZ> conv_out(T);
+        {
+            std::exception_ptr first;
+            for (int k = 0; k < T; ++k) {
+                try { conv_out[k] = conv[k].get(); } catch (...) { if (!first) first = std::current_exception(); }
+            }
+            if (first) std::rethrow_exception(first);
+        }
         for (int k = 0; k < T; ++k) {
-            CsrZ A = term_to_csr(d, index_bytes, base, orientation, ptr[k], idx[k], val[k]);
+            CsrZ A = std::move(conv_out[k]);
             h->term_nnz[k] = A.nnz();
             bool found = false;
             for (int q = 0; q < (int)h->planes0.size() && !found; ++q) {
@@ -1994,6 +2043,7 @@ int wae_family_create_opts(wae_family **out, int64_t d, int32_t T, int32_t index
             }
         }
         h->nplanes = (int)h->planes0.size();
+        clap("terms to CSR, distinct planes");
         // renumber the rows into compact tiles (tiles.h); WAE_REORDER=0 keeps the caller's numbering (A/B measurements)
         static const bool reorder_on = !(getenv("WAE_REORDER") && atoi(getenv("WAE_REORDER")) == 0);
         if (reorder_on) {
@@ -2021,9 +2071,12 @@ int wae_family_create_opts(wae_family **out, int64_t d, int32_t T, int32_t index
         }
         h->ops.resize(1);
         h->slot_plane.resize(1);
+        tc = now_s();
         h->slot_plane[0] = build_levelop(h->ops[0], h->planes0, h->stream, sym_tol);
+        clap("operator groups (CSR, both orientations)");
         if (!h->tile_row_ptr.empty()) {
             build_level_tiles(h->ops[0], h->planes0, h->slot_plane[0], h->tile_row_ptr, h->stream, 2, getenv("WAE_TILE_NBUF") ? atoi(getenv("WAE_TILE_NBUF")) : 2);
+            clap("tile storage");
         }
         cplx one = {1.0, 0.0};
         h->one_dev.upload(&one, 1, h->stream);
