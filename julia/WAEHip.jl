@@ -448,8 +448,17 @@ function _normalise(fam::DeviceFamily, v0, v0_adj)                 # Householder
     return v0, v0_adj
 end
 
-"sol, n, flag = householder(Ld, z; maxiter, tol, relax, lam_tol, order, nev, v0, v0_adj, output)   (Householder.jl:70-192)"
-function householder(fam::DeviceFamily, z; maxiter=10, tol=0., relax=1., lam_tol=Inf, order=1, nev=1, v0=[], v0_adj=[], output=false)
+"sol, n, flag = householder(Ld, z; maxiter, tol, relax, lam_tol, order, nev, v0, v0_adj, output)   (Householder.jl:70-192).
+nev = 1 (the default) runs the device-resident iteration of `householder_many` for the one start value (the eigenvector pair stays in HBM
+between the Arnoldi processes, the perturbation step and the update: half the time per call at 1M DoF); resident = false or nev > 1:
+the vectors pass through host memory between the library calls."
+function householder(fam::DeviceFamily, z; maxiter=10, tol=0., relax=1., lam_tol=Inf, order=1, nev=1, v0=[], v0_adj=[], output=false, resident::Bool=true)
+    if resident && nev == 1
+        d1 = size(fam.L.terms[1].coeff, 1)
+        return householder_many(fam, [z]; maxiter=maxiter, tol=tol, relax=relax, lam_tol=lam_tol, order=order,
+                                v0s=(v0 == [] ? nothing : reshape(Vector{ComplexF64}(v0), d1, 1)),
+                                v0s_adj=(v0_adj == [] ? nothing : reshape(Vector{ComplexF64}(v0_adj), d1, 1)), output=output)[1]
+    end
     L = fam.L
     z = ComplexF64(z); z0 = complex(Inf); lam = Inf; n = 0
     active, mode = L.active, L.mode

@@ -623,8 +623,10 @@ def test_householder_many_matches_single_runs():
     Lp = helmholtz_family(F.rijke_terms(), n=0.01, tau=0.001)
     Lp.solver_ref = 2 * np.pi * 400.0
     starts = [2 * np.pi * 340.0, 2 * np.pi * 700.0, 2 * np.pi * 250.0]
-    single = [householder(Lp, z0, maxiter=12, tol=1e-10) for z0 in starts]
+    single = [householder(Lp, z0, maxiter=12, tol=1e-10, resident=False) for z0 in starts]      # (the host-memory iteration, one start value at a time)
     many = householder_many(Lp, starts, maxiter=12, tol=1e-10)
+    s_res, n_res, f_res = householder(Lp, starts[0], maxiter=12, tol=1e-10)                          # (default: the resident form of one start value)
+    assert abs(s_res.params["ω"] - single[0][0].params["ω"]) <= 1e-9 * abs(single[0][0].params["ω"]) and f_res == single[0][2]
     w1 = c(G["G1"]["omega"])
     assert abs(many[0][0].params["ω"] - w1) < 1e-9 * abs(w1)                   # tutorial_04's eigenvalue
     for (s1, n1, f1), (s2, n2, f2) in zip(single, many):

@@ -184,9 +184,18 @@ def _normalise(L, v0, v0_adj):
     return v0, v0_adj
 
 
-def householder(L, z, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, nev=1, v0=None, v0_adj=None, output=False):
+def householder(L, z, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, nev=1, v0=None, v0_adj=None, output=False, resident=True):
     """sol, n, flag = householder(L, z; maxiter, tol, relax, lam_tol, order, nev, v0, v0_adj, output)
-    (Householder.jl:70-192; flags 1 converged / 0 slow / -1 maxiter / -4 eigs / -6 singular / -5 NaN)"""
+    (Householder.jl:70-192; flags 1 converged / 0 slow / -1 maxiter / -4 eigs / -6 singular / -5 NaN)
+    nev = 1 (the default) runs the device-resident iteration of `householder_many` for the one start value: the eigenvector pair stays
+    in HBM between the Arnoldi processes, the perturbation step and the update (0.49 -> 0.26 s per call at 1M DoF); resident=False or
+    nev > 1: the vectors pass through host memory between the library calls, as below."""
+    if resident and nev == 1:
+        d = L.size()
+        return householder_many(L, [z], maxiter=maxiter, tol=tol, relax=relax, lam_tol=lam_tol, order=order,
+                                v0s=None if v0 is None else np.asarray(v0, dtype=np.complex128).reshape(d, 1),
+                                v0s_adj=None if v0_adj is None else np.asarray(v0_adj, dtype=np.complex128).reshape(d, 1), output=output,
+                                _single=True)[0]
     z = complex(z)
     z0 = complex(np.inf)
     lam = np.inf
@@ -741,7 +750,8 @@ def eigs_many_slots(fam, cA, cM, v0_slot, cols, op, sigmas, out_slot, tol=1e-12,
     return out
 
 
-def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, v0s=None, v0s_adj=None, output=False, stats=None, resident=True):
+def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, v0s=None, v0s_adj=None, output=False, stats=None, resident=True,
+                     _single=False):
     """[(sol, n, flag), ...] = householder_many(L, zs; ...): `householder` (Householder.jl:70-192) for several start values, the device
     work (two shift-invert Arnoldi processes per Newton step and start value) batched over the start values, and every vector of the
     iteration resident in HBM: the estimates go to the device once (wae_slot_write), the Arnoldi processes start from slot columns and
@@ -805,6 +815,8 @@ def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, orde
             break
         cA, sig = [], []
         for s in act:
+            if output and _single:                            # (the line `householder` prints per iteration, Householder.jl:95)
+                print(n[s], "\t\t", abs(lam[s]), "\t", abs(z[s] - z0[s]), "\t", z[s])
             hist[s].append(z[s])
             z0[s] = z[s]
             L.params[L.eigval] = z[s]
@@ -846,7 +858,7 @@ def householder_many(L, zs, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, orde
             finally:
                 L.active = [L.eigval]
             lam[s] = lam_r
-            if output:
+            if output and not _single:
                 print(s, n[s], "\t", abs(lam[s]), "\t", abs(dz), "\t", z[s])
             z[s] = z[s] + relax * dz
             moved.append(s)
