@@ -492,17 +492,70 @@ function householder(fam::DeviceFamily, z; maxiter=10, tol=0., relax=1., lam_tol
     return Solution(L.params, v0, v0_adj, L.eigval), n, flag
 end
 
+# the single-start iterations on device-resident vectors (slots 4-7, column 1): the pair (v0, v0_adj) of `mslp` stays in HBM
+const _SV, _SW, _SXR, _SXL = 4, 5, 6, 7
+function _slots_begin(fam::DeviceFamily, v0, v0_adj)
+    d = size(fam.L.terms[1].coeff, 1)
+    slot_write(fam, _SV, v0 == [] ? ones(ComplexF64, d, 1) : reshape(Vector{ComplexF64}(v0), d, 1))
+    if v0_adj == []
+        slot_write(fam, _SW, nothing; ncols_total=1)
+        slot_axpby(fam, _SW, [1], _SV, [1], 1.0, 0.0; conj_src=true)          # conj(v0)  (Householder.jl:84-86)
+    else
+        slot_write(fam, _SW, reshape(Vector{ComplexF64}(v0_adj), d, 1))
+    end
+    slot_write(fam, _SXR, nothing; ncols_total=1); slot_write(fam, _SXL, nothing; ncols_total=1)
+    return
+end
+"`_aux_step` for nev = 1 on the slots: Ritz vectors to _SXR / _SXL, the perturbation step reads them there; returns (lam, candidate update)"
+function _aux_step_slots(fam::DeviceFamily, z, order, update, state)
+    L = fam.L; T = length(L.terms)
+    L.params[L.eigval] = z; L.params[L.auxval] = 0
+    L.active = [L.eigval]; L.mode = :all
+    cA = reshape(coefficients(L, z), T, 1)
+    cM = zeros(ComplexF64, T); cM[end] = -1                         # M = -L.terms[end].coeff  (Householder.jl:92)
+    gap_prev, lam_prev = get(state, :gap, Inf), get(state, :lam, Inf)
+    sigma = (isfinite(gap_prev) && lam_prev < 1e-4 * gap_prev) ? 1e-5 * gap_prev : 0.0
+    right = eigs_many_slots(fam, cA, cM, _SV, [1], OP_N, [sigma], _SXR)[1]
+    left = eigs_many_slots(fam, cA, cM, _SW, [1], OP_C, [sigma], _SXL)[1]
+    right isa EigsError && throw(right)
+    left isa EigsError && throw(left)
+    lam, gap = right
+    state[:gap] = isfinite(gap) ? gap : gap_prev
+    state[:lam] = abs(lam)
+    L.params[L.auxval] = lam
+    return lam, update(eigval_series_slots(fam, L.auxval, L.eigval, order, _SXR, 1, _SXL, 1))
+end
+"`_normalise` (Householder.jl:189-190) on the slots, then the pair back to the host"
+function _slots_finish(fam::DeviceFamily)
+    L = fam.L; T = length(L.terms)
+    cM = zeros(ComplexF64, T); cM[end] = -1
+    nv = slot_forms(fam, reshape(cM, T, 1), _SV, [1], _SV, [1])
+    slot_axpby(fam, _SV, [1], _SV, [1], 1.0 / sqrt(nv[1]), 0.0)
+    saved = (L.active, L.mode); L.active = [L.eigval]; L.mode = :all
+    cD = reshape(coefficients(L, L.params[L.eigval], 1), T, 1)
+    L.active, L.mode = saved
+    dw = slot_forms(fam, cD, _SW, [1], _SV, [1])
+    slot_axpby(fam, _SW, [1], _SW, [1], 1.0 / conj(dw[1]), 0.0)
+    return slot_read(fam, _SV, 1, 1)[:, 1], slot_read(fam, _SW, 1, 1)[:, 1]
+end
+
 "sol, n, flag = mslp(Ld, z; maxiter, tol, relax, lam_tol, order, nev, v0, v0_adj, num_order, scale, output)   (iterative_solvers.jl:93-252).
 The family must end with its auxiliary term (`discretize` adds it, Helmholtz.jl:571-574): the device copy is immutable."
-function mslp(fam::DeviceFamily, z; maxiter=10, tol=0., relax=1., lam_tol=Inf, order=1, nev=1, v0=[], v0_adj=[], num_order=1, scale=1, output=false)
+function mslp(fam::DeviceFamily, z; maxiter=10, tol=0., relax=1., lam_tol=Inf, order=1, nev=1, v0=[], v0_adj=[], num_order=1, scale=1, output=false,
+              resident::Bool=true)
     L = fam.L
     L.terms[end].operator == "__aux__" || error("mslp(::DeviceFamily): push the __aux__ term before creating the DeviceFamily (iterative_solvers.jl:119-123)")
     z = ComplexF64(z) * scale; tol *= scale
     z0 = complex(Inf); lam = Inf; lam0 = complex(Inf); n = 0
     active, mode = L.active, L.mode
     d = size(L.terms[1].coeff, 1)
-    v0 == [] && (v0 = ones(ComplexF64, d))
-    v0_adj == [] && (v0_adj = conj.(v0))
+    on_dev = resident && nev == 1                                   # the pair stays in HBM (slots) between the library calls
+    if on_dev
+        ensure_solver!(fam); _slots_begin(fam, v0, v0_adj)
+    else
+        v0 == [] && (v0 = ones(ComplexF64, d))
+        v0_adj == [] && (v0_adj = conj.(v0))
+    end
     flag = itsol_converged; state = Dict{Symbol,Float64}()
     polyval(p, x) = foldr((a, acc) -> a + x * acc, p)
     try
@@ -515,13 +568,23 @@ function mslp(fam::DeviceFamily, z; maxiter=10, tol=0., relax=1., lam_tol=Inf, o
                 r = poly_roots(num)
                 return r[sortperm(abs.(r))[1]]
             end
-            lams, v, v_adj, dzs = _aux_step(fam, z, order, nev, v0, v0_adj, upd, state)
+            local lams, v, v_adj, dzs
+            if on_dev
+                lam1, dz1 = _aux_step_slots(fam, z, order, upd, state)
+                lams, dzs = [lam1], [dz1]
+            else
+                lams, v, v_adj, dzs = _aux_step(fam, z, order, nev, v0, v0_adj, upd, state)
+            end
             i = isinf(z0) ? sortperm(abs.(dzs))[1] : sortperm([abs(lam0 - polyval(nd[1], z0 - z) / polyval(nd[2], z0 - z)) for nd in pades])[1]
             lam = lams[i]; L.params[L.auxval] = lam
             z0 = z; lam0 = lam
             z += relax * dzs[i]
-            v0 = (1 - relax) .* v0 .+ relax .* v[:, i]
-            v0_adj = (1 - relax) .* v0_adj .+ relax .* v_adj[:, i]
+            if on_dev
+                slot_axpby(fam, _SV, [1], _SXR, [1], relax, 1 - relax); slot_axpby(fam, _SW, [1], _SXL, [1], relax, 1 - relax)
+            else
+                v0 = (1 - relax) .* v0 .+ relax .* v[:, i]
+                v0_adj = (1 - relax) .* v0_adj .+ relax .* v_adj[:, i]
+            end
             n += 1
         end
     catch excp
@@ -534,7 +597,7 @@ function mslp(fam::DeviceFamily, z; maxiter=10, tol=0., relax=1., lam_tol=Inf, o
         flag = n >= maxiter ? itsol_maxiter : (abs(lam) <= lam_tol ? itsol_converged : (abs(z - z0) <= tol ? itsol_slow_convergence : (isnan(z) ? itsol_isnan : itsol_impossible)))
     end
     L.active, L.mode = active, mode
-    v0, v0_adj = _normalise(fam, v0, v0_adj)
+    v0, v0_adj = on_dev ? _slots_finish(fam) : _normalise(fam, v0, v0_adj)
     return Solution(L.params, v0, v0_adj, L.eigval), n, flag
 end
 

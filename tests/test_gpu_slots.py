@@ -219,3 +219,27 @@ def test_householder_many_resident_equals_the_host_memory_form(annulus):
             Dv = fam.spmv(cD, np.asfortranarray(s1.v.reshape(d, 1)))[:, 0]
             assert abs(np.vdot(s1.v_adj, Dv) - 1) < 1e-8
     assert householder_many(L, [], v0s=np.zeros((d, 0))) == []
+
+
+def test_single_start_solvers_resident_equal_the_host_memory_forms(annulus):
+    """`householder` and `mslp` with nev = 1 keep their eigenvector pair in HBM by default (slots 4-7, column 0); resident=False is the
+    host-memory iteration of rounds 1-3: same eigenvalue, same step count (+-1), same flag, same normalised vectors up to a phase."""
+    L, pb, fam, mats = annulus
+    from wae_amd.nlevp import beyn, householder, mslp
+    G = np.array([300 - 100j, 600 - 100j, 600 + 100j, 300 + 100j]) * 2 * np.pi
+    Om, P = beyn(L, G, l=6, K=1, N=32)[:2]
+    res = fam.eig_residuals(np.array([L.coefficients(w_) for w_ in Om]), P=np.asfortranarray(P))
+    k = int(np.argmin(res))
+    z0, v0 = Om[k] * (1 + 3e-4), P[:, k]
+    tol = 1e-8 * 2 * np.pi * 500.0
+    for solver, kw in ((householder, {}), (householder, {"order": 2}), (mslp, {}), (mslp, {"order": 2, "num_order": 1})):
+        for start in (None, v0):
+            a = solver(L, z0, maxiter=12, tol=tol, v0=start, output=False, **kw)
+            b = solver(L, z0, maxiter=12, tol=tol, v0=start, output=False, resident=False, **kw)
+            wa, wb = complex(a[0].params[L.eigval]), complex(b[0].params[L.eigval])
+            assert abs(wa - wb) <= 1e-9 * abs(wb), (solver.__name__, kw, wa, wb)
+            assert a[2] == b[2] and abs(a[1] - b[1]) <= 1, (solver.__name__, kw, a[1:], b[1:])
+            for x, y in ((a[0].v, b[0].v), (a[0].v_adj, b[0].v_adj)):
+                ov = abs(np.vdot(x, y)) / (np.linalg.norm(x) * np.linalg.norm(y))
+                assert ov > 1 - 1e-8, (solver.__name__, kw, ov)
+            assert abs(np.linalg.norm(a[0].v) / np.linalg.norm(b[0].v) - 1) < 1e-8          # (the same normalisation)

@@ -184,6 +184,67 @@ def _normalise(L, v0, v0_adj):
     return v0, v0_adj
 
 
+def _aux_step_slots(L, fam, z, order, update, state):
+    """`_aux_step` for nev = 1 with the eigenvector pair resident in HBM: v0 / v0_adj are column 0 of the slots _SV / _SW of the family,
+    the Ritz vectors of the two Arnoldi processes go to column 0 of _SXR / _SXL and the perturbation step reads them there.  Returns
+    (lam, candidate update)."""
+    L.params[L.eigval] = z
+    L.params[L.auxval] = 0
+    T = len(L.terms)
+    cA = np.array([L.coefficients(z)])
+    cM = np.zeros(T, dtype=np.complex128)
+    cM[T - 1] = -1.0                                      # M = -L.terms[end].coeff
+    sigma = 0.0
+    gap_prev, lam_prev = state.get("gap", np.inf), state.get("lam", np.inf)
+    if np.isfinite(gap_prev) and lam_prev < 1e-4 * gap_prev:
+        sigma = 1e-5 * gap_prev
+    right = eigs_many_slots(fam, cA, cM, _SV, [0], OP_N, [sigma], _SXR, stol=L.solver_tol, smax=L.solver_maxit)[0]
+    left = eigs_many_slots(fam, cA, cM, _SW, [0], OP_C, [sigma], _SXL, stol=L.solver_tol, smax=L.solver_maxit)[0]
+    for r in (right, left):
+        if isinstance(r, Exception):
+            raise r
+    lam, gap = right
+    state["gap"] = gap if np.isfinite(gap) else gap_prev
+    state["lam"] = float(abs(lam))
+    L.params[L.auxval] = lam
+    try:
+        cand = update(eigval_series_slots(L, L.auxval, L.eigval, order, _SXR, 0, _SXL, 0))
+    finally:
+        L.active = [L.eigval]
+    return lam, cand
+
+
+def _slots_begin(L, fam, v0, v0_adj):
+    """the eigenvector pair of a single-start iteration into column 0 of the slots (v0_adj None: conj(v0), Householder.jl:84-86)"""
+    d = L.size()
+    fam.slot_write(_SV, np.ones((d, 1), dtype=np.complex128) if v0 is None else np.asarray(v0, dtype=np.complex128).reshape(d, 1))
+    if v0_adj is None:
+        fam.slot_write(_SW, None, ncols_total=1)
+        fam.slot_axpby(_SW, [0], _SV, [0], alpha=1.0, beta=0.0, conj_src=True)
+    else:
+        fam.slot_write(_SW, np.asarray(v0_adj, dtype=np.complex128).reshape(d, 1))
+    fam.slot_write(_SXR, None, ncols_total=1)
+    fam.slot_write(_SXL, None, ncols_total=1)
+
+
+def _slots_finish(L, fam):
+    """`_normalise` (Householder.jl:189-190) on the slots, then the pair back to the host: (v0, v0_adj)"""
+    T = len(L.terms)
+    cM = np.zeros(T, dtype=np.complex128)
+    cM[T - 1] = -1.0
+    nv = fam.slot_forms(cM, _SV, [0], _SV, [0])
+    fam.slot_axpby(_SV, [0], _SV, [0], alpha=1.0 / np.sqrt(nv), beta=0.0)
+    saved = L.active, L.mode
+    L.active, L.mode = [L.eigval], "all"
+    try:
+        cD = np.array([L.coefficients(L.params[L.eigval], 1)])
+    finally:
+        L.active, L.mode = saved
+    dw = fam.slot_forms(cD, _SW, [0], _SV, [0])
+    fam.slot_axpby(_SW, [0], _SW, [0], alpha=1.0 / np.conj(dw), beta=0.0)
+    return fam.slot_read(_SV, 0, 1)[:, 0], fam.slot_read(_SW, 0, 1)[:, 0]
+
+
 def householder(L, z, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, nev=1, v0=None, v0_adj=None, output=False, resident=True):
     """sol, n, flag = householder(L, z; maxiter, tol, relax, lam_tol, order, nev, v0, v0_adj, output)
     (Householder.jl:70-192; flags 1 converged / 0 slow / -1 maxiter / -4 eigs / -6 singular / -5 NaN)
@@ -248,8 +309,10 @@ def householder(L, z, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, n
 
 
 def mslp(L, z, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, nev=1, v0=None, v0_adj=None, num_order=1,
-         scale=1.0, output=False):
-    """sol, n, flag = mslp(L, z; ...)   (iterative_solvers.jl:93-252)"""
+         scale=1.0, output=False, resident=True):
+    """sol, n, flag = mslp(L, z; ...)   (iterative_solvers.jl:93-252)
+    nev = 1 (the default): the eigenvector pair stays in HBM between the Arnoldi processes, the perturbation step and the update
+    (`_aux_step_slots`); resident=False or nev > 1: through host memory (`_aux_step`)."""
     z = complex(z) * scale
     tol = tol * scale
     z0 = complex(np.inf)
@@ -258,14 +321,20 @@ def mslp(L, z, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, nev=1, v
     n = 0
     active, mode = L.active, L.mode
     d = L.size()
-    v0 = np.ones(d, dtype=np.complex128) if v0 is None else np.asarray(v0, dtype=np.complex128)
-    v0_adj = np.conj(v0) if v0_adj is None else np.asarray(v0_adj, dtype=np.complex128)
+    on_dev = bool(resident) and nev == 1
+    if not on_dev:
+        v0 = np.ones(d, dtype=np.complex128) if v0 is None else np.asarray(v0, dtype=np.complex128)
+        v0_adj = np.conj(v0) if v0_adj is None else np.asarray(v0_adj, dtype=np.complex128)
     flag = itsol_converged
     if L.terms[-1].operator != "__aux__":          # iterative_solvers.jl:119-123
         L.push(Term(-sp.identity(d, dtype=np.complex128, format="csr"), (pow1,), (("__aux__",),), "__aux__", "__aux__"))
         L.auxval = "__aux__"
     history = []
     state = {}
+    fam = None
+    if on_dev:
+        fam = L.ensure_solver()                    # (after the push: the family on the device has the aux term)
+        _slots_begin(L, fam, v0, v0_adj)
     try:
         while abs(z - z0) > tol and n < maxiter:
             if output:
@@ -278,7 +347,11 @@ def mslp(L, z, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, nev=1, v
                 pades.append((num, den))
                 roots = poly_roots(num)
                 return roots[np.argsort(np.abs(roots))[0]]
-            lams, v, v_adj, dzs = _aux_step(L, z, order, nev, v0, v0_adj, upd, state)
+            if on_dev:
+                lam1, dz1 = _aux_step_slots(L, fam, z, order, upd, state)
+                lams, dzs = [lam1], [dz1]
+            else:
+                lams, v, v_adj, dzs = _aux_step(L, z, order, nev, v0, v0_adj, upd, state)
             if not np.isinf(z0):
                 back = [lam0 - polyval(num, z0 - z) / polyval(den, z0 - z) for num, den in pades]
                 i = int(np.argsort(np.abs(back))[0])
@@ -289,8 +362,12 @@ def mslp(L, z, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, nev=1, v
             z0 = z
             lam0 = lam
             z = z + relax * dzs[i]
-            v0 = (1 - relax) * v0 + relax * v[:, i]
-            v0_adj = (1 - relax) * v0_adj + relax * v_adj[:, i]
+            if on_dev:
+                fam.slot_axpby(_SV, [0], _SXR, [0], alpha=relax, beta=1.0 - relax)
+                fam.slot_axpby(_SW, [0], _SXL, [0], alpha=relax, beta=1.0 - relax)
+            else:
+                v0 = (1 - relax) * v0 + relax * v[:, i]
+                v0_adj = (1 - relax) * v0_adj + relax * v_adj[:, i]
             n += 1
     except EigsError:
         flag = itsol_arpack_exception
@@ -311,7 +388,7 @@ def mslp(L, z, maxiter=10, tol=0.0, relax=1.0, lam_tol=np.inf, order=1, nev=1, v
         else:
             flag = itsol_impossible
     L.active, L.mode = active, mode
-    v0, v0_adj = _normalise(L, v0, v0_adj)
+    v0, v0_adj = _slots_finish(L, fam) if on_dev else _normalise(L, v0, v0_adj)
     sol = Solution(L.params, v0, v0_adj, L.eigval)
     sol.history = history
     return sol, n, flag
