@@ -38,7 +38,8 @@ __device__ __forceinline__ cplx cdiv(cplx a, cplx b) {
 }
 
 // Long rows (OpDev::long_*, TileDev::ls_*): acc[row][b] = sum over the entries of the row of pc[sys(b)][slot] * val * X[col][b].  A row of
-// the transposed flame term holds one entry per flame node (50 000 at 1M DoF): as ONE workgroup's loop that was 68-74 us per product --
+// the transposed flame term holds one entry per flame node (4 875 at 1M DoF, 48 such rows): as ONE workgroup's loop -- 150 dependent
+// index -> operand round trips per lane -- that was 68-74 us per product:
 // a sixth of an adjoint Krylov step of the Newton-type solvers, whose narrow batches leave the rest of the chip idle meanwhile.  The
 // entries of a row are therefore split over WAE_LONG_SPLIT workgroups per 8-column chunk (32 lanes stride over a piece, 8 lanes across
 // the columns; fixed-order LDS reduction) that write partial sums, and long_reduce_kernel adds the partials in a fixed order.
